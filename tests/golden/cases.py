@@ -1,0 +1,78 @@
+"""Golden-fixture case definitions shared by make_golden.py (reference side) and the tests.
+
+Reference-free: only names, shapes and deterministic-input recipes live here.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle.detfill import det_input, det_ints  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+
+# ---- generator cases: name -> (feature_type, channels, B, T_feat)
+GEN_CASES = {
+    "gen_su_c48": ("SPEECH_UNITS", 48, 3, 5),
+    "gen_su_c96_t12": ("SPEECH_UNITS", 96, 2, 12),
+    "gen_mfcc_c48": ("MFCCS", 48, 2, 6),
+    "gen_su_full_c768": ("SPEECH_UNITS", 768, 1, 3),
+    "gen_su_c48_t1": ("SPEECH_UNITS", 48, 1, 1),         # single-frame edge case (T_emg=16)
+}
+
+# ---- discriminator cases: name -> (small, B, T)
+DISC_CASES = {
+    "disc_small_t192": (True, 2, 192),
+    "disc_small_t64": (True, 3, 64),
+    "disc_small_t400": (True, 1, 400),
+    "disc_full_t192": (False, 1, 192),
+}
+
+# ---- TD-loss cases: name -> (B, T)
+TD_CASES = {"td_t192": (2, 192), "td_t400": (1, 400), "td_t96": (3, 96)}
+
+# ---- encoder cases: name -> (model_size, n_layers, dim_ff, B, T_emg)
+ENC_CASES = {
+    "enc_m64_l2": (64, 2, 128, 2, 192),
+    "enc_m64_l2_long": (64, 2, 128, 1, 1664),             # T_enc=104 > 100 -> -1e8 mask branch
+    "enc_full_t64": (768, 6, 3072, 1, 64),
+}
+
+# ---- train-step cases: name -> (gen channels, enc (model_size, layers, ff), B, T_su, steps)
+STEP_CASES = {"step_c48_b2": (48, (64, 2, 128), 2, 4, 2)}
+
+
+def gen_inputs(name):
+    ft, ch, B, T = GEN_CASES[name]
+    F = 256 if ft == "SPEECH_UNITS" else 25
+    return (det_input(name + ".feats", (B, T, F)), det_ints(name + ".sess", (B,), 17),
+            det_ints(name + ".spk", (B,), 3))
+
+
+def disc_input(name):
+    small, B, T = DISC_CASES[name]
+    return det_input(name + ".x", (B, T, 8), "tanh")
+
+
+def td_inputs(name):
+    B, T = TD_CASES[name]
+    return det_input(name + ".real", (B, T, 8), "tanh"), det_input(name + ".gen", (B, T, 8), "tanh")
+
+
+def enc_inputs(name):
+    ms, nl, ff, B, T = ENC_CASES[name]
+    Te = T // 16
+    return (det_input(name + ".emg", (B, T, 8), "tanh"), det_input(name + ".su", (B, Te, 256)),
+            det_ints(name + ".ph", (B, Te), 48))
+
+
+def step_batch(name, step):
+    ch, enc, B, T, _ = STEP_CASES[name]
+    tag = f"{name}.s{step}"
+    su = det_input(tag + ".su", (B, T, 256))
+    return {"su": su, "feats": su, "x_real": det_input(tag + ".x", (B, 16 * T, 8), "tanh"),
+            "sess": det_ints(tag + ".sess", (B,), 17), "phonemes": det_ints(tag + ".ph", (B, T), 48)}

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Needs /root/reference (read-only; never present on the GPU box -- tests read only the .npz).
+Harness-side shims, no reference file is modified or copied:
+  1. a stub ``omegaconf`` module (the reference imports it only for annotations),
+  2. ``layer.self_attn.batch_first = False`` on the encoder's custom attention so torch 2.10's
+     ``nn.TransformerEncoder.forward`` takes its plain per-layer loop (torch 2.0.1 behaviour).
+Weights come from oracle.detfill (pure function of key + shape) pushed in via load_state_dict,
+inputs from tests/golden/cases.py, so fixtures hold outputs only.
+"""
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+_stub = types.ModuleType("omegaconf")
+
+
+class _DictConfig(dict):
+    __getattr__ = dict.__getitem__
+
+
+_stub.DictConfig = _DictConfig
+_stub.OmegaConf = _DictConfig
+sys.modules["omegaconf"] = _stub
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import ste_gan  # noqa: E402  (reference package)
+from ste_gan.losses.emg_encoder_loss import EMGEncoderLoss  # noqa: E402
+from ste_gan.losses.time_domain_loss import MultiTimeDomainFeatureLoss  # noqa: E402
+from ste_gan.models.discriminator import Discriminator, DiscriminatorSmall  # noqa: E402
+from ste_gan.models.emg_encoder import EMGEncoderTransformer  # noqa: E402
+from ste_gan.models.generator import EMGGeneratorGanTTS  # noqa: E402
+
+import cases  # noqa: E402
+from oracle import shapes as oshapes  # noqa: E402
+from oracle.detfill import det_input, fill_state_dict, shapes_of  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def load_det(module, expect_shapes):
+    got = shapes_of(module.state_dict())
+    assert list(got.items()) == list(expect_shapes.items()), "oracle/shapes.py disagrees with the reference state_dict"
+    module.load_state_dict(fill_state_dict(got))
+    return module
+
+
+def stats(t):
+    t = t.detach().double().flatten()
+    return np.array([t.sum(), t.abs().sum(), (t * t).sum()], np.float64)
+
+
+def head(t, n=8):
+    f = t.detach().flatten()[:n].double().numpy()
+    return np.pad(f, (0, n - len(f)))
+
+
+def grad_summary(named):
+    return (np.array([float(g.double().norm()) for _, g in named], np.float64),
+            np.stack([head(g, 4) for _, g in named]))
+
+
+def make_encoder(ms, nl, ff):
+    # dim_feedforward is hard-wired to 3072 in the reference constructor (emg_encoder.py:62-64);
+    # small cases rebuild the layer stack with a smaller FFN through the same layer class.
+    enc = EMGEncoderTransformer(8, 256, 48, model_size=ms, num_transformer_layers=nl)
+    if ff != 3072:
+        from ste_gan.layers.transformer import TransformerEncoderLayer
+        layer = TransformerEncoderLayer(d_model=ms, nhead=8, relative_positional=True,
+                                        relative_positional_distance=100, dim_feedforward=ff, dropout=0.2)
+        enc.transformer = torch.nn.TransformerEncoder(layer, nl)
+    for layer in enc.transformer.layers:
+        layer.self_attn.batch_first = False          # shim 2
+    enc = load_det(enc, oshapes.encoder_shapes(ms, 3, nl, dim_feedforward=ff))
+    return enc.eval()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB  " + " ".join(f"{k}{tuple(np.shape(v))}" for k, v in arrs.items()))
+
+
+# ----------------------------------------------------------------------------------------------
+def gen_cases():
+    for name, (ft, ch, B, T) in cases.GEN_CASES.items():
+        g = EMGGeneratorGanTTS(ft, 256 if ft == "SPEECH_UNITS" else 25, 17, 8, channels=ch)
+        load_det(g, oshapes.generator_shapes(ft, ch))
+        feats, sess, spk = cases.gen_inputs(name)
+        g.train()
+        out = g(feats, sess, spk)
+        probe = det_input(name + ".probe", out.shape)
+        (out * probe).sum().backward()
+        gn, gh = grad_summary([(k, p.grad) for k, p in g.named_parameters()])
+        with torch.inference_mode():
+            out_gen = g.generate(feats, sess, spk)
+        assert torch.equal(out_gen, out.detach())
+        save(name, out=out.detach().numpy(), grad_norm=gn, grad_head=gh)
+
+
+def disc_cases():
+    for name, (small, B, T) in cases.DISC_CASES.items():
+        d = (DiscriminatorSmall if small else Discriminator)(8)
+        load_det(d, oshapes.discriminator_shapes(small))
+        x = cases.disc_input(name).requires_grad_(True)
+        out1 = d(x)
+        loss = 0
+        for sc in out1:
+            loss = loss + F.mse_loss(sc[-1], torch.ones_like(sc[-1]))
+            for fm in sc[:-1]:
+                loss = loss + fm.abs().mean()
+        loss.backward()
+        gn, gh = grad_summary([(k, p.grad) for k, p in d.named_parameters()])
+        out2 = d(x.detach())
+        sd = d.state_dict()
+        sn = {k: sd[k].numpy() for k in sd if k.endswith("weight_u") or (k.endswith("weight_v") and k[:-1] + "u" in sd)}
+        save(name,
+             logits1=np.concatenate([sc[-1].detach().flatten().numpy() for sc in out1]),
+             logits2=np.concatenate([sc[-1].detach().flatten().numpy() for sc in out2]),
+             fmap_shapes=np.array([list(fm.shape) + [0] * (4 - fm.dim()) for sc in out1 for fm in sc], np.int64),
+             fmap_stats=np.stack([stats(fm) for sc in out1 for fm in sc]),
+             fmap_head=np.stack([head(fm) for sc in out1 for fm in sc]),
+             loss=np.float64(loss.item()), dx=x.grad.numpy(), grad_norm=gn, grad_head=gh,
+             **{"sn." + k: v for k, v in sn.items()})
+
+
+def td_cases():
+    for name, (B, T) in cases.TD_CASES.items():
+        m = MultiTimeDomainFeatureLoss(8)
+        xr, xg = cases.td_inputs(name)
+        xg = xg.requires_grad_(True)
+        loss, vals = m.time_domain_loss(xr, xg)
+        loss.backward()
+        feats0 = m.time_domain_losses[0].calculate_time_domain_features(xr)
+        save(name, loss=np.float64(loss.item()), scale_losses=np.array([v.item() for v in vals], np.float64),
+             dx=xg.grad.numpy(), feats0=feats0.detach().numpy())
+
+
+def enc_cases():
+    for name, (ms, nl, ff, B, T) in cases.ENC_CASES.items():
+        enc = make_encoder(ms, nl, ff)
+        emg, su, ph = cases.enc_inputs(name)
+        emg = emg.requires_grad_(True)
+        lossmod = EMGEncoderLoss(enc)
+        out = lossmod(emg, su, ph)
+        (out.speech_unit_loss + out.phoneme_loss).backward()
+        save(name, su_pred=out.speech_unit_pred.detach().numpy(), ph_pred=out.phoneme_pred.detach().numpy(),
+             su_loss=np.float64(out.speech_unit_loss.item()), ph_loss=np.float64(out.phoneme_loss.item()),
+             counters=np.array([out.num_phones, out.num_silence_phones, out.num_correct_phones,
+                                out.num_correct_phones_no_silence], np.int64),
+             argmax=out.phoneme_pred.argmax(-1).numpy(), demg=emg.grad.numpy())
+
+
+def step_cases():
+    """Restatement of ste_gan/train.py:165-268 over the reference modules (train.py itself needs
+    omegaconf + tensorboard and a dataset).  CPU: autocast/GradScaler are no-ops."""
+    for name, (ch, (ms, nl, ff), B, T, steps) in cases.STEP_CASES.items():
+        netG = load_det(EMGGeneratorGanTTS("SPEECH_UNITS", 256, 17, 8, channels=ch),
+                        oshapes.generator_shapes("SPEECH_UNITS", ch))
+        netD = load_det(DiscriminatorSmall(8), oshapes.discriminator_shapes(True))
+        enc = make_encoder(ms, nl, ff)
+        multi_td = MultiTimeDomainFeatureLoss(8)
+        enc_loss = EMGEncoderLoss(enc)
+        optG = ste_gan.OPTIMIZER(netG.parameters())
+        optD = ste_gan.OPTIMIZER(netD.parameters())
+        rec = {}
+        for step in range(steps):
+            b = cases.step_batch(name, step)
+            netD.zero_grad(); netG.zero_grad()
+            netG.train()
+            x_t = b["x_real"]
+            x_pred = netG(b["feats"], b["sess"], torch.zeros_like(b["sess"]))
+            D_fake_det = netD(x_pred.detach())
+            D_real = netD(x_t)
+            loss_D = 0
+            for sc in D_fake_det:
+                loss_D += F.mse_loss(sc[-1], torch.zeros_like(sc[-1]))
+            for sc in D_real:
+                loss_D += F.mse_loss(sc[-1], torch.ones_like(sc[-1]))
+            loss_D.backward()
+            d_gn, d_gh = grad_summary([(k, p.grad) for k, p in netD.named_parameters()])
+            optD.step()
+            loss_G = 0
+            D_fake = netD(x_pred)
+            D_real = netD(x_t)
+            adv = 0
+            for sc in D_fake:
+                adv += F.mse_loss(sc[-1], torch.ones_like(sc[-1]))
+            loss_G += adv
+            td = multi_td(x_t, x_pred)
+            loss_G += 15.0 * td
+            eo = enc_loss(x_pred, b["su"], b["phonemes"])
+            loss_G += 1.0 * eo.speech_unit_loss
+            loss_G += 1.0 * eo.phoneme_loss
+            fm = 0
+            for i in range(len(D_fake)):
+                for j in range(len(D_fake[i]) - 1):
+                    fm += F.l1_loss(D_fake[i][j], D_real[i][j].detach())
+            loss_G += 7.0 * fm
+            loss_G.backward()
+            g_gn, g_gh = grad_summary([(k, p.grad) for k, p in netG.named_parameters()])
+            optG.step()
+            tag = f"s{step}."
+            rec[tag + "losses"] = np.array([loss_D.item(), loss_G.item(), adv.item(), td.item(),
+                                            eo.speech_unit_loss.item(), eo.phoneme_loss.item(), fm.item()], np.float64)
+            rec[tag + "counters"] = np.array([eo.num_phones, eo.num_silence_phones, eo.num_correct_phones,
+                                              eo.num_correct_phones_no_silence], np.int64)
+            rec[tag + "x_pred"] = x_pred.detach().numpy()
+            rec[tag + "g_grad_norm"], rec[tag + "g_grad_head"] = g_gn, g_gh
+            rec[tag + "d_grad_norm"], rec[tag + "d_grad_head"] = d_gn, d_gh
+            rec[tag + "g_param_norm"], rec[tag + "g_param_head"] = grad_summary(list(netG.state_dict().items()))
+            rec[tag + "d_param_norm"], rec[tag + "d_param_head"] = grad_summary(list(netD.state_dict().items()))
+        save(name, **rec)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gen", "disc", "td", "enc", "step"]
+    for w in which:
+        {"gen": gen_cases, "disc": disc_cases, "td": td_cases, "enc": enc_cases, "step": step_cases}[w]()
+    leaked = [os.path.join(dp, d) for dp, dn, _ in os.walk("/root/reference") for d in dn if d == "__pycache__"]
+    assert not leaked, f"__pycache__ written into the reference tree: {leaked}"

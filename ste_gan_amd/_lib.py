@@ -1,0 +1,75 @@
+"""ctypes binding of libstegan_hip.so (the C ABI declared in include/stegan_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a kernel returns a
+non-zero status, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstegan_hip.so")
+ABI_VERSION = 1
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "B", "Cin", "Cout", "groups", "K", "stride", "dilation", "pad", "Tin", "Tout",
+        "upsample", "in_act", "out_act", "out_btc")]
+
+
+_P = C.c_void_p
+_I32 = C.c_int32
+_I64 = C.c_int64
+_D = C.POINTER(ConvDesc)
+
+# name -> argtypes; every symbol declared in include/stegan_hip.h must be listed here
+SIGNATURES = {
+    "stegan_abi_version": [],
+    "stegan_selftest_host": [],
+    "stegan_conv1d_fwd": [_D, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_data": [_D, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_weight": [_D, _P, _P, _P, _P, _P],
+    "stegan_wn_scales": [_I32, _P, _P, _P, _P, _P, _I32, _P],
+    "stegan_wn_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
+    "stegan_wn_scale1": [_P, _P, _P, _I32, _I32, _P],
+    "stegan_wn_backward1": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
+}
+
+_lib = None
+
+
+class SteganHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SteganHipError(
+                f"{LIB_PATH} is missing: build it with `python -m ste_gan_amd.build` "
+                "(ste_gan_amd has no CPU / eager fallback)")
+        handle = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the .so does not export it
+            fn.argtypes = args
+            fn.restype = C.c_int
+        if handle.stegan_abi_version() != ABI_VERSION:
+            raise SteganHipError("libstegan_hip.so ABI version mismatch: rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status == 0:
+        return
+    if status == -1:
+        # same class the reference surfaces for bad shapes (ATen raises RuntimeError)
+        raise RuntimeError(f"{what}: invalid argument or unsupported shape")
+    raise SteganHipError(f"{what}: HIP error {status}")

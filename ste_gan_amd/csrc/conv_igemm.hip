@@ -1,0 +1,361 @@
+// Direct 1-D convolution as an implicit GEMM on the fp32 matrix cores of gfx950.
+//
+//   C[m][n] = sum_r A[m][r] * B[r][n]
+//
+//   mode        m          n            r (reduction)      A                    B
+//   FWD         co         (b, t_out)   (ci, k)            w[co][ci][k]         act(up(x))[b][ci][t*s+k*d-p]
+//   BWD_DATA    ci         (b, t_eff)   (co, k)            w[co][ci][k]         scale[co]*dy[b][co][(t+p-k*d)/s]
+//   BWD_WEIGHT  co         (ci, k)      (b, t_out)         dy[b][co][t]         act(up(x))[b][ci][t*s+k*d-p]
+//
+// The im2col matrix never exists in HBM: every block gathers its B tile straight from the
+// (B,C,T) activation into LDS (zero padding, dilation, stride, nearest-x2 upsample, the input
+// ReLU and dead-tap skipping are all resolved in that gather), stages the weight tile next to
+// it, and four wave64s run v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) over the LDS tiles.
+// Weight-norm / spectral-norm / BatchNorm factors enter as a per-output-channel scale in the
+// epilogue (FWD) or on the dy operand (BWD_DATA), so normalised weights are never written out.
+//
+// Tile: block = 256 threads = 2x2 waves, wave tile = (32*TM) x (32*TN), K-chunk = 32.
+// LDS image: [r][m] and [r][n] with +1 padding; operand reads are ds_read_b32 with the 32 lanes
+// of each half-wave on consecutive dwords (conflict-free), lanes 32-63 on the next r row, which
+// is exactly the A[i=l&31][k=l>>5] / B[k=l>>5][j=l&31] operand map of the 32x32x2 MFMA.
+#include "common.h"
+
+namespace {
+
+enum { MODE_FWD = 0, MODE_BWD_DATA = 1, MODE_BWD_WEIGHT = 2 };
+constexpr int KC = 32;
+
+struct ConvK {
+    const float* x;      // FWD/BWD_WEIGHT: conv input (B,Cin,Tin).  BWD_DATA: unused
+    const float* w;      // (Cout, Cin_g, K) raw direction tensor
+    const float* dy;     // BWD_*: (B,Cout,Tout)
+    const float* scale;  // (Cout) or null
+    const float* bias;   // (Cout) or null           (FWD)
+    const float* res;    // residual / add_src or null
+    const float* mask;   // BWD_DATA: pre-activation input (B,Cin,Tin) or null
+    float* out;          // FWD: y, BWD_DATA: dx (B,Cin,Te), BWD_WEIGHT: dw (atomic accumulate)
+    int B, Cin, Cout, K, stride, dil, pad, Tin, Tout, Te, ups;  // ups = log2(upsample)
+    int in_act, out_act, out_btc;
+    int Cin_g, Cout_g;
+    int k_lo, K_eff;     // live tap range: taps outside it only ever see zero padding
+    int M, N, R;         // GEMM extents per group
+    int m_tiles;         // M tiles per group
+    int r_chunks_per_split;
+    FastDiv fdK;         // / K_eff
+    FastDiv fdT;         // / Tout (FWD, BWD_WEIGHT) or / Te (BWD_DATA)
+    FastDiv fdS;         // / stride
+};
+
+template <int MODE>
+__device__ __forceinline__ float load_a(const ConvK& p, int g, int m, int r) {
+    // m, r are group-local indices; caller guarantees nothing -> predicate here
+    if (m >= p.M || r >= p.R) return 0.f;
+    if (MODE == MODE_FWD) {
+        uint32_t ci, ke;
+        fd_divmod((uint32_t)r, p.fdK, ci, ke);
+        return p.w[((size_t)(g * p.Cout_g + m) * p.Cin_g + ci) * p.K + ke + p.k_lo];
+    } else if (MODE == MODE_BWD_DATA) {
+        uint32_t co, ke;
+        fd_divmod((uint32_t)r, p.fdK, co, ke);
+        return p.w[((size_t)(g * p.Cout_g + co) * p.Cin_g + m) * p.K + ke + p.k_lo];
+    } else {
+        uint32_t b, t;
+        fd_divmod((uint32_t)r, p.fdT, b, t);
+        return p.dy[((size_t)b * p.Cout + g * p.Cout_g + m) * p.Tout + t];
+    }
+}
+
+// gather of the (activated, upsampled, zero padded) conv input for channel ci (group local), tap index ke
+__device__ __forceinline__ float gather_x(const ConvK& p, int g, uint32_t b, uint32_t t, uint32_t ci, uint32_t ke) {
+    int tin = (int)t * p.stride + (int)(ke + p.k_lo) * p.dil - p.pad;
+    if (tin < 0 || tin >= p.Te) return 0.f;
+    float v = p.x[((size_t)b * p.Cin + g * p.Cin_g + ci) * p.Tin + (tin >> p.ups)];
+    if (p.in_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
+    return v;
+}
+
+template <int MODE>
+__device__ __forceinline__ float load_b(const ConvK& p, int g, int r, int n) {
+    if (r >= p.R || n >= p.N) return 0.f;
+    if (MODE == MODE_FWD) {
+        uint32_t ci, ke, b, t;
+        fd_divmod((uint32_t)r, p.fdK, ci, ke);
+        fd_divmod((uint32_t)n, p.fdT, b, t);
+        return gather_x(p, g, b, t, ci, ke);
+    } else if (MODE == MODE_BWD_DATA) {
+        uint32_t co, ke, b, te;
+        fd_divmod((uint32_t)r, p.fdK, co, ke);
+        fd_divmod((uint32_t)n, p.fdT, b, te);
+        int tt = (int)te + p.pad - (int)(ke + p.k_lo) * p.dil;
+        if (tt < 0) return 0.f;
+        uint32_t q, rem;
+        fd_divmod((uint32_t)tt, p.fdS, q, rem);
+        if (rem != 0 || (int)q >= p.Tout) return 0.f;
+        int cog = g * p.Cout_g + co;
+        float v = p.dy[((size_t)b * p.Cout + cog) * p.Tout + q];
+        if (p.scale) v *= p.scale[cog];
+        return v;
+    } else {
+        uint32_t ci, ke, b, t;
+        fd_divmod((uint32_t)n, p.fdK, ci, ke);
+        fd_divmod((uint32_t)r, p.fdT, b, t);
+        return gather_x(p, g, b, t, ci, ke);
+    }
+}
+
+template <int MODE, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    // staging thread maps: "r fast" = lanes along r (global contiguity along r), else along m / n
+    constexpr bool A_RFAST = (MODE != MODE_BWD_DATA);
+    constexpr bool B_RFAST = (MODE == MODE_BWD_WEIGHT);
+    constexpr int A_PER = KC * BM / 256;
+    constexpr int B_PER = KC * BN / 256;
+
+    __shared__ float lds[KC * LDA + KC * LDB];
+    float* As = lds;
+    float* Bs = lds + KC * LDA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN;
+    const int g = blockIdx.y / p.m_tiles;
+    const int m0 = (blockIdx.y % p.m_tiles) * BM;
+
+    int chunk_lo = 0, chunk_hi = (p.R + KC - 1) / KC;
+    if (MODE == MODE_BWD_WEIGHT) {
+        chunk_lo = blockIdx.z * p.r_chunks_per_split;
+        chunk_hi = min(chunk_hi, chunk_lo + p.r_chunks_per_split);
+        if (chunk_lo >= chunk_hi) return;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[A_PER], rb[B_PER];
+
+    auto load_chunk = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int m, r;
+            if (A_RFAST) { r = tid & 31; m = (tid >> 5) + 8 * i; }
+            else         { m = tid % BM; r = tid / BM + (256 / BM) * i; }
+            ra[i] = load_a<MODE>(p, g, m0 + m, r0 + r);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            int n, r;
+            if (B_RFAST) { r = tid & 31; n = (tid >> 5) + 8 * i; }
+            else         { n = tid % BN; r = tid / BN + (256 / BN) * i; }
+            rb[i] = load_b<MODE>(p, g, r0 + r, n0 + n);
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            int m, r;
+            if (A_RFAST) { r = tid & 31; m = (tid >> 5) + 8 * i; }
+            else         { m = tid % BM; r = tid / BM + (256 / BM) * i; }
+            As[r * LDA + m] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            int n, r;
+            if (B_RFAST) { r = tid & 31; n = (tid >> 5) + 8 * i; }
+            else         { n = tid % BN; r = tid / BN + (256 / BN) * i; }
+            Bs[r * LDB + n] = rb[i];
+        }
+    };
+
+    load_chunk(chunk_lo * KC);
+    for (int c = chunk_lo; c < chunk_hi; ++c) {
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < chunk_hi) load_chunk((c + 1) * KC);   // global loads in flight under the MFMAs
+        const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll 4
+        for (int kk = 0; kk < KC; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[(kk + half) * LDA + (wm * TM + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + half) * LDB + (wn * TN + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + l31;
+        if (n >= p.N) continue;
+        uint32_t q0, q1;   // FWD/BWD_DATA: (b, t)   BWD_WEIGHT: (ci, ke)
+        fd_divmod((uint32_t)n, (MODE == MODE_BWD_WEIGHT) ? p.fdK : p.fdT, q0, q1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m >= p.M) continue;
+                float v = acc[i][j][e];
+                if (MODE == MODE_FWD) {
+                    const int co = g * p.Cout_g + m;
+                    if (p.scale) v *= p.scale[co];
+                    if (p.bias) v += p.bias[co];
+                    const size_t idx = ((size_t)q0 * p.Cout + co) * p.Tout + q1;
+                    if (p.res) v += p.res[idx];
+                    if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+                    else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
+                    if (p.out_btc) p.out[((size_t)q0 * p.Tout + q1) * p.Cout + co] = v;
+                    else p.out[idx] = v;
+                } else if (MODE == MODE_BWD_DATA) {
+                    const int ci = g * p.Cin_g + m;
+                    if (p.mask) {
+                        const float xv = p.mask[((size_t)q0 * p.Cin + ci) * p.Tin + (q1 >> p.ups)];
+                        if (!(xv > 0.f)) v = 0.f;
+                    }
+                    const size_t idx = ((size_t)q0 * p.Cin + ci) * p.Te + q1;
+                    if (p.res) v += p.res[idx];
+                    p.out[idx] = v;
+                } else {
+                    atomicAdd(&p.out[((size_t)(g * p.Cout_g + m) * p.Cin_g + q0) * p.K + q1 + p.k_lo], v);
+                }
+            }
+        }
+    }
+}
+
+// db[c] += sum_{b,t} dy[b,c,t] : one block per channel
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
+                                                        int B, int C, int T) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* row = dy + ((size_t)b * C + c) * T;
+        for (int t = threadIdx.x; t < T; t += 256) s += row[t];
+    }
+    __shared__ float part[4];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
+}
+
+int fill_common(const stegan_conv_desc* d, ConvK& p) {
+    STEGAN_CHECK_ARG(d != nullptr);
+    STEGAN_CHECK_ARG(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->groups > 0 && d->K > 0);
+    STEGAN_CHECK_ARG(d->Cin % d->groups == 0 && d->Cout % d->groups == 0);
+    STEGAN_CHECK_ARG(d->stride >= 1 && d->dilation >= 1 && d->pad >= 0 && d->Tin > 0);
+    STEGAN_CHECK_ARG(d->upsample == 1 || d->upsample == 2);
+    STEGAN_CHECK_ARG(d->in_act == STEGAN_ACT_NONE || d->in_act == STEGAN_ACT_RELU);
+    const int Te = d->Tin * d->upsample;
+    const int span = Te + 2 * d->pad - d->dilation * (d->K - 1) - 1;
+    STEGAN_CHECK_ARG(span >= 0);
+    STEGAN_CHECK_ARG(d->Tout == span / d->stride + 1);
+    STEGAN_CHECK_ARG((int64_t)d->B * (d->Cin > d->Cout ? d->Cin : d->Cout) * (Te > d->Tout ? Te : d->Tout) < (1ll << 31));
+    p.B = d->B; p.Cin = d->Cin; p.Cout = d->Cout; p.K = d->K; p.stride = d->stride; p.dil = d->dilation;
+    p.pad = d->pad; p.Tin = d->Tin; p.Tout = d->Tout; p.Te = Te; p.ups = d->upsample == 2 ? 1 : 0;
+    p.in_act = d->in_act; p.out_act = d->out_act; p.out_btc = d->out_btc;
+    p.Cin_g = d->Cin / d->groups; p.Cout_g = d->Cout / d->groups;
+    // live taps: tap k touches real data for some t_out iff  [k*d - pad, (Tout-1)*s + k*d - pad] meets [0, Te)
+    int k_lo = d->K, k_hi = -1;
+    for (int k = 0; k < d->K; ++k) {
+        const int lo = k * d->dilation - d->pad, hi = (d->Tout - 1) * d->stride + lo;
+        if (hi >= 0 && lo < Te) { if (k < k_lo) k_lo = k; k_hi = k; }
+    }
+    STEGAN_CHECK_ARG(k_hi >= k_lo);
+    p.k_lo = k_lo; p.K_eff = k_hi - k_lo + 1;
+    p.fdK = make_fastdiv((uint32_t)p.K_eff);
+    p.fdS = make_fastdiv((uint32_t)d->stride);
+    p.r_chunks_per_split = 1 << 30;
+    p.x = p.w = p.dy = p.scale = p.bias = p.res = p.mask = nullptr;
+    p.out = nullptr;
+    return STEGAN_OK;
+}
+
+template <int MODE>
+int launch(const ConvK& p, int groups, int splits, hipStream_t s) {
+    // tile choice: 128x128 when that still gives every CU >= 2 blocks, else 64x64
+    const long tiles128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * groups * splits;
+    ConvK q = p;
+    if (tiles128 >= 512 && p.M >= 96) {
+        q.m_tiles = ceil_div(p.M, 128);
+        dim3 grid(ceil_div(p.N, 128), q.m_tiles * groups, splits);
+        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, q);
+    } else {
+        q.m_tiles = ceil_div(p.M, 64);
+        dim3 grid(ceil_div(p.N, 64), q.m_tiles * groups, splits);
+        hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1, 1>), grid, dim3(256), 0, s, q);
+    }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+}  // namespace
+
+extern "C" int stegan_conv1d_fwd(const stegan_conv_desc* d, const float* x, const float* w, const float* scale,
+                                 const float* bias, const float* residual, float* y, void* stream) {
+    ConvK p;
+    int rc = fill_common(d, p);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(x && w && y);
+    STEGAN_CHECK_ARG(d->out_act == STEGAN_ACT_NONE || d->out_act == STEGAN_ACT_LRELU || d->out_act == STEGAN_ACT_TANH);
+    STEGAN_CHECK_ARG(!(d->out_btc && residual));
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.out = y;
+    p.M = p.Cout_g; p.N = d->B * d->Tout; p.R = p.Cin_g * p.K_eff;
+    p.fdT = make_fastdiv((uint32_t)d->Tout);
+    return launch<MODE_FWD>(p, d->groups, 1, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
+                                      const float* mask_src, const float* add_src, float* dx, void* stream) {
+    ConvK p;
+    int rc = fill_common(d, p);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(dy && w && dx);
+    STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mask_src);
+    p.dy = dy; p.w = w; p.scale = scale; p.res = add_src; p.out = dx;
+    p.mask = d->in_act == STEGAN_ACT_RELU ? mask_src : nullptr;
+    p.M = p.Cin_g; p.N = d->B * p.Te; p.R = p.Cout_g * p.K_eff;
+    p.fdT = make_fastdiv((uint32_t)p.Te);
+    return launch<MODE_BWD_DATA>(p, d->groups, 1, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                        float* db, void* stream) {
+    ConvK p;
+    int rc = fill_common(d, p);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(x && dy && dw);
+    p.x = x; p.dy = dy; p.out = dw;
+    p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout;
+    p.fdT = make_fastdiv((uint32_t)d->Tout);
+    // split the (b,t) reduction so the grid fills the chip; partial sums meet in fp32 atomics
+    const int chunks = ceil_div(p.R, KC);
+    const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * d->groups;
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    p.r_chunks_per_split = ceil_div(chunks, splits);
+    splits = ceil_div(chunks, p.r_chunks_per_split);
+    rc = launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
+    if (rc) return rc;
+    if (db) {
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, db, d->B, d->Cout, d->Tout);
+        STEGAN_LAUNCH_CHECK();
+    }
+    return STEGAN_OK;
+}

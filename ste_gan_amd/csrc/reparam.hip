@@ -1,0 +1,136 @@
+// Weight re-parametrisation kernels (weight norm; multi-tensor: one launch covers a whole network).
+#include "common.h"
+
+namespace {
+
+// one wave per row: scale[row] = g[row] / ||v[row,:]||
+__device__ __forceinline__ void wn_scale_row(const float* v, const float* g, float* scale, int row, int C) {
+    const int lane = threadIdx.x & 63;
+    const float* vr = v + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { float a = vr[c]; s += a * a; }
+    s = wave_sum(s);
+    if (lane == 0) scale[row] = g[row] / sqrtf(s);
+}
+
+// one wave per row: ds = <dw,v>; dg = ds/||v||; dv = (g/||v||) dw - (ds g/||v||^3) v
+__device__ __forceinline__ void wn_backward_row(const float* v, const float* g, const float* dw, float* dv,
+                                                float* dg, int row, int C) {
+    const int lane = threadIdx.x & 63;
+    const float* vr = v + (size_t)row * C;
+    const float* dwr = dw + (size_t)row * C;
+    float* dvr = dv + (size_t)row * C;
+    float nn = 0.f, dot = 0.f;
+    for (int c = lane; c < C; c += 64) { float a = vr[c]; nn += a * a; dot += a * dwr[c]; }
+    nn = wave_sum(nn);
+    dot = wave_sum(dot);
+    const float inv = 1.f / sqrtf(nn);
+    const float gv = g[row];
+    const float s = gv * inv;
+    const float k = dot * gv * inv * inv * inv;
+    for (int c = lane; c < C; c += 64) dvr[c] = s * dwr[c] - k * vr[c];
+    if (lane == 0) dg[row] = dot * inv;
+}
+
+__global__ __launch_bounds__(256) void wn_scales_kernel(int n, const float* const* v, const float* const* g,
+                                                        float* const* scale, const int* rows, const int* cols) {
+    const int ti = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ti >= n || row >= rows[ti]) return;
+    wn_scale_row(v[ti], g[ti], scale[ti], row, cols[ti]);
+}
+
+__global__ __launch_bounds__(256) void wn_scale1_kernel(const float* v, const float* g, float* scale, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    wn_scale_row(v, g, scale, row, cols);
+}
+
+__global__ __launch_bounds__(256) void wn_backward_kernel(int n, const float* const* v, const float* const* g,
+                                                          const float* const* dw, float* const* dv, float* const* dg,
+                                                          const int* rows, const int* cols) {
+    const int ti = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ti >= n || row >= rows[ti]) return;
+    wn_backward_row(v[ti], g[ti], dw[ti], dv[ti], dg[ti], row, cols[ti]);
+}
+
+__global__ __launch_bounds__(256) void wn_backward1_kernel(const float* v, const float* g, const float* dw, float* dv,
+                                                           float* dg, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    wn_backward_row(v, g, dw, dv, dg, row, cols);
+}
+
+__global__ __launch_bounds__(256) void fold_upsample2_kernel(const float* __restrict__ dxe, float* __restrict__ dx,
+                                                             long total) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const float2 v = reinterpret_cast<const float2*>(dxe)[i];
+        dx[i] = v.x + v.y;
+    }
+}
+
+}  // namespace
+
+extern "C" int stegan_wn_scales(int32_t n, const float* const* v, const float* const* g, float* const* scale,
+                                const int32_t* rows, const int32_t* cols, int32_t max_rows, void* stream) {
+    STEGAN_CHECK_ARG(n > 0 && v && g && scale && rows && cols && max_rows > 0);
+    hipLaunchKernelGGL(wn_scales_kernel, dim3(ceil_div(max_rows, 4), n), dim3(256), 0, (hipStream_t)stream, n, v, g,
+                       scale, rows, cols);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_wn_backward(int32_t n, const float* const* v, const float* const* g, const float* const* dw,
+                                  float* const* dv, float* const* dg, const int32_t* rows, const int32_t* cols,
+                                  int32_t max_rows, void* stream) {
+    STEGAN_CHECK_ARG(n > 0 && v && g && dw && dv && dg && rows && cols && max_rows > 0);
+    hipLaunchKernelGGL(wn_backward_kernel, dim3(ceil_div(max_rows, 4), n), dim3(256), 0, (hipStream_t)stream, n, v, g,
+                       dw, dv, dg, rows, cols);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_wn_scale1(const float* v, const float* g, float* scale, int32_t rows, int32_t cols, void* stream) {
+    STEGAN_CHECK_ARG(v && g && scale && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(wn_scale1_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, v, g, scale, rows, cols);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_wn_backward1(const float* v, const float* g, const float* dw, float* dv, float* dg,
+                                   int32_t rows, int32_t cols, void* stream) {
+    STEGAN_CHECK_ARG(v && g && dw && dv && dg && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(wn_backward1_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, v, g, dw, dv, dg,
+                       rows, cols);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(dxe && dx && rows > 0 && T > 0);
+    const long total = (long)rows * T;   // T = folded (output) length; dxe rows have 2T floats, 8-byte aligned pairs
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(fold_upsample2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxe, dx, total);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_abi_version(void) { return STEGAN_ABI_VERSION; }
+
+extern "C" int stegan_selftest_host(void) {
+    // magic division must be exact for every divisor / dividend range the kernels use
+    for (uint32_t d = 1; d <= 4200; ++d) {
+        FastDiv f = make_fastdiv(d);
+        for (uint32_t n = 0; n < 70000; n += (n < 5000 ? 1 : 97)) {
+            if (fd_div(n, f) != n / d) return 1;
+        }
+        const uint32_t big[] = {(1u << 24) - 1, (1u << 24), (1u << 30) + 12345u, 0x7fffffffu};
+        for (uint32_t n : big)
+            if (fd_div(n, f) != n / d) return 2;
+    }
+    return 0;
+}

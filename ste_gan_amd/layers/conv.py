@@ -1,0 +1,101 @@
+"""Convolution layers of the generator / discriminators, host side.
+
+Mirrors ``ste_gan/layers/conv.py`` (WNConv1d :16-17, get_padding :24-25, GBlock :29-84,
+NormedConv1d/2d :89-101) but every layer is ONE fused launch of the implicit-GEMM kernel
+(ste_gan_amd/csrc/conv_igemm.hip): the ReLU / nearest-x2 upsample in front of a conv, the
+weight-norm factor, bias, residual add and output activation are folded into it.
+Parameter names and shapes equal the reference's old-style ``weight_norm`` layout
+(``weight_g`` (Cout,1,1), ``weight_v`` (Cout,Cin/groups,K), ``bias``) so checkpoints interchange.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import replace
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH
+
+
+def get_padding(kernel_size, dilation=1):
+    """"same" padding for odd kernels -- ste_gan/layers/conv.py:24-25."""
+    return int((kernel_size * dilation - dilation) / 2)
+
+
+class WNConv1d(nn.Module):
+    """Weight-normalised Conv1d (old-style ``weight_norm``: parameters weight_g / weight_v / bias).
+
+    Extra keyword arguments describe what is fused around the convolution:
+    ``in_act`` (ReLU on the input), ``upsample`` (nearest x2 on the input), ``out_act``
+    (leaky_relu(0.1) / tanh on the output), ``out_btc`` (store (B,T,C)).  ``kernel_dims`` = 2
+    keeps the trailing singleton of the reference's (k,1) Conv2d weights in the state dict.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 in_act=ACT_NONE, upsample=1, out_act=ACT_NONE, out_btc=False, kernel_dims=1):
+        super().__init__()
+        self.cfg = ops.ConvCfg(in_channels, out_channels, kernel_size, stride, dilation, padding, groups,
+                               upsample, in_act, out_act, out_btc)
+        kshape = (kernel_size,) + (1,) * (kernel_dims - 1)
+        v = torch.empty(out_channels, in_channels // groups, *kshape)
+        # same initial distribution as nn.Conv1d.reset_parameters + weight_norm (g = ||v||)
+        nn.init.kaiming_uniform_(v, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(v[0].numel())
+        self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, *([1] * kernel_dims)))
+        self.weight_v = nn.Parameter(v)
+
+    def forward(self, x, residual=None):
+        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg)
+
+    def extra_repr(self):
+        return str(self.cfg)
+
+
+class _Slot(nn.Module):
+    """Parameter-free placeholder keeping nn.Sequential indices equal to the reference's
+    (its ReLU / Upsample modules are fused into the neighbouring conv launch here)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return f"{self.what} (fused into the next conv launch)"
+
+
+class GBlock(nn.Module):
+    """GAN-TTS residual block -- ste_gan/layers/conv.py:29-84.
+
+    y = conv_d3(relu(conv_d1(up(relu(x))))) + conv1x1(up(x));  out = y + conv_d27(relu(conv_d9(relu(y)))).
+    Five fused launches; the two residual adds ride in the epilogues of conv_d3 / conv_d27.
+    Sequential indices (conv1.1/.3 or .2/.4, res1.0 or .1, conv2.1/.3) match the reference.
+    """
+
+    def __init__(self, input_dim, output_dim, upsample=1, kernel_size=3):
+        super().__init__()
+        k = kernel_size
+        up = upsample if upsample > 1 else 1
+        c1 = [_Slot("ReLU")] + ([_Slot("Upsample")] if upsample > 1 else [])
+        c1 += [WNConv1d(input_dim, output_dim, k, padding=get_padding(k), in_act=ACT_RELU, upsample=up),
+               _Slot("ReLU"),
+               WNConv1d(output_dim, output_dim, k, dilation=3, padding=get_padding(k, 3), in_act=ACT_RELU)]
+        r1 = ([_Slot("Upsample")] if upsample > 1 else []) + [WNConv1d(input_dim, output_dim, 1, upsample=up)]
+        c2 = [_Slot("ReLU"),
+              WNConv1d(output_dim, output_dim, k, dilation=9, padding=get_padding(k, 9), in_act=ACT_RELU),
+              _Slot("ReLU"),
+              WNConv1d(output_dim, output_dim, k, dilation=27, padding=get_padding(k, 27), in_act=ACT_RELU)]
+        self.conv1 = nn.Sequential(*c1)
+        self.res1 = nn.Sequential(*r1)
+        self.conv2 = nn.Sequential(*c2)
+        self._o = 1 if upsample > 1 else 0
+
+    def forward(self, x):
+        o = self._o
+        h = self.conv1[1 + o](x)
+        r = self.res1[o](x)
+        y = self.conv1[3 + o](h, residual=r)
+        h = self.conv2[1](y)
+        return self.conv2[3](h, residual=y)

@@ -115,6 +115,79 @@ int stegan_wn_backward(int32_t n, const float* const* v, const float* const* g, 
 int stegan_wn_backward1(const float* v, const float* g, const float* dw, float* dv, float* dg,
                         int32_t rows, int32_t cols, void* stream);
 
+/*
+ * Spectral norm (old-style torch.nn.utils.spectral_norm, n_power_iterations=1, eps=1e-12, dim=0) of a
+ * (rows=Cout, cols=Cin/g*K) matrix -- ste_gan/layers/conv.py:92-94 via discriminator.py:136,172.
+ * power_iterate != 0 (module in training mode): v <- normalize(W^T u); u <- normalize(W v), IN PLACE,
+ * exactly once per call (the reference runs it on each of the 4 D forwards of a step).  Then
+ * sigma = u^T W v, *sigma is written and scale[0..rows) = 1/sigma (the conv epilogue factor).
+ * workspace: stegan_spectral_norm_workspace_floats(rows, cols) floats.
+ */
+int64_t stegan_spectral_norm_workspace_floats(int32_t rows, int32_t cols);
+int stegan_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* scale, float* sigma,
+                             float* workspace, int32_t rows, int32_t cols, int32_t power_iterate, void* stream);
+/* dw_orig = dw/sigma - (<dw,W>/sigma^2) u v^T, dw = raw-direction gradient of stegan_conv1d_bwd_weight
+ * (autograd of weight_orig / sigma with u, v held constant).  workspace: >= rows floats. */
+int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
+                             const float* sigma, float* workspace, float* dw_orig, int32_t rows, int32_t cols,
+                             void* stream);
+
+/* ---- discriminator input plumbing ---------------------------------------------------------- */
+/*
+ * Multi-period fold: right reflect-pad x (B,T,C) by n = period - T % period (a FULL period when
+ * divisible), view as (B,C,H,period), and emit it with the period axis folded into the batch:
+ * out[(b*period + w), c, h] = xpad[b, h*period + w, c], shape (B*period, C, H), H = (T+n)/period.
+ * Replaces F.pad(reflect) + view of discriminator.py:36-37,86-87 (+ the rearrange of :145,181); the
+ * (k,1) Conv2d stack then runs as Conv1d over H.  _bwd scatters the gradient back (optionally +=).
+ */
+int stegan_mpd_fold_fwd(const float* x_btc, float* out, int32_t B, int32_t T, int32_t C, int32_t period, void* stream);
+int stegan_mpd_fold_bwd(const float* dout, float* dx_btc, int32_t B, int32_t T, int32_t C, int32_t period,
+                        int32_t accumulate, void* stream);
+/* rearrange 'b t c -> b c t' (discriminator.py:145,181) and its transpose (optionally +=). */
+int stegan_btc_to_bct(const float* x, float* y, int32_t B, int32_t T, int32_t C, void* stream);
+int stegan_bct_to_btc(const float* x, float* y, int32_t B, int32_t T, int32_t C, int32_t accumulate, void* stream);
+/* nn.AvgPool1d(kernel_size=4, stride=2, padding=1) (discriminator.py:140,153) on (rows, T); bwd: dx = pool^T dy + add. */
+int stegan_avgpool421_fwd(const float* x, float* y, int64_t rows, int32_t T, void* stream);
+int stegan_avgpool421_bwd(const float* dy, const float* add, float* dx, int64_t rows, int32_t T, void* stream);
+
+/* ---- losses: scalar (accumulated into *loss_slot, a device float) + input gradient in one pass ---- */
+/*
+ * mode 0: weight * mean|a - b|      (F.l1_loss: feature matching, ste_gan/train.py:257-262)
+ * mode 1: weight * mean (a - b)^2   (F.mse_loss: LSGAN train.py:192-196,209-211; waveform :251-254)
+ * b == NULL compares against the constant `target` (torch.zeros_like / ones_like targets).
+ * da (nullable) receives d(weight*loss)/da.  loss_slot may be NULL (gradient only).
+ */
+int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64_t n, int32_t mode, float weight,
+                             float* loss_slot, float* da, void* stream);
+/* out = x * (*scalar_dev): chains an upstream 0-dim gradient into a stored unit gradient without a host sync. */
+int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
+/*
+ * Multi-resolution time-domain feature loss (losses/time_domain_loss.py:35-73,87-107 with
+ * layers/average_filter.py:22-28): per scale (win, shift): low = avg9(avg9(x)) (reflect pad 4),
+ * rect = |x - low|, frames over a reflect-padded (win/2) axis, features [mean low, sum low^2,
+ * sum rect^2, mean rect], L1 mean against the real signal's features; summed over n_scales (<= 3).
+ * x_* are (B,T,C).  *loss_slot += weight*loss; per_scale[n_scales] (nullable) = unweighted losses;
+ * dx_gen (nullable) = d(weight*loss)/dx_gen.  workspace: stegan_multi_td_workspace_floats(B,C) floats.
+ * T is limited by the 160 KiB LDS of a CU (9*T floats per row must fit in 150 KiB).
+ */
+int64_t stegan_multi_td_workspace_floats(int32_t B, int32_t C);
+int stegan_multi_td_fwd_bwd(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
+                            int32_t n_scales, const int32_t* win_host, const int32_t* shift_host, float weight,
+                            float* loss_slot, float* per_scale, float* dx_gen, float* workspace, void* stream);
+/* weight * mean_rows ||target - pred + 1e-6||_2 (F.pairwise_distance, losses/emg_encoder_loss.py:63-67).
+ * workspace: rows floats. */
+int stegan_su_loss_fwd_bwd(const float* target, const float* pred, int32_t rows, int32_t D, float weight,
+                           float* loss_slot, float* dpred, float* workspace, void* stream);
+/*
+ * weight * cross_entropy(logits (rows,P<=64), targets) (losses/emg_encoder_loss.py:80-83) plus the
+ * EMGEncoderLossOutput counters (:27-53), bit-exact integers accumulated into counters[4] =
+ * {num_phones, num_silence, num_correct, num_correct_no_silence}; argmax uses torch's first-maximum
+ * tie rule.  dlogits / counters / argmax_out are nullable.  workspace: rows floats.
+ */
+int stegan_phoneme_ce_fwd_bwd(const float* logits, const int64_t* targets, int32_t rows, int32_t P,
+                              int32_t silence_index, float weight, float* loss_slot, int32_t* counters,
+                              float* dlogits, int64_t* argmax_out, float* workspace, void* stream);
+
 /* ---- elementwise helpers of the backward pass --------------------------------------------- */
 /* dx[b,c,t] = dxe[b,c,2t] + dxe[b,c,2t+1]   (backward of nn.Upsample(scale_factor=2), conv.py:40,55) */
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);

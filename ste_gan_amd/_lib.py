@@ -37,9 +37,26 @@ SIGNATURES = {
     "stegan_wn_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_wn_scale1": [_P, _P, _P, _I32, _I32, _P],
     "stegan_wn_backward1": [_P, _P, _P, _P, _P, _I32, _I32, _P],
+    "stegan_spectral_norm_fwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stegan_spectral_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
+    "stegan_mpd_fold_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "stegan_mpd_fold_bwd": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "stegan_btc_to_bct": [_P, _P, _I32, _I32, _I32, _P],
+    "stegan_bct_to_btc": [_P, _P, _I32, _I32, _I32, _I32, _P],
+    "stegan_avgpool421_fwd": [_P, _P, _I64, _I32, _P],
+    "stegan_avgpool421_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "stegan_pair_loss_fwd_bwd": [_P, _P, C.c_float, _I64, _I32, C.c_float, _P, _P, _P],
+    "stegan_scale_by_scalar": [_P, _P, _P, _I64, _P],
+    "stegan_multi_td_fwd_bwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, C.c_float, _P, _P, _P, _P, _P],
+    "stegan_su_loss_fwd_bwd": [_P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P],
+    "stegan_phoneme_ce_fwd_bwd": [_P, _P, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
 }
+
+# symbols whose return value is not a status code
+INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
+                "stegan_multi_td_workspace_floats": [_I32, _I32]}
 
 _lib = None
 
@@ -60,6 +77,10 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)      # AttributeError if the .so does not export it
             fn.argtypes = args
             fn.restype = C.c_int
+        for name, args in INT64_RETURN.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = C.c_int64
         if handle.stegan_abi_version() != ABI_VERSION:
             raise SteganHipError("libstegan_hip.so ABI version mismatch: rebuild")
         _lib = handle

@@ -1,0 +1,315 @@
+// Discriminator-side data movement kernels: MPD reflect-pad + period fold, (B,T,C)<->(B,C,T),
+// AvgPool1d(4,2,1) and the spectral-norm power iteration.  All HBM-bound, tiny next to the convs.
+#include "common.h"
+
+namespace {
+
+// out[(b*p + w), c, h] = xpad[b, h*p + w, c],  xpad = right reflect pad of x (B,T,C) to H*p samples
+__global__ __launch_bounds__(256) void mpd_fold_fwd_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                           int B, int T, int Cc, int p, int H) {
+    const long total = (long)B * p * Cc * H;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int h = (int)(i % H);
+        long r = i / H;
+        const int c = (int)(r % Cc);
+        r /= Cc;
+        const int w = (int)(r % p), b = (int)(r / p);
+        int t = h * p + w;
+        if (t >= T) t = 2 * T - 2 - t;          // reflect (no edge repeat): xpad[T+i] = x[T-2-i]
+        out[i] = x[((long)b * T + t) * Cc + c];
+    }
+}
+
+// dx[b,t,c] (+)= sum over the folded positions that read x[b,t,c]
+__global__ __launch_bounds__(256) void mpd_fold_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx,
+                                                           int B, int T, int Cc, int p, int H, int accumulate) {
+    const long total = (long)B * T * Cc;
+    const int Tp = H * p;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cc);
+        long r = i / Cc;
+        const int t = (int)(r % T), b = (int)(r / T);
+        float g = dout[(((long)b * p + t % p) * Cc + c) * H + t / p];
+        const int tr = 2 * T - 2 - t;            // padded position that mirrors onto t
+        if (tr >= T && tr < Tp) g += dout[(((long)b * p + tr % p) * Cc + c) * H + tr / p];
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// (B,T,C) -> (B,C,T)   (C is tiny: 8)
+__global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int B, int T, int Cc) {
+    const long total = (long)B * T * Cc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % T);
+        long r = i / T;
+        const int c = (int)(r % Cc), b = (int)(r / Cc);
+        y[i] = x[((long)b * T + t) * Cc + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void bct_to_btc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int B, int T, int Cc, int accumulate) {
+    const long total = (long)B * T * Cc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % Cc);
+        long r = i / Cc;
+        const int t = (int)(r % T), b = (int)(r / T);
+        const float v = x[((long)b * Cc + c) * T + t];
+        y[i] = accumulate ? y[i] + v : v;
+    }
+}
+
+// AvgPool1d(kernel 4, stride 2, pad 1, count_include_pad): y[t] = (x[2t-1]+x[2t]+x[2t+1]+x[2t+2])/4
+__global__ __launch_bounds__(256) void avgpool421_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             long rows, int T, int To) {
+    const long total = rows * To;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % To);
+        const float* xr = x + (i / To) * T;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ti = 2 * t - 1 + k;
+            if (ti >= 0 && ti < T) s += xr[ti];
+        }
+        y[i] = 0.25f * s;
+    }
+}
+
+// dx[ti] = 0.25 * sum_{t : 2t-1 <= ti <= 2t+2} dy[t]  (+ add[ti])
+__global__ __launch_bounds__(256) void avgpool421_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
+                                                             float* __restrict__ dx, long rows, int T, int To) {
+    const long total = rows * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ti = (int)(i % T);
+        const float* dr = dy + (i / T) * To;
+        // t ranges over ceil((ti-2)/2) .. floor((ti+1)/2)
+        int lo = (ti - 2 + 1) >> 1, hi = (ti + 1) >> 1;
+        if (ti - 2 < 0) lo = 0;
+        float s = 0.f;
+        for (int t = lo; t <= hi; ++t)
+            if (t >= 0 && t < To) s += dr[t];
+        dx[i] = 0.25f * s + (add ? add[i] : 0.f);
+    }
+}
+
+// ---------------- spectral norm: one power iteration + sigma --------------------------------
+// stage 1: partial[rc][j] = sum_{i in row chunk rc} W[i][j] * u[i]       (deterministic two-stage column sums)
+constexpr int SN_ROWS = 32;
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                     float* __restrict__ partial, int R, int Cn) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = blockIdx.y * SN_ROWS;
+    if (j >= Cn) return;
+    float s = 0.f;
+    const int r1 = min(R, r0 + SN_ROWS);
+    for (int i = r0; i < r1; ++i) s += W[(size_t)i * Cn + j] * u[i];
+    partial[(size_t)blockIdx.y * Cn + j] = s;
+}
+
+// stage 2 (single block): t = sum partial; v = t / max(||t||, eps)
+__global__ __launch_bounds__(1024) void sn_vnorm_kernel(const float* __restrict__ partial, float* __restrict__ v,
+                                                        int nchunks, int Cn, float eps) {
+    __shared__ float red[16];
+    __shared__ float inv;
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < Cn; j += 1024) {
+        float t = 0.f;
+        for (int c = 0; c < nchunks; ++c) t += partial[(size_t)c * Cn + j];
+        v[j] = t;
+        ss += t * t;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int k = 0; k < 16; ++k) a += red[k];
+        inv = 1.f / fmaxf(sqrtf(a), eps);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Cn; j += 1024) v[j] *= inv;
+}
+
+// stage 3: s[i] = <W[i,:], v>   (one wave per row)
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                    float* __restrict__ s, int R, int Cn) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const float* wr = W + (size_t)row * Cn;
+    float a = 0.f;
+    for (int j = lane; j < Cn; j += 64) a += wr[j] * v[j];
+    a = wave_sum(a);
+    if (lane == 0) s[row] = a;
+}
+
+// stage 4 (single block): u = s / max(||s||,eps) (if update_u); sigma = <u, s>; scale[:] = 1/sigma; sigma_out
+__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* __restrict__ s, float* __restrict__ u,
+                                                         float* __restrict__ scale, float* __restrict__ sigma_out,
+                                                         int R, float eps, int update_u) {
+    __shared__ float red[16];
+    __shared__ float bc;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < R; i += 1024) ss += s[i] * s[i];
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int k = 0; k < 16; ++k) a += red[k];
+        bc = 1.f / fmaxf(sqrtf(a), eps);
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < R; i += 1024) {
+        float ui = update_u ? s[i] * bc : u[i];
+        if (update_u) u[i] = ui;
+        dot += ui * s[i];
+    }
+    dot = wave_sum(dot);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+        for (int k = 0; k < 16; ++k) a += red[k];
+        bc = a;
+        *sigma_out = a;
+    }
+    __syncthreads();
+    const float inv_sigma = 1.f / bc;
+    for (int i = threadIdx.x; i < R; i += 1024) scale[i] = inv_sigma;
+}
+
+// dW_orig = dw/sigma - (<dw, W>/sigma^2) u v^T      two kernels: row dots -> total, then elementwise
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ W, const float* __restrict__ dw,
+                                                         float* __restrict__ rowdot, int R, int Cn) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    float a = 0.f;
+    for (int j = lane; j < Cn; j += 64) a += W[(size_t)row * Cn + j] * dw[(size_t)row * Cn + j];
+    a = wave_sum(a);
+    if (lane == 0) rowdot[row] = a;
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw, const float* __restrict__ rowdot,
+                                                           const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma, float* __restrict__ dW,
+                                                           int R, int Cn) {
+    __shared__ float tot;
+    if (threadIdx.x < 64) {            // every block re-reduces the R row dots (R <= 1024): deterministic, no atomics
+        float a = 0.f;
+        for (int i = threadIdx.x; i < R; i += 64) a += rowdot[i];
+        a = wave_sum(a);
+        if (threadIdx.x == 0) tot = a;
+    }
+    __syncthreads();
+    const float sg = *sigma;
+    const float k = tot / (sg * sg), inv = 1.f / sg;
+    const long total = (long)R * Cn;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % Cn), r = (int)(i / Cn);
+        dW[i] = dw[i] * inv - k * u[r] * v[j];
+    }
+}
+
+inline int nblocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int stegan_mpd_fold_fwd(const float* x_btc, float* out, int32_t B, int32_t T, int32_t Cc, int32_t period,
+                                   void* stream) {
+    STEGAN_CHECK_ARG(x_btc && out && B > 0 && T > 0 && Cc > 0 && period > 0);
+    const int n_pad = period - T % period;
+    STEGAN_CHECK_ARG(n_pad < T);                     // reflect pad needs pad < length (ATen raises likewise)
+    const int H = (T + n_pad) / period;
+    hipLaunchKernelGGL(mpd_fold_fwd_kernel, dim3(nblocks((long)B * period * Cc * H)), dim3(256), 0, (hipStream_t)stream,
+                       x_btc, out, B, T, Cc, period, H);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_mpd_fold_bwd(const float* dout, float* dx_btc, int32_t B, int32_t T, int32_t Cc, int32_t period,
+                                   int32_t accumulate, void* stream) {
+    STEGAN_CHECK_ARG(dout && dx_btc && B > 0 && T > 0 && Cc > 0 && period > 0);
+    const int n_pad = period - T % period;
+    STEGAN_CHECK_ARG(n_pad < T);
+    const int H = (T + n_pad) / period;
+    hipLaunchKernelGGL(mpd_fold_bwd_kernel, dim3(nblocks((long)B * T * Cc)), dim3(256), 0, (hipStream_t)stream, dout,
+                       dx_btc, B, T, Cc, period, H, accumulate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_btc_to_bct(const float* x, float* y, int32_t B, int32_t T, int32_t Cc, void* stream) {
+    STEGAN_CHECK_ARG(x && y && B > 0 && T > 0 && Cc > 0);
+    hipLaunchKernelGGL(btc_to_bct_kernel, dim3(nblocks((long)B * T * Cc)), dim3(256), 0, (hipStream_t)stream, x, y, B, T, Cc);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_bct_to_btc(const float* x, float* y, int32_t B, int32_t T, int32_t Cc, int32_t accumulate,
+                                 void* stream) {
+    STEGAN_CHECK_ARG(x && y && B > 0 && T > 0 && Cc > 0);
+    hipLaunchKernelGGL(bct_to_btc_kernel, dim3(nblocks((long)B * T * Cc)), dim3(256), 0, (hipStream_t)stream, x, y, B, T,
+                       Cc, accumulate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_avgpool421_fwd(const float* x, float* y, int64_t rows, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(x && y && rows > 0 && T >= 2);
+    const int To = (T + 2 - 4) / 2 + 1;
+    hipLaunchKernelGGL(avgpool421_fwd_kernel, dim3(nblocks(rows * To)), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, T, To);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_avgpool421_bwd(const float* dy, const float* add, float* dx, int64_t rows, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(dy && dx && rows > 0 && T >= 2);
+    const int To = (T + 2 - 4) / 2 + 1;
+    hipLaunchKernelGGL(avgpool421_bwd_kernel, dim3(nblocks(rows * T)), dim3(256), 0, (hipStream_t)stream, dy, add, dx, (long)rows, T, To);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int64_t stegan_spectral_norm_workspace_floats(int32_t rows, int32_t cols) {
+    return (int64_t)ceil_div(rows, SN_ROWS) * cols + rows;
+}
+
+extern "C" int stegan_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* scale, float* sigma,
+                                        float* workspace, int32_t rows, int32_t cols, int32_t power_iterate,
+                                        void* stream) {
+    STEGAN_CHECK_ARG(w_orig && u && v && scale && sigma && workspace && rows > 0 && cols > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = ceil_div(rows, SN_ROWS);
+    float* partial = workspace;
+    float* svec = workspace + (size_t)nch * cols;
+    const float eps = 1e-12f;
+    if (power_iterate) {
+        hipLaunchKernelGGL(sn_wtu_kernel, dim3(ceil_div(cols, 256), nch), dim3(256), 0, s, w_orig, u, partial, rows, cols);
+        hipLaunchKernelGGL(sn_vnorm_kernel, dim3(1), dim3(1024), 0, s, partial, v, nch, cols, eps);
+    }
+    hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w_orig, v, svec, rows, cols);
+    hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, svec, u, scale, sigma, rows, eps, power_iterate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
+                                        const float* sigma, float* workspace, float* dw_orig, int32_t rows,
+                                        int32_t cols, void* stream) {
+    STEGAN_CHECK_ARG(w_orig && dw && u && v && sigma && workspace && dw_orig && rows > 0 && cols > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w_orig, dw, workspace, rows, cols);
+    hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nblocks((long)rows * cols)), dim3(256), 0, s, dw, workspace, u, v, sigma,
+                       dw_orig, rows, cols);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}

@@ -1,0 +1,345 @@
+// Loss kernels: every loss produces its scalar (accumulated into a device "loss slot") AND the
+// gradient w.r.t. its input in the same pass -- the reductions are wavefront shuffles + one atomic
+// per block, nothing is re-read.  All fp32.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// mode 0: L1 |a-b|, mode 1: MSE (a-b)^2;  b == nullptr -> constant target
+__global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float target, long n, int mode, float w_over_n,
+                                                        float* __restrict__ loss_slot, float* __restrict__ da) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = a[i] - (b ? b[i] : target);
+        if (mode == 0) {
+            s += fabsf(d);
+            if (da) da[i] = d > 0.f ? w_over_n : (d < 0.f ? -w_over_n : 0.f);
+        } else {
+            s += d * d;
+            if (da) da[i] = 2.f * d * w_over_n;
+        }
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0 && loss_slot) atomicAdd(loss_slot, s * w_over_n);
+}
+
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                              float* __restrict__ out, long n) {
+    const float k = *s;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] * k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-resolution time-domain feature loss.  One block per (batch, channel) row of length T.
+// ---------------------------------------------------------------------------------------------
+struct TDScale { int W, S, P, F; float inv_n; };   // window, shift, pad = W/2, frames, 1/(B*F*C*4)
+
+__device__ __forceinline__ int refl(int t, int T) {        // reflect without edge repeat
+    if (t < 0) t = -t;
+    if (t >= T) t = 2 * T - 2 - t;
+    return t;
+}
+
+// dst[t] = (1/9) sum_{j=-4..4} src[refl(t+j)]
+__device__ __forceinline__ void box9(const float* src, float* dst, int T) {
+    for (int t = threadIdx.x; t < T; t += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = -4; j <= 4; ++j) s += src[refl(t + j, T)];
+        dst[t] = s * (1.f / 9.f);
+    }
+}
+
+// adjoint of box9: dsrc[s] = sum over padded taps that read src[s]
+__device__ __forceinline__ float box9_pad_adj(const float* dy, int tau, int T) {   // d/dxpad[tau], tau in [0,T+8)
+    if (tau < 0 || tau >= T + 8) return 0.f;
+    float s = 0.f;
+    const int lo = max(0, tau - 8), hi = min(T - 1, tau);
+    for (int t = lo; t <= hi; ++t) s += dy[t];
+    return s * (1.f / 9.f);
+}
+__device__ __forceinline__ void box9_adjoint(const float* dy, float* dsrc, int T) {
+    for (int s = threadIdx.x; s < T; s += 256) {
+        float g = box9_pad_adj(dy, s + 4, T);
+        if (s >= 1 && s <= 4) g += box9_pad_adj(dy, 4 - s, T);
+        if (s >= T - 5 && s <= T - 2) g += box9_pad_adj(dy, 4 + 2 * (T - 1) - s, T);
+        dsrc[s] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__ x_real, const float* __restrict__ x_gen,
+                                                       int T, int Cc, TDScale s0, TDScale s1, TDScale s2, float weight,
+                                                       float* __restrict__ partial, float* __restrict__ dx_gen,
+                                                       int maxF) {
+    extern __shared__ float sm[];
+    // layout: xr, xg, low_r, low_g, rect_r, rect_g, tmp, dlow, drect  (9*T) + frame coefs 4*maxF
+    float* xr = sm;            float* xg = xr + T;
+    float* low_r = xg + T;     float* low_g = low_r + T;
+    float* rect_r = low_g + T; float* rect_g = rect_r + T;
+    float* tmp = rect_g + T;   float* dlow = tmp + T;   float* drect = dlow + T;
+    float* cf = drect + T;     // [4][maxF]: g_mlow/W, 2*g_plow, 2*g_prect, g_mrect/W   (already * inv_n * weight)
+    __shared__ float red[4];
+    const int row = blockIdx.x;            // row = b*C + c
+    const int b = row / Cc, c = row % Cc;
+    for (int t = threadIdx.x; t < T; t += 256) {
+        xr[t] = x_real[((size_t)b * T + t) * Cc + c];
+        xg[t] = x_gen[((size_t)b * T + t) * Cc + c];
+        dlow[t] = 0.f;
+        drect[t] = 0.f;
+    }
+    __syncthreads();
+    box9(xr, tmp, T);   __syncthreads();
+    box9(tmp, low_r, T); __syncthreads();
+    box9(xg, tmp, T);   __syncthreads();
+    box9(tmp, low_g, T); __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        rect_r[t] = fabsf(xr[t] - low_r[t]);
+        rect_g[t] = fabsf(xg[t] - low_g[t]);
+    }
+    __syncthreads();
+
+    const TDScale sc[3] = {s0, s1, s2};
+    float loss_acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int si = 0; si < 3; ++si) {
+        const TDScale S = sc[si];
+        float l = 0.f;
+        for (int f = threadIdx.x; f < S.F; f += 256) {
+            float ml_r = 0.f, pl_r = 0.f, pr_r = 0.f, mr_r = 0.f, ml_g = 0.f, pl_g = 0.f, pr_g = 0.f, mr_g = 0.f;
+            for (int j = 0; j < S.W; ++j) {
+                const int t = refl(f * S.S + j - S.P, T);
+                const float a = low_r[t], r = rect_r[t], ag = low_g[t], rg = rect_g[t];
+                ml_r += a; pl_r += a * a; pr_r += r * r; mr_r += r;
+                ml_g += ag; pl_g += ag * ag; pr_g += rg * rg; mr_g += rg;
+            }
+            const float invW = 1.f / (float)S.W;
+            const float d0 = (ml_g - ml_r) * invW, d1 = pl_g - pl_r, d2 = pr_g - pr_r, d3 = (mr_g - mr_r) * invW;
+            l += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+            const float k = S.inv_n * weight;
+            auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+            cf[0 * maxF + f] = sgn(d0) * k * invW;
+            cf[1 * maxF + f] = sgn(d1) * k * 2.f;
+            cf[2 * maxF + f] = sgn(d2) * k * 2.f;
+            cf[3 * maxF + f] = sgn(d3) * k * invW;
+        }
+        loss_acc[si] = l * S.inv_n;
+        __syncthreads();
+        if (dx_gen) {
+            // gather form of the frame/reflect adjoint: position t receives from padded taus t+P and its mirrors
+            for (int t = threadIdx.x; t < T; t += 256) {
+                float gl = 0.f, gr = 0.f;
+                const float lv = low_g[t], rv = rect_g[t];
+                int taus[3] = {t + S.P, (t >= 1 && t <= S.P) ? S.P - t : -1,
+                               (t >= T - 1 - S.P && t <= T - 2) ? S.P + 2 * (T - 1) - t : -1};
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int tau = taus[q];
+                    if (tau < 0) continue;
+                    // frames f with f*S <= tau < f*S + W
+                    int f_hi = tau / S.S;
+                    if (f_hi > S.F - 1) f_hi = S.F - 1;
+                    int f_lo = tau - S.W + 1;
+                    f_lo = f_lo <= 0 ? 0 : (f_lo + S.S - 1) / S.S;
+                    for (int f = f_lo; f <= f_hi; ++f) {
+                        gl += cf[0 * maxF + f] + cf[1 * maxF + f] * lv;
+                        gr += cf[3 * maxF + f] + cf[2 * maxF + f] * rv;
+                    }
+                }
+                dlow[t] += gl;
+                drect[t] += gr;
+            }
+        }
+        __syncthreads();
+    }
+    // loss partials: [row][3]
+    for (int si = 0; si < 3; ++si) {
+        const float tot = block_sum_256(loss_acc[si], red);
+        if (threadIdx.x == 0) partial[(size_t)row * 3 + si] = tot;
+    }
+    if (!dx_gen) return;
+    // rect = |x - low|:  dh = sign(x-low)*drect ; dx = dh + A^T A^T (dlow - dh)
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const float h = xg[t] - low_g[t];
+        const float dh = (h > 0.f ? 1.f : (h < 0.f ? -1.f : 0.f)) * drect[t];
+        rect_g[t] = dh;                  // reuse as dh
+        dlow[t] -= dh;
+    }
+    __syncthreads();
+    box9_adjoint(dlow, tmp, T);  __syncthreads();
+    box9_adjoint(tmp, low_g, T); __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) dx_gen[((size_t)b * T + t) * Cc + c] = rect_g[t] + low_g[t];
+}
+
+// out[slot_base + s] += sum_rows partial[row][s]   (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void td_finish_kernel(const float* __restrict__ partial, int rows, float weight,
+                                                        float* __restrict__ loss_slot, float* __restrict__ per_scale) {
+    __shared__ float red[4];
+    float tot = 0.f;
+    for (int s = 0; s < 3; ++s) {
+        float a = 0.f;
+        for (int r = threadIdx.x; r < rows; r += 256) a += partial[(size_t)r * 3 + s];
+        a = block_sum_256(a, red);
+        if (threadIdx.x == 0 && per_scale) per_scale[s] = a;
+        tot += a;
+    }
+    if (threadIdx.x == 0 && loss_slot) *loss_slot += tot * weight;
+}
+
+// speech-unit loss: mean_rows || t - p + eps ||_2 ; one wave per row
+__global__ __launch_bounds__(256) void su_loss_kernel(const float* __restrict__ tgt, const float* __restrict__ pred,
+                                                      int rows, int D, float eps, float w_over_rows,
+                                                      float* __restrict__ partial, float* __restrict__ dpred) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* t = tgt + (size_t)row * D;
+    const float* p = pred + (size_t)row * D;
+    float ss = 0.f;
+    for (int j = lane; j < D; j += 64) { const float d = t[j] - p[j] + eps; ss += d * d; }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    if (lane == 0) partial[row] = nrm;
+    if (dpred) {
+        const float k = nrm > 0.f ? -w_over_rows / nrm : 0.f;
+        for (int j = lane; j < D; j += 64) dpred[(size_t)row * D + j] = (t[j] - p[j] + eps) * k;
+    }
+}
+
+// cross entropy + argmax counters; one wave per row, P <= 64 classes
+__global__ __launch_bounds__(256) void phoneme_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
+                                                         int rows, int P, int silence, float w_over_rows,
+                                                         float* __restrict__ partial, int* __restrict__ counters,
+                                                         float* __restrict__ dlogits, long long* __restrict__ argmax_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float x = lane < P ? logits[(size_t)row * P + lane] : -INFINITY;
+    // max + first-index argmax (torch.argmax returns the first maximal index)
+    float m = x;
+    int am = lane < P ? lane : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(m, o, 64);
+        const int oa = __shfl_xor(am, o, 64);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    const float e = lane < P ? expf(x - m) : 0.f;
+    const float se = wave_sum(e);
+    const int tg = (int)target[row];
+    const float lse = logf(se) + m;
+    const float xt = __shfl(x, tg, 64);
+    if (lane == 0) {
+        partial[row] = lse - xt;
+        if (argmax_out) argmax_out[row] = am;
+        if (counters) {
+            atomicAdd(&counters[0], 1);
+            if (tg == silence) atomicAdd(&counters[1], 1);
+            if (am == tg) {
+                atomicAdd(&counters[2], 1);
+                if (tg != silence) atomicAdd(&counters[3], 1);
+            }
+        }
+    }
+    if (dlogits && lane < P) dlogits[(size_t)row * P + lane] = (e / se - (lane == tg ? 1.f : 0.f)) * w_over_rows;
+}
+
+// loss_slot += scale * sum(partial[0..n))  in fixed order (single block)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int n, float scale,
+                                                           float* __restrict__ loss_slot) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) a += partial[r];
+    a = block_sum_256(a, red);
+    if (threadIdx.x == 0) *loss_slot += a * scale;
+}
+
+inline int nblk(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64_t n, int32_t mode,
+                                        float weight, float* loss_slot, float* da, void* stream) {
+    STEGAN_CHECK_ARG(a && n > 0 && (mode == 0 || mode == 1));
+    hipLaunchKernelGGL(pair_loss_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, (long)n, mode,
+                       weight / (float)n, loss_slot, da);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream) {
+    STEGAN_CHECK_ARG(x && scalar_dev && out && n > 0);
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, scalar_dev, out, (long)n);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int64_t stegan_multi_td_workspace_floats(int32_t B, int32_t C) { return (int64_t)B * C * 3; }
+
+extern "C" int stegan_multi_td_fwd_bwd(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
+                                       int32_t n_scales, const int32_t* win_host, const int32_t* shift_host,
+                                       float weight, float* loss_slot, float* per_scale, float* dx_gen,
+                                       float* workspace, void* stream) {
+    STEGAN_CHECK_ARG(x_real && x_gen && workspace && B > 0 && T > 0 && C > 0);
+    STEGAN_CHECK_ARG(n_scales >= 1 && n_scales <= 3 && win_host && shift_host);
+    TDScale sc[3] = {TDScale{1, 1, 0, 0, 0.f}, TDScale{1, 1, 0, 0, 0.f}, TDScale{1, 1, 0, 0, 0.f}};
+    int maxF = 1;
+    for (int i = 0; i < n_scales; ++i) {
+        const int W = win_host[i], S = shift_host[i], P = W / 2;
+        STEGAN_CHECK_ARG(W >= 1 && S >= 1);
+        STEGAN_CHECK_ARG(P < T && T > 4);          // reflect padding needs pad < length (ATen raises likewise)
+        const int F = (T + 2 * P - W) / S + 1;
+        STEGAN_CHECK_ARG(F >= 1);
+        sc[i] = TDScale{W, S, P, F, 1.f / ((float)B * F * C * 4.f)};
+        if (F > maxF) maxF = F;
+    }
+    const size_t lds = ((size_t)9 * T + 4 * maxF) * sizeof(float);
+    STEGAN_CHECK_ARG(lds <= 150 * 1024);
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)multi_td_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(multi_td_kernel, dim3(B * C), dim3(256), lds, s, x_real, x_gen, T, C, sc[0], sc[1], sc[2], weight,
+                       workspace, dx_gen, maxF);
+    hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(256), 0, s, workspace, B * C, weight, loss_slot, per_scale);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_su_loss_fwd_bwd(const float* target, const float* pred, int32_t rows, int32_t D, float weight,
+                                      float* loss_slot, float* dpred, float* workspace, void* stream) {
+    STEGAN_CHECK_ARG(target && pred && loss_slot && workspace && rows > 0 && D > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(su_loss_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, target, pred, rows, D, 1e-6f,
+                       weight / (float)rows, workspace, dpred);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, rows, weight / (float)rows, loss_slot);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_phoneme_ce_fwd_bwd(const float* logits, const int64_t* targets, int32_t rows, int32_t P,
+                                         int32_t silence_index, float weight, float* loss_slot, int32_t* counters,
+                                         float* dlogits, int64_t* argmax_out, float* workspace, void* stream) {
+    STEGAN_CHECK_ARG(logits && targets && loss_slot && workspace && rows > 0 && P > 0 && P <= 64);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(phoneme_ce_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, (const long long*)targets,
+                       rows, P, silence_index, weight / (float)rows, workspace, counters, dlogits, (long long*)argmax_out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, rows, weight / (float)rows, loss_slot);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}

@@ -1,0 +1,162 @@
+"""Multi-period / multi-scale discriminators, host side -- mirrors ``ste_gan/models/discriminator.py``.
+
+Class names, constructor arguments, ``forward((B,T,C)) -> list[list[Tensor]]`` (5 MPD periods
+2,3,5,7,11 then 3 MSD scales; last entry of each inner list = logits), ``discriminator_names`` and
+state-dict keys equal the reference's.  Each conv + leaky_relu(0.1) is one fused launch; the MPD
+reflect-pad/fold, the 'b t c -> b c t' rearrange and AvgPool1d(4,2,1) are small HIP kernels.
+MPD feature maps are returned as (B,C,H,p) *views* of the period-folded (B*p,C,H) buffers.
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import ACT_LRELU
+from ..layers.conv import NormedConv1d, NormedConv2d
+
+
+def _unfold_view(fm, B, p):
+    """(B*p, C, H) period-folded map -> the reference's (B, C, H, p) tensor (a view, no copy)."""
+    _, Cc, H = fm.shape
+    return fm.view(B, p, Cc, H).permute(0, 2, 3, 1)
+
+
+class _PeriodDisc(nn.Module):
+    def forward(self, x_btc):
+        B = x_btc.shape[0]
+        x = ops.mpd_fold(x_btc, self.period)
+        fmaps = []
+        for layer in self.layers:
+            x = layer(x)                       # conv + leaky_relu(0.1) fused
+            fmaps.append(_unfold_view(x, B, self.period))
+        fmaps.append(_unfold_view(self.output(x), B, self.period))
+        return fmaps
+
+
+class DiscriminatorP(_PeriodDisc):
+    """Full-size period discriminator -- discriminator.py:19-43."""
+
+    def __init__(self, num_emg_channels: int, period, norm="weight_norm", name="DiscriminatorP"):
+        super().__init__()
+        self.name = name
+        self.num_emg_channels = num_emg_channels
+        self.layers = nn.ModuleList([
+            NormedConv2d(num_emg_channels, 32, (5, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(32, 128, (5, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(128, 512, (5, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(512, 1024, (5, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(1024, 1024, (5, 1), 1, padding=(2, 0), norm=norm, out_act=ACT_LRELU)])
+        self.output = NormedConv2d(1024, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.period = period
+
+
+class DiscriminatorSmallerP(_PeriodDisc):
+    """Small period discriminator -- discriminator.py:70-93."""
+
+    def __init__(self, num_emg_channels: int, period, norm="weight_norm", name="DiscriminatorP"):
+        super().__init__()
+        self.name = name
+        self.num_emg_channels = num_emg_channels
+        self.layers = nn.ModuleList([
+            NormedConv2d(num_emg_channels, 32, (3, 1), (1, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(32, 256, (3, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU),
+            NormedConv2d(256, 512, (3, 1), (3, 1), padding=(2, 0), norm=norm, out_act=ACT_LRELU)])
+        self.output = NormedConv2d(512, 1, kernel_size=(3, 1), padding=(1, 0))
+        self.period = period
+
+
+class _ScaleDisc(nn.Module):
+    def forward(self, x_bct):
+        fmaps = []
+        x = x_bct
+        for layer in self.layers:
+            x = layer(x)
+            fmaps.append(x)
+        fmaps.append(self.output(x))
+        return fmaps
+
+
+class DiscriminatorSmallerS(_ScaleDisc):
+    """Small scale discriminator -- discriminator.py:47-67."""
+
+    def __init__(self, num_emg_channels, norm="weight_norm", name="DiscriminatorS"):
+        super().__init__()
+        self.name = name
+        self.num_emg_channels = num_emg_channels
+        self.layers = nn.ModuleList([
+            NormedConv1d(num_emg_channels, 128, 15, 1, padding=7, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(128, 256, 37, 2, groups=4, padding=18, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(256, 512, 37, 2, groups=16, padding=18, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(512, 1024, 5, 1, padding=2, norm=norm, out_act=ACT_LRELU)])
+        self.output = NormedConv1d(1024, 1, 3, 1, padding=1)
+
+
+class DiscriminatorS(_ScaleDisc):
+    """Full-size scale discriminator -- discriminator.py:96-119."""
+
+    def __init__(self, num_emg_channels, norm="weight_norm", name="DiscriminatorS"):
+        super().__init__()
+        self.name = name
+        self.num_emg_channels = num_emg_channels
+        self.layers = nn.ModuleList([
+            NormedConv1d(num_emg_channels, 128, 15, 1, padding=7, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(128, 128, 41, 2, groups=4, padding=20, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(128, 256, 41, 2, groups=16, padding=20, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(256, 512, 41, 4, groups=16, padding=20, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(512, 1024, 41, 4, groups=16, padding=20, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(1024, 1024, 41, 1, groups=16, padding=20, norm=norm, out_act=ACT_LRELU),
+            NormedConv1d(1024, 1024, 5, 1, padding=2, norm=norm, out_act=ACT_LRELU)])
+        self.output = NormedConv1d(1024, 1, 3, 1, padding=1)
+
+
+class _MultiDisc(nn.Module):
+    PRIMES = [2, 3, 5, 7, 11]
+
+    def _build(self, num_emg_channels, num_multi_pool, num_multi_scale, cls_p, cls_s):
+        self.num_emg_channels = num_emg_channels
+        self.multi_pooled_disc = nn.ModuleList([
+            cls_p(num_emg_channels, self.PRIMES[i], name=f"DiscriminatorP-{self.PRIMES[i]}")
+            for i in range(num_multi_pool)])
+        self.multi_scale_disc = nn.ModuleList([
+            cls_s(num_emg_channels=num_emg_channels, norm="spectral_norm" if i == 0 else "weight_norm",
+                  name=f"DiscriminatorS-{i}")
+            for i in range(num_multi_scale)])
+        self.discriminator_names = [d.name for d in self.multi_pooled_disc] + [d.name for d in self.multi_scale_disc]
+
+    def forward(self, x):
+        """x: (B, T, C) -> [[fmaps..., logits] for 5 MPD + 3 MSD]  (discriminator.py:144-155 / 180-191)."""
+        results = [disc(x) for disc in self.multi_pooled_disc]
+        xs = ops.btc_to_bct(x)
+        for disc in self.multi_scale_disc:
+            results.append(disc(xs))
+            xs = ops.avgpool421(xs)            # the reference also pools once more after the last scale
+        return results
+
+
+class DiscriminatorSmall(_MultiDisc):
+    """discriminator.py:122-155."""
+
+    def __init__(self, num_emg_channels: int, num_multi_pool=5, num_multi_scale=3):
+        super().__init__()
+        self._build(num_emg_channels, num_multi_pool, num_multi_scale, DiscriminatorSmallerP, DiscriminatorSmallerS)
+
+
+class Discriminator(_MultiDisc):
+    """discriminator.py:158-191."""
+
+    def __init__(self, num_emg_channels: int, num_multi_pool=5, num_multi_scale=3):
+        super().__init__()
+        self._build(num_emg_channels, num_multi_pool, num_multi_scale, DiscriminatorP, DiscriminatorS)
+
+
+def init_emg_discriminators(cfg):
+    """Factory -- discriminator.py:194-203."""
+    num_emg_channels = cfg.data.num_emg_channels
+    if cfg.model.discriminator_small:
+        logging.info(f"Initializing small discriminators with {num_emg_channels} channels")
+        return DiscriminatorSmall(num_emg_channels)
+    logging.info(f"Initializing FULL discriminators with {num_emg_channels} channels")
+    return Discriminator(num_emg_channels)

@@ -180,3 +180,289 @@ def act_bwd(dy: Tensor, y: Tensor, act: int) -> Tensor:
     out = torch.empty_like(dy)
     check(_lib.lib().stegan_act_bwd(_p(dy), _p(y), _p(out), dy.numel(), act, _stream()), "stegan_act_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd: spectral-normalised fused conv (MSD scale 0)
+# ---------------------------------------------------------------------------------------------
+class _SNConvFn(torch.autograd.Function):
+    """y = out_act( (w_orig (*) x) / sigma + bias ), sigma = u^T W v after one in-place power iteration."""
+
+    @staticmethod
+    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool):
+        rows = w_orig.shape[0]
+        cols = w_orig.numel() // rows
+        L = _lib.lib()
+        ws = torch.empty(int(L.stegan_spectral_norm_workspace_floats(rows, cols)), device=x.device, dtype=torch.float32)
+        scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+        sigma = torch.empty(1, device=x.device, dtype=torch.float32)
+        check(L.stegan_spectral_norm_fwd(_p(w_orig), _p(u), _p(v), _p(scale), _p(sigma), _p(ws), rows, cols,
+                                         int(training), _stream()), "stegan_spectral_norm_fwd")
+        y = conv1d_fwd(x, w_orig, scale, bias, None, cfg)
+        ctx.cfg = cfg
+        # u / v are cloned because the next forward power-iterates them in place (torch clones them too)
+        ctx.save_for_backward(x, w_orig, u.clone(), v.clone(), scale, sigma, y if cfg.out_act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg: ConvCfg = ctx.cfg
+        x, w_orig, u, v, scale, sigma, y = ctx.saved_tensors
+        dy = _gpu_f32(dy, "grad_output")
+        if cfg.out_act != ACT_NONE:
+            dy = act_bwd(dy, y, cfg.out_act)
+        dx = dw_orig = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2])
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
+            dw = torch.zeros_like(w_orig)
+            db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32)
+            conv1d_bwd_weight(x, dy, cfg, dw, db)
+            rows = w_orig.shape[0]
+            ws = torch.empty(rows, device=dy.device, dtype=torch.float32)
+            dw_orig = torch.empty_like(w_orig)
+            check(_lib.lib().stegan_spectral_norm_bwd(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
+                                                      rows, w_orig.numel() // rows, _stream()),
+                  "stegan_spectral_norm_bwd")
+        return dx, dw_orig, None, None, db, None, None
+
+
+def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool) -> Tensor:
+    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training)
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd: discriminator input plumbing
+# ---------------------------------------------------------------------------------------------
+class _MPDFoldFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_btc, period: int):
+        x_btc = _gpu_f32(x_btc, "x")
+        B, T, Cc = x_btc.shape
+        n_pad = period - T % period
+        if n_pad >= T:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                               f"but got: padding (0, {n_pad}) at dimension 2 of input {[B, Cc, T]}")
+        H = (T + n_pad) // period
+        out = torch.empty((B * period, Cc, H), device=x_btc.device, dtype=torch.float32)
+        check(_lib.lib().stegan_mpd_fold_fwd(_p(x_btc), _p(out), B, T, Cc, period, _stream()), "stegan_mpd_fold_fwd")
+        ctx.dims = (B, T, Cc, period)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, Cc, period = ctx.dims
+        dout = _gpu_f32(dout, "grad")
+        dx = torch.empty((B, T, Cc), device=dout.device, dtype=torch.float32)
+        check(_lib.lib().stegan_mpd_fold_bwd(_p(dout), _p(dx), B, T, Cc, period, 0, _stream()), "stegan_mpd_fold_bwd")
+        return dx, None
+
+
+class _BtcToBctFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _gpu_f32(x, "x")
+        B, T, Cc = x.shape
+        y = torch.empty((B, Cc, T), device=x.device, dtype=torch.float32)
+        check(_lib.lib().stegan_btc_to_bct(_p(x), _p(y), B, T, Cc, _stream()), "stegan_btc_to_bct")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _gpu_f32(dy, "grad")
+        B, Cc, T = dy.shape
+        dx = torch.empty((B, T, Cc), device=dy.device, dtype=torch.float32)
+        check(_lib.lib().stegan_bct_to_btc(_p(dy), _p(dx), B, T, Cc, 0, _stream()), "stegan_bct_to_btc")
+        return dx
+
+
+class _AvgPool421Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _gpu_f32(x, "x")
+        B, Cc, T = x.shape
+        To = (T + 2 - 4) // 2 + 1
+        y = torch.empty((B, Cc, To), device=x.device, dtype=torch.float32)
+        check(_lib.lib().stegan_avgpool421_fwd(_p(x), _p(y), B * Cc, T, _stream()), "stegan_avgpool421_fwd")
+        ctx.T = T
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _gpu_f32(dy, "grad")
+        B, Cc, To = dy.shape
+        dx = torch.empty((B, Cc, ctx.T), device=dy.device, dtype=torch.float32)
+        check(_lib.lib().stegan_avgpool421_bwd(_p(dy), None, _p(dx), B * Cc, ctx.T, _stream()), "stegan_avgpool421_bwd")
+        return dx
+
+
+def mpd_fold(x_btc, period):
+    return _MPDFoldFn.apply(x_btc, period)
+
+
+def btc_to_bct(x):
+    return _BtcToBctFn.apply(x)
+
+
+def avgpool421(x):
+    return _AvgPool421Fn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd: losses.  Each kernel emits the scalar and the unit gradient in one pass; backward only
+# rescales the stored gradient by the upstream 0-dim gradient (read on the device, no host sync).
+# ---------------------------------------------------------------------------------------------
+def _chain(unit_grad: Tensor, grad_out: Tensor) -> Tensor:
+    out = torch.empty_like(unit_grad)
+    g = _gpu_f32(grad_out.reshape(1), "grad_output")
+    check(_lib.lib().stegan_scale_by_scalar(_p(unit_grad), _p(g), _p(out), unit_grad.numel(), _stream()),
+          "stegan_scale_by_scalar")
+    return out
+
+
+def _memory_order_pair(a: Tensor, b: Optional[Tensor]):
+    """Flat views of a (and b) in a's MEMORY order -- permuted dense views (the MPD feature maps) need no copy
+    because the means below are permutation invariant.  Returns (a_flat, b_flat, restore(da_flat) -> like a)."""
+    if a.is_contiguous() and (b is None or b.is_contiguous()):
+        return a.reshape(-1), (b.reshape(-1) if b is not None else None), (lambda g: g.view(a.shape))
+    order = sorted(range(a.dim()), key=lambda i: -a.stride(i))
+    ap = a.permute(order)
+    if ap.is_contiguous() and (b is None or (b.shape == a.shape and b.stride() == a.stride())):
+        inv = [order.index(i) for i in range(a.dim())]
+        bp = b.permute(order) if b is not None else None
+        return ap.reshape(-1), (bp.reshape(-1) if bp is not None else None), (lambda g: g.view(ap.shape).permute(inv))
+    a_c = a.contiguous()
+    return a_c.reshape(-1), (b.contiguous().reshape(-1) if b is not None else None), (lambda g: g.view(a.shape))
+
+
+class _PairLossFn(torch.autograd.Function):
+    """mean |a-b| (mode 0) or mean (a-b)^2 (mode 1); b may be None (constant target)."""
+
+    @staticmethod
+    def forward(ctx, a, b, target: float, mode: int):
+        a = a if a.is_cuda else _gpu_f32(a, "input")
+        af, bf, restore = _memory_order_pair(a, b)
+        af = _gpu_f32(af, "input")
+        if bf is not None:
+            bf = _gpu_f32(bf, "target")
+            if bf.numel() != af.numel():
+                raise RuntimeError(f"The size of tensor a ({list(a.shape)}) must match the size of tensor b ({list(b.shape)})")
+        loss = torch.zeros((), device=af.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        da = torch.empty_like(af) if need else None
+        check(_lib.lib().stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target), af.numel(), mode, 1.0, _p(loss), _p(da),
+                                                  _stream()), "stegan_pair_loss_fwd_bwd")
+        ctx.restore = restore
+        ctx.save_for_backward(da)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        if da is None:
+            return None, None, None, None
+        return ctx.restore(_chain(da, g)), None, None, None
+
+
+def l1_loss(a, b):
+    return _PairLossFn.apply(a, b.detach(), 0.0, 0)
+
+
+def mse_loss(a, b):
+    return _PairLossFn.apply(a, b.detach(), 0.0, 1)
+
+
+def mse_to_const(a, target: float):
+    return _PairLossFn.apply(a, None, float(target), 1)
+
+
+class _MultiTDFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_real, x_gen, wins, shifts):
+        x_real = _gpu_f32(x_real, "x_real")
+        x_gen = _gpu_f32(x_gen, "x_generated")
+        if x_real.shape != x_gen.shape:
+            raise RuntimeError(f"The size of tensor a ({list(x_gen.shape)}) must match the size of tensor b "
+                               f"({list(x_real.shape)})")
+        B, T, Cc = x_gen.shape
+        L = _lib.lib()
+        n = len(wins)
+        loss = torch.zeros((), device=x_gen.device, dtype=torch.float32)
+        per = torch.zeros(3, device=x_gen.device, dtype=torch.float32)
+        ws = torch.empty(int(L.stegan_multi_td_workspace_floats(B, Cc)), device=x_gen.device, dtype=torch.float32)
+        dx = torch.empty_like(x_gen) if ctx.needs_input_grad[1] else None
+        wa = (C.c_int32 * n)(*wins)
+        sa = (C.c_int32 * n)(*shifts)
+        check(L.stegan_multi_td_fwd_bwd(_p(x_real), _p(x_gen), B, T, Cc, n, wa, sa, 1.0, _p(loss), _p(per), _p(dx), _p(ws),
+                                        _stream()), "stegan_multi_td_fwd_bwd")
+        ctx.save_for_backward(dx)
+        ctx.mark_non_differentiable(per)
+        return loss, per
+
+    @staticmethod
+    def backward(ctx, g, _gper):
+        (dx,) = ctx.saved_tensors
+        return None, (_chain(dx, g) if dx is not None else None), None, None
+
+
+def multi_td_loss(x_real, x_gen, wins, shifts):
+    return _MultiTDFn.apply(x_real.detach(), x_gen, tuple(wins), tuple(shifts))
+
+
+class _SULossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, pred):
+        target = _gpu_f32(target, "speech_unit_target")
+        pred = _gpu_f32(pred, "speech_unit_pred")
+        D = pred.shape[-1]
+        rows = pred.numel() // D
+        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
+        ws = torch.empty(rows, device=pred.device, dtype=torch.float32)
+        dp = torch.empty_like(pred) if ctx.needs_input_grad[1] else None
+        check(_lib.lib().stegan_su_loss_fwd_bwd(_p(target), _p(pred), rows, D, 1.0, _p(loss), _p(dp), _p(ws), _stream()),
+              "stegan_su_loss_fwd_bwd")
+        ctx.save_for_backward(dp)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return None, (_chain(dp, g) if dp is not None else None)
+
+
+def speech_unit_loss(target, pred):
+    return _SULossFn.apply(target.detach(), pred)
+
+
+class _PhonemeCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, silence_index: int):
+        logits = _gpu_f32(logits, "phoneme_pred")
+        if not targets.is_cuda or targets.dtype != torch.int64:
+            raise RuntimeError("ste_gan_amd: phoneme targets must be a cuda int64 tensor")
+        targets = targets.contiguous()
+        P = logits.shape[-1]
+        rows = logits.numel() // P
+        if targets.numel() != rows:
+            raise RuntimeError(f"Expected target size {list(logits.shape[:-1])}, got {list(targets.shape)}")
+        dev = logits.device
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        counters = torch.zeros(4, device=dev, dtype=torch.int32)
+        argmax = torch.empty(logits.shape[:-1], device=dev, dtype=torch.int64)
+        ws = torch.empty(rows, device=dev, dtype=torch.float32)
+        dl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().stegan_phoneme_ce_fwd_bwd(_p(logits), _p(targets), rows, P, silence_index, 1.0, _p(loss),
+                                                   _p(counters), _p(dl), _p(argmax), _p(ws), _stream()),
+              "stegan_phoneme_ce_fwd_bwd")
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(counters, argmax)
+        return loss, counters, argmax
+
+    @staticmethod
+    def backward(ctx, g, _c, _a):
+        (dl,) = ctx.saved_tensors
+        return (_chain(dl, g) if dl is not None else None), None, None
+
+
+def phoneme_ce(logits, targets, silence_index):
+    return _PhonemeCEFn.apply(logits, targets, silence_index)

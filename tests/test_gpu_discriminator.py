@@ -1,0 +1,84 @@
+"""-m gpu: discriminators (small + full) forward / backward through libstegan_hip.so vs the golden
+fixtures of the reference modules and the CPU oracle.  fp32, tolerances relative to tensor max-abs."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import shapes as oshapes
+from oracle import stegan_oracle as O
+from oracle.detfill import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= rtol, f"{what}: max err {err:.3e}"
+
+
+def stats(t):
+    t = t.detach().double().flatten()
+    return np.array([float(t.sum()), float(t.abs().sum()), float((t * t).sum())])
+
+
+@pytest.mark.parametrize("name", list(cases.DISC_CASES))
+def test_discriminator_vs_golden(name, golden):
+    from ste_gan_amd.models.discriminator import Discriminator, DiscriminatorSmall
+    small, B, T = cases.DISC_CASES[name]
+    g = golden(name)
+    d = (DiscriminatorSmall if small else Discriminator)(8)
+    d.load_state_dict(fill_state_dict(oshapes.discriminator_shapes(small)))
+    d = d.cuda()
+    x = cases.disc_input(name).cuda().requires_grad_(True)
+    out1 = d(x)
+    close(torch.cat([sc[-1].flatten() for sc in out1]).detach().cpu().numpy(), g["logits1"], 5e-5, "logits1")
+    fms = [fm for sc in out1 for fm in sc]
+    assert [list(fm.shape) + [0] * (4 - fm.dim()) for fm in fms] == g["fmap_shapes"].tolist()
+    close(np.stack([stats(fm) for fm in fms]), g["fmap_stats"], 5e-5, "fmap_stats")
+    head = np.stack([np.pad(fm.detach().flatten()[:8].double().cpu().numpy(), (0, max(0, 8 - fm.numel()))) for fm in fms])
+    close(head, g["fmap_head"], 5e-5, "fmap_head")
+    loss = 0
+    for sc in out1:
+        loss = loss + torch.nn.functional.mse_loss(sc[-1], torch.ones_like(sc[-1]))
+        for fm in sc[:-1]:
+            loss = loss + fm.abs().mean()
+    close(float(loss), g["loss"], 5e-5, "loss")
+    loss.backward()
+    close(x.grad.cpu().numpy(), g["dx"], 2e-4, "dx")
+    params = list(d.parameters())
+    gn = np.array([float(p.grad.double().norm()) for p in params])
+    close(gn, g["grad_norm"], 2e-4, "grad_norm")
+    np.testing.assert_allclose(gn, g["grad_norm"], rtol=1e-3, atol=1e-5 * g["grad_norm"].max())
+    gh = np.stack([np.pad(p.grad.flatten()[:4].double().cpu().numpy(), (0, max(0, 4 - p.numel()))) for p in params])
+    close(gh, g["grad_head"], 5e-4, "grad_head")
+    out2 = d(x.detach())
+    close(torch.cat([sc[-1].flatten() for sc in out2]).detach().cpu().numpy(), g["logits2"], 5e-5, "logits2")
+    sd = d.state_dict()
+    for k in g.files:
+        if k.startswith("sn."):
+            close(sd[k[3:]].cpu().numpy(), g[k], 5e-5, k)
+
+
+def test_eval_mode_does_not_power_iterate():
+    from ste_gan_amd.models.discriminator import DiscriminatorSmall
+    d = DiscriminatorSmall(8)
+    d.load_state_dict(fill_state_dict(oshapes.discriminator_shapes(True)))
+    d = d.cuda().eval()
+    u0 = d.multi_scale_disc[0].layers[0].weight_u.clone()
+    x = cases.disc_input("disc_small_t64").cuda()
+    a = d(x); b = d(x)
+    assert torch.equal(u0, d.multi_scale_disc[0].layers[0].weight_u)
+    assert torch.equal(a[5][-1], b[5][-1])
+    sd = {k: v.cpu() for k, v in d.state_dict().items()}
+    ref = O.discriminator_forward(sd, x.cpu(), True, training=False)
+    close(a[5][-1].detach().cpu().numpy(), ref[5][-1].detach().numpy(), 5e-5, "eval logits")
+
+
+def test_reflect_pad_too_large_raises():
+    from ste_gan_amd.models.discriminator import DiscriminatorSmall
+    d = DiscriminatorSmall(8).cuda()
+    with pytest.raises(RuntimeError):          # T=4: period 11 needs pad 7 >= T (ATen raises too)
+        d(torch.zeros(1, 4, 8, device="cuda"))

@@ -1,0 +1,98 @@
+"""-m gpu: fused value+gradient loss kernels vs golden fixtures (multi-TD) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import shapes as oshapes
+from oracle import stegan_oracle as O
+from oracle.detfill import det_input, det_ints, fill_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= rtol, f"{what}: max err {err:.3e}"
+
+
+@pytest.mark.parametrize("name", list(cases.TD_CASES))
+def test_multi_td_vs_golden(name, golden):
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss, TimeDomainFeatureLoss
+    g = golden(name)
+    xr, xg = cases.td_inputs(name)
+    xg_d = xg.cuda().requires_grad_(True)
+    m = MultiTimeDomainFeatureLoss(8)
+    loss, vals = m.time_domain_loss(xr.cuda(), xg_d)
+    close(float(loss), g["loss"], 2e-5, "loss")
+    close([float(v) for v in vals], g["scale_losses"], 2e-5, "scale_losses")
+    (loss * 3.0).backward()                      # upstream scalar gradient is chained on the device
+    close(xg_d.grad.cpu().numpy() / 3.0, g["dx"], 1e-4, "dx")
+    single = TimeDomainFeatureLoss(8, 51, 13)(xr.cuda(), xg.cuda())
+    close(float(single), g["scale_losses"][1], 2e-5, "single scale")
+
+
+def test_td_edge_cases():
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    m = MultiTimeDomainFeatureLoss(8)
+    with pytest.raises(RuntimeError):            # T=32: reflect pad 40 >= T, ATen raises as well
+        m(torch.zeros(1, 32, 8, device="cuda"), torch.zeros(1, 32, 8, device="cuda"))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 96, 8, device="cuda"), torch.zeros(1, 112, 8, device="cuda"))
+    # identical signals: loss exactly 0 and zero gradient (sign(0) = 0 as in torch)
+    x = det_input("td.same", (2, 128, 8), "tanh").cuda()
+    xg = x.clone().requires_grad_(True)
+    l = m(x, xg)
+    l.backward()
+    assert float(l) == 0.0 and float(xg.grad.abs().max()) == 0.0
+
+
+def test_su_and_phoneme_losses_vs_oracle():
+    from ste_gan_amd import ops
+    B, T = 5, 12
+    su_t = det_input("l.su_t", (B, T, 256))
+    su_p = det_input("l.su_p", (B, T, 256)).requires_grad_(True)
+    ph_l = (det_input("l.ph", (B, T, 48)) * 3).requires_grad_(True)
+    ph_t = det_ints("l.ph_t", (B, T), 48)
+    ph_t[0, :4] = 47                                             # some silence targets
+    with torch.no_grad():                                        # force exact ties: first index must win
+        ph_l[1, 0, 5] = ph_l[1, 0, 9] = 50.0
+        ph_l[2, 3, 47] = ph_l[2, 3, 0] = 60.0
+    ref_su, ref_ph = O.speech_unit_loss(su_t, su_p), O.phoneme_loss(ph_l, ph_t)
+    g_su, g_ph = torch.autograd.grad(2 * ref_su + 0.5 * ref_ph, [su_p, ph_l])
+    su_pd = su_p.detach().cuda().requires_grad_(True)
+    ph_ld = ph_l.detach().cuda().requires_grad_(True)
+    l_su = ops.speech_unit_loss(su_t.cuda(), su_pd)
+    l_ph, counters, argmax = ops.phoneme_ce(ph_ld, ph_t.cuda(), 47)
+    close(float(l_su), float(ref_su), 2e-6, "su")
+    close(float(l_ph), float(ref_ph), 2e-6, "ph")
+    (2 * l_su + 0.5 * l_ph).backward()
+    close(su_pd.grad.cpu().numpy(), g_su.numpy(), 2e-5, "dsu")
+    close(ph_ld.grad.cpu().numpy(), g_ph.numpy(), 2e-5, "dph")
+    c = O.phoneme_counters(ph_l.detach(), ph_t)
+    assert counters.tolist() == [c["num_phones"], c["num_silence_phones"], c["num_correct_phones"],
+                                 c["num_correct_phones_no_silence"]]
+    assert torch.equal(argmax.cpu(), ph_l.detach().argmax(-1))   # bit-exact incl. ties
+
+
+def test_lsgan_and_feature_matching_vs_oracle():
+    from ste_gan_amd.losses.gan_losses import feature_matching_loss, lsgan_loss
+    from ste_gan_amd.models.discriminator import DiscriminatorSmall
+    sd = fill_state_dict(oshapes.discriminator_shapes(True))
+    d = DiscriminatorSmall(8)
+    d.load_state_dict(sd)
+    d = d.cuda().eval()                          # eval: no power iteration, so both passes see the same weights
+    xf = det_input("gl.fake", (2, 96, 8), "tanh")
+    xr = det_input("gl.real", (2, 96, 8), "tanh")
+    xf_d = xf.cuda().requires_grad_(True)
+    of, orl = d(xf_d), d(xr.cuda())
+    loss = lsgan_loss(of, 1.0) + 0.5 * lsgan_loss(orl, 0.0) + 7.0 * feature_matching_loss(of, orl)
+    loss.backward()
+    xf_c = xf.clone().requires_grad_(True)
+    rf = O.discriminator_forward(sd, xf_c, True, training=False)
+    rr = O.discriminator_forward(sd, xr, True, training=False)
+    ref = O.lsgan_loss(rf, 1.0) + 0.5 * O.lsgan_loss(rr, 0.0) + 7.0 * O.feature_matching_loss(rf, rr)
+    close(float(loss), float(ref), 2e-5, "loss")
+    close(xf_d.grad.cpu().numpy(), torch.autograd.grad(ref, xf_c)[0].numpy(), 2e-4, "dx_fake")

@@ -37,7 +37,8 @@ int stegan_selftest_host(void);
 
 /* ---- activation / layout codes ---------------------------------------------------------- */
 #define STEGAN_ACT_NONE 0
-#define STEGAN_ACT_RELU 1   /* input-side: ReLU applied while gathering x (pre-activation blocks) */
+#define STEGAN_ACT_RELU 1   /* input-side: ReLU applied while gathering x (pre-activation blocks);
+                               output-side: F.relu of the encoder ResBlock / FFN (conv.py:125,133)   */
 #define STEGAN_ACT_LRELU 2  /* output-side: leaky_relu(0.1)   (discriminator.py:38,64,90,116)    */
 #define STEGAN_ACT_TANH 3   /* output-side: tanh              (generator.py:160)                 */
 
@@ -63,7 +64,7 @@ typedef struct stegan_conv_desc {
     int32_t Tout;       /* output length = (Tin*upsample + 2*pad - dilation*(K-1) - 1)/stride + 1 */
     int32_t upsample;   /* 1 or 2 */
     int32_t in_act;     /* STEGAN_ACT_NONE | STEGAN_ACT_RELU */
-    int32_t out_act;    /* STEGAN_ACT_NONE | STEGAN_ACT_LRELU | STEGAN_ACT_TANH */
+    int32_t out_act;    /* STEGAN_ACT_NONE | STEGAN_ACT_RELU | STEGAN_ACT_LRELU | STEGAN_ACT_TANH */
     int32_t out_btc;    /* 0: y is (B,Cout,Tout); 1: y is (B,Tout,Cout)  (generator.py:157) */
 } stegan_conv_desc;
 
@@ -149,6 +150,31 @@ int stegan_bct_to_btc(const float* x, float* y, int32_t B, int32_t T, int32_t C,
 /* nn.AvgPool1d(kernel_size=4, stride=2, padding=1) (discriminator.py:140,153) on (rows, T); bwd: dx = pool^T dy + add. */
 int stegan_avgpool421_fwd(const float* x, float* y, int64_t rows, int32_t T, void* stream);
 int stegan_avgpool421_bwd(const float* dy, const float* add, float* dx, int64_t rows, int32_t T, void* stream);
+
+/* ---- frozen EMG encoder: attention + LayerNorm on the (B, C, T) layout ----------------------- */
+/*
+ * Multi-head self attention with learned relative-position logits
+ * (ste_gan/layers/transformer.py:88-113 + :168-306, eval mode: no dropout).
+ * qkv: (B, 3*H*A, T), channel = {q,k,v}*H*A + h*A + a (the fused projection conv's output);
+ * rel_emb: (H, 2*max_rel-1, A) (= relative_positional.embeddings[...,0]);
+ * logits[i,j] = q_i.k_j/sqrt(A) + q_i.emb[h, max_rel-1+(j-i)]  for |j-i| <= max_rel-1, -1e8 added beyond;
+ * probs: (B,H,T,T) softmax (saved for backward); out: (B, H*A, T) = sum_j probs[i,j] v_j.
+ * _bwd: gradient w.r.t. qkv only (the encoder is frozen); workspace: B*H*T*T floats.
+ */
+int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B, int32_t H,
+                                int32_t A, int32_t T, int32_t max_rel, void* stream);
+int stegan_relpos_attention_bwd(const float* qkv, const float* rel_emb, const float* probs, const float* dout,
+                                float* workspace, float* dqkv, int32_t B, int32_t H, int32_t A, int32_t T,
+                                int32_t max_rel, void* stream);
+/*
+ * y = LayerNorm_C(x + residual) * gamma + beta over the channel axis of (B,C,T)
+ * (post-LN residual blocks, transformer.py:56-60; nn.LayerNorm eps 1e-5).  xhat (B,C,T) / rstd (B*T)
+ * are saved for _bwd, which returns dz = d/d(x+residual) (the same tensor is the gradient of both).
+ */
+int stegan_add_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                             float* xhat, float* rstd, int32_t B, int32_t C, int32_t T, float eps, void* stream);
+int stegan_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dz,
+                             int32_t B, int32_t C, int32_t T, void* stream);
 
 /* ---- losses: scalar (accumulated into *loss_slot, a device float) + input gradient in one pass ---- */
 /*

@@ -50,6 +50,10 @@ SIGNATURES = {
     "stegan_multi_td_fwd_bwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, C.c_float, _P, _P, _P, _P, _P],
     "stegan_su_loss_fwd_bwd": [_P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P],
     "stegan_phoneme_ce_fwd_bwd": [_P, _P, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P],
+    "stegan_relpos_attention_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "stegan_relpos_attention_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "stegan_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float, _P],
+    "stegan_add_layernorm_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
 }

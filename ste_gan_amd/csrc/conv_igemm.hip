@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                     const size_t idx = ((size_t)q0 * p.Cout + co) * p.Tout + q1;
                     if (p.res) v += p.res[idx];
                     if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+                    else if (p.out_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
                     if (p.out_btc) p.out[((size_t)q0 * p.Tout + q1) * p.Cout + co] = v;
                     else p.out[idx] = v;
@@ -312,7 +313,7 @@ extern "C" int stegan_conv1d_fwd(const stegan_conv_desc* d, const float* x, cons
     int rc = fill_common(d, p);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && w && y);
-    STEGAN_CHECK_ARG(d->out_act == STEGAN_ACT_NONE || d->out_act == STEGAN_ACT_LRELU || d->out_act == STEGAN_ACT_TANH);
+    STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
     STEGAN_CHECK_ARG(!(d->out_btc && residual));
     p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.res = residual; p.out = y;
     p.M = p.Cout_g; p.N = d->B * d->Tout; p.R = p.Cin_g * p.K_eff;

@@ -11,9 +11,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         if (i + 3 < n) {
             float4 d = *reinterpret_cast<const float4*>(dy + i);
             const float4 v = *reinterpret_cast<const float4*>(y + i);
-            if (act == STEGAN_ACT_LRELU) {
-                d.x *= v.x > 0.f ? 1.f : 0.1f; d.y *= v.y > 0.f ? 1.f : 0.1f;
-                d.z *= v.z > 0.f ? 1.f : 0.1f; d.w *= v.w > 0.f ? 1.f : 0.1f;
+            if (act == STEGAN_ACT_LRELU || act == STEGAN_ACT_RELU) {
+                const float ns = act == STEGAN_ACT_LRELU ? 0.1f : 0.f;
+                d.x *= v.x > 0.f ? 1.f : ns; d.y *= v.y > 0.f ? 1.f : ns;
+                d.z *= v.z > 0.f ? 1.f : ns; d.w *= v.w > 0.f ? 1.f : ns;
             } else {
                 d.x *= 1.f - v.x * v.x; d.y *= 1.f - v.y * v.y;
                 d.z *= 1.f - v.z * v.z; d.w *= 1.f - v.w * v.w;
@@ -22,7 +23,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
         } else {
             for (long j = i; j < n; ++j) {
                 const float v = y[j];
-                out[j] = dy[j] * (act == STEGAN_ACT_LRELU ? (v > 0.f ? 1.f : 0.1f) : (1.f - v * v));
+                const float ns = act == STEGAN_ACT_LRELU ? 0.1f : 0.f;
+                out[j] = dy[j] * (act == STEGAN_ACT_TANH ? (1.f - v * v) : (v > 0.f ? 1.f : ns));
             }
         }
     }
@@ -32,7 +34,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 extern "C" int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream) {
     STEGAN_CHECK_ARG(dy && y && out && n > 0);
-    STEGAN_CHECK_ARG(act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH);
+    STEGAN_CHECK_ARG(act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH || act == STEGAN_ACT_RELU);
     STEGAN_CHECK_ARG(((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
     long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;

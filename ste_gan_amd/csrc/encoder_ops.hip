@@ -1,0 +1,211 @@
+// Frozen EMG-encoder pieces that are not convolutions: relative-position multi-head attention and
+// post-LayerNorm, both on the (B, C, T) layout the conv kernels use (C = model dim, T = frames).
+// T is tiny on this path (12 frames at chunk 200, 128 at chunk 2048), so these are latency-bound
+// VALU kernels: one block per (batch, head) / per (batch, frame tile).
+#include "common.h"
+
+namespace {
+
+// qkv: (B, 3*C, T), channel = which*C + h*A + a.   emb: (H, 2R-1, A).   P out: (B,H,T,T).  O out: (B, C, T)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
+                                                       float* __restrict__ P, float* __restrict__ O, int H, int A,
+                                                       int T, int R, float inv_sqrt_d) {
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int Cm = H * A;
+    const float* q = qkv + ((size_t)b * 3 * Cm + 0 * Cm + h * A) * T;
+    const float* k = qkv + ((size_t)b * 3 * Cm + 1 * Cm + h * A) * T;
+    const float* v = qkv + ((size_t)b * 3 * Cm + 2 * Cm + h * A) * T;
+    const float* e = emb + (size_t)h * (2 * R - 1) * A;
+    float* Pb = P + (size_t)blockIdx.x * T * T;
+    // phase 1: logits
+    for (int ij = threadIdx.x; ij < T * T; ij += 256) {
+        const int i = ij / T, j = ij % T;
+        const int rel = j - i;
+        float s;
+        if (rel > R - 1 || rel < -(R - 1)) {
+            float qk = 0.f;
+            for (int a = 0; a < A; ++a) qk += q[a * T + i] * k[a * T + j];
+            s = qk * inv_sqrt_d + (-1e8f);      // zero embedding, then the -1e8 mask (transformer.py:256-263)
+        } else {
+            const float* er = e + (size_t)(rel + R - 1) * A;
+            float qk = 0.f, qe = 0.f;
+            for (int a = 0; a < A; ++a) {
+                const float qa = q[a * T + i];
+                qk += qa * k[a * T + j];
+                qe += qa * er[a];
+            }
+            s = qk * inv_sqrt_d + qe;
+        }
+        Pb[ij] = s;
+    }
+    __syncthreads();
+    // phase 2: row softmax, one wave per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < T; i += 4) {
+        float m = -INFINITY;
+        for (int j = lane; j < T; j += 64) m = fmaxf(m, Pb[i * T + j]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float se = 0.f;
+        for (int j = lane; j < T; j += 64) { const float ex = expf(Pb[i * T + j] - m); Pb[i * T + j] = ex; se += ex; }
+        se = wave_sum(se);
+        const float inv = 1.f / se;
+        for (int j = lane; j < T; j += 64) Pb[i * T + j] *= inv;
+    }
+    __syncthreads();
+    // phase 3: O[a][i] = sum_j P[i][j] v[a][j]
+    float* Ob = O + ((size_t)b * Cm + h * A) * T;
+    for (int ai = threadIdx.x; ai < A * T; ai += 256) {
+        const int a = ai / T, i = ai % T;
+        float s = 0.f;
+        for (int j = 0; j < T; ++j) s += Pb[i * T + j] * v[a * T + j];
+        Ob[ai] = s;
+    }
+}
+
+// dO: (B,C,T).  Outputs dqkv (B,3C,T).  dS is staged in the workspace (B,H,T,T).
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
+                                                       const float* __restrict__ P, const float* __restrict__ dO,
+                                                       float* __restrict__ dS, float* __restrict__ dqkv, int H, int A,
+                                                       int T, int R, float inv_sqrt_d) {
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int Cm = H * A;
+    const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
+    const float* q = qkv + base;
+    const float* k = qkv + base + (size_t)Cm * T;
+    const float* v = qkv + base + (size_t)2 * Cm * T;
+    float* dq = dqkv + base;
+    float* dk = dqkv + base + (size_t)Cm * T;
+    float* dv = dqkv + base + (size_t)2 * Cm * T;
+    const float* e = emb + (size_t)h * (2 * R - 1) * A;
+    const float* Pb = P + (size_t)blockIdx.x * T * T;
+    float* dSb = dS + (size_t)blockIdx.x * T * T;
+    const float* dOb = dO + ((size_t)b * Cm + h * A) * T;
+    // dP[i][j] = sum_a dO[a][i] v[a][j]
+    for (int ij = threadIdx.x; ij < T * T; ij += 256) {
+        const int i = ij / T, j = ij % T;
+        float s = 0.f;
+        for (int a = 0; a < A; ++a) s += dOb[a * T + i] * v[a * T + j];
+        dSb[ij] = s;
+    }
+    __syncthreads();
+    // dS = P * (dP - rowsum(dP*P)), one wave per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < T; i += 4) {
+        float r = 0.f;
+        for (int j = lane; j < T; j += 64) r += dSb[i * T + j] * Pb[i * T + j];
+        r = wave_sum(r);
+        for (int j = lane; j < T; j += 64) dSb[i * T + j] = Pb[i * T + j] * (dSb[i * T + j] - r);
+    }
+    __syncthreads();
+    for (int ai = threadIdx.x; ai < A * T; ai += 256) {
+        const int a = ai / T, i = ai % T;
+        // dv[a][i] = sum_r P[r][i] dO[a][r];  dk[a][i] = sum_r dS[r][i] q[a][r] / sqrt(d)
+        // dq[a][i] = sum_j dS[i][j] (k[a][j]/sqrt(d) + emb[rel(j-i)][a])
+        float sv = 0.f, sk = 0.f, sq = 0.f;
+        for (int r = 0; r < T; ++r) {
+            sv += Pb[r * T + i] * dOb[a * T + r];
+            sk += dSb[r * T + i] * q[a * T + r];
+            const int rel = r - i;
+            float kk = k[a * T + r] * inv_sqrt_d;
+            if (rel <= R - 1 && rel >= -(R - 1)) kk += e[(size_t)(rel + R - 1) * A + a];
+            sq += dSb[i * T + r] * kk;
+        }
+        dv[ai] = sv;
+        dk[ai] = sk * inv_sqrt_d;
+        dq[ai] = sq;
+    }
+}
+
+// y = LayerNorm_C(x + r) * gamma + beta on (B, C, T); one wave per (b, t) column; saves xhat and rstd
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ y, float* __restrict__ xhat,
+                                                     float* __restrict__ rstd, int B, int Cm, int T, float eps) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * T) return;
+    const int lane = threadIdx.x & 63;
+    const int b = col / T, t = col % T;
+    const size_t base = (size_t)b * Cm * T + t;
+    float s = 0.f;
+    for (int c = lane; c < Cm; c += 64) s += x[base + (size_t)c * T] + (r ? r[base + (size_t)c * T] : 0.f);
+    s = wave_sum(s);
+    const float mean = s / (float)Cm;
+    float vs = 0.f;
+    for (int c = lane; c < Cm; c += 64) {
+        const float d = x[base + (size_t)c * T] + (r ? r[base + (size_t)c * T] : 0.f) - mean;
+        vs += d * d;
+    }
+    vs = wave_sum(vs);
+    const float rs = rsqrtf(vs / (float)Cm + eps);
+    for (int c = lane; c < Cm; c += 64) {
+        const float xh = (x[base + (size_t)c * T] + (r ? r[base + (size_t)c * T] : 0.f) - mean) * rs;
+        if (xhat) xhat[base + (size_t)c * T] = xh;
+        y[base + (size_t)c * T] = xh * gamma[c] + beta[c];
+    }
+    if (lane == 0 && rstd) rstd[col] = rs;
+}
+
+// dz = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = gamma * dy     (z = x + r; dx = dr = dz)
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     float* __restrict__ dz, int B, int Cm, int T) {
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= B * T) return;
+    const int lane = threadIdx.x & 63;
+    const int b = col / T, t = col % T;
+    const size_t base = (size_t)b * Cm * T + t;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < Cm; c += 64) {
+        const float g = gamma[c] * dy[base + (size_t)c * T];
+        s1 += g;
+        s2 += g * xhat[base + (size_t)c * T];
+    }
+    s1 = wave_sum(s1) / (float)Cm;
+    s2 = wave_sum(s2) / (float)Cm;
+    const float rs = rstd[col];
+    for (int c = lane; c < Cm; c += 64) {
+        const float g = gamma[c] * dy[base + (size_t)c * T];
+        dz[base + (size_t)c * T] = rs * (g - s1 - xhat[base + (size_t)c * T] * s2);
+    }
+}
+
+}  // namespace
+
+extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B,
+                                           int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream) {
+    STEGAN_CHECK_ARG(qkv && rel_emb && probs && out && B > 0 && H > 0 && A > 0 && T > 0 && max_rel > 0);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, out, H, A, T,
+                       max_rel, 1.f / sqrtf((float)A));
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_relpos_attention_bwd(const float* qkv, const float* rel_emb, const float* probs, const float* dout,
+                                           float* workspace, float* dqkv, int32_t B, int32_t H, int32_t A, int32_t T,
+                                           int32_t max_rel, void* stream) {
+    STEGAN_CHECK_ARG(qkv && rel_emb && probs && dout && workspace && dqkv && B > 0 && H > 0 && A > 0 && T > 0);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, dout,
+                       workspace, dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A));
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_add_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
+                                        float* y, float* xhat, float* rstd, int32_t B, int32_t C, int32_t T, float eps,
+                                        void* stream) {
+    STEGAN_CHECK_ARG(x && gamma && beta && y && B > 0 && C > 0 && T > 0);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
+                       beta, y, xhat, rstd, B, C, T, eps);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                        float* dz, int32_t B, int32_t C, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(dy && xhat && rstd && gamma && dz && B > 0 && C > 0 && T > 0);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma,
+                       dz, B, C, T);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}

@@ -466,3 +466,98 @@ class _PhonemeCEFn(torch.autograd.Function):
 
 def phoneme_ce(logits, targets, silence_index):
     return _PhonemeCEFn.apply(logits, targets, silence_index)
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd: frozen-weight ops of the EMG encoder (gradient w.r.t. the activation only)
+# ---------------------------------------------------------------------------------------------
+class _FrozenConvFn(torch.autograd.Function):
+    """y = out_act(scale * (w (*) x) + bias + residual) with constant w / scale / bias: backward yields dx (+ dres)."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, bias, residual, cfg: ConvCfg):
+        y = conv1d_fwd(x, w, scale, bias, residual, cfg)
+        ctx.cfg = cfg
+        ctx.has_res = residual is not None
+        ctx.tin = x.shape[2]
+        ctx.save_for_backward(w, scale, y if cfg.out_act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cfg: ConvCfg = ctx.cfg
+        w, scale, y = ctx.saved_tensors
+        dy = _gpu_f32(dy, "grad_output")
+        if cfg.out_btc:
+            dy = dy.transpose(1, 2).contiguous()
+            if y is not None:
+                y = y.transpose(1, 2).contiguous()
+        if cfg.out_act != ACT_NONE:
+            dy = act_bwd(dy, y, cfg.out_act)
+        dx = conv1d_bwd_data(dy, w, scale, None, None, cfg, ctx.tin) if ctx.needs_input_grad[0] else None
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        return dx, None, None, None, dres, None
+
+
+def frozen_conv1d(x, w, scale, bias, residual, cfg: ConvCfg) -> Tensor:
+    return _FrozenConvFn.apply(x, w, scale, bias, residual, cfg)
+
+
+class _RelPosAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, rel_emb, H: int, max_rel: int):
+        qkv = _gpu_f32(qkv, "qkv")
+        B, C3, T = qkv.shape
+        Cm = C3 // 3
+        A = Cm // H
+        probs = torch.empty((B, H, T, T), device=qkv.device, dtype=torch.float32)
+        out = torch.empty((B, Cm, T), device=qkv.device, dtype=torch.float32)
+        check(_lib.lib().stegan_relpos_attention_fwd(_p(qkv), _p(rel_emb), _p(probs), _p(out), B, H, A, T, max_rel,
+                                                     _stream()), "stegan_relpos_attention_fwd")
+        ctx.dims = (B, H, A, T, max_rel)
+        ctx.save_for_backward(qkv, rel_emb, probs)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, rel_emb, probs = ctx.saved_tensors
+        B, H, A, T, max_rel = ctx.dims
+        dout = _gpu_f32(dout, "grad_output")
+        ws = torch.empty_like(probs)
+        dqkv = torch.empty_like(qkv)
+        check(_lib.lib().stegan_relpos_attention_bwd(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(ws), _p(dqkv), B, H, A,
+                                                     T, max_rel, _stream()), "stegan_relpos_attention_bwd")
+        return dqkv, None, None, None
+
+
+def relpos_attention(qkv, rel_emb, H, max_rel):
+    return _RelPosAttnFn.apply(qkv, rel_emb, H, max_rel)
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps: float):
+        x = _gpu_f32(x, "x")
+        residual = _gpu_f32(residual, "residual")
+        B, Cm, T = x.shape
+        y = torch.empty_like(x)
+        xhat = torch.empty_like(x)
+        rstd = torch.empty(B * T, device=x.device, dtype=torch.float32)
+        check(_lib.lib().stegan_add_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), B,
+                                                  Cm, T, eps, _stream()), "stegan_add_layernorm_fwd")
+        ctx.save_for_backward(xhat, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, rstd, gamma = ctx.saved_tensors
+        dy = _gpu_f32(dy, "grad_output")
+        B, Cm, T = dy.shape
+        dz = torch.empty_like(dy)
+        check(_lib.lib().stegan_add_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dz), B, Cm, T, _stream()),
+              "stegan_add_layernorm_bwd")
+        return dz, dz, None, None, None
+
+
+def add_layernorm(x, residual, gamma, beta, eps=1e-5):
+    return _AddLayerNormFn.apply(x, residual, gamma, beta, eps)

@@ -214,6 +214,18 @@ int stegan_phoneme_ce_fwd_bwd(const float* logits, const int64_t* targets, int32
                               int32_t silence_index, float weight, float* loss_slot, int32_t* counters,
                               float* dlogits, int64_t* argmax_out, float* workspace, void* stream);
 
+/* ---- optimiser -------------------------------------------------------------------------------- */
+/*
+ * One AdamW step (decoupled weight decay; torch.optim.AdamW single-tensor arithmetic) over a flat
+ * arena of n fp32 parameters -- replaces ste_gan.OPTIMIZER(...).step() (constants.py:57, train.py:199,267).
+ * hyper_dev = device float[3] {lr, 1-beta1^t, 1-beta2^t} (kept on the device so a captured graph
+ * can be replayed with new values).  grads are multiplied by grad_scale first (1/world_size after a
+ * sum all-reduce).  All arenas 16-byte aligned.
+ */
+int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                      float grad_scale, void* stream);
+
 /* ---- elementwise helpers of the backward pass --------------------------------------------- */
 /* dx[b,c,t] = dxe[b,c,2t] + dxe[b,c,2t+1]   (backward of nn.Upsample(scale_factor=2), conv.py:40,55) */
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "stegan_relpos_attention_bwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "stegan_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float, _P],
     "stegan_add_layernorm_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stegan_adamw_step": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
 }

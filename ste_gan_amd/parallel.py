@@ -1,0 +1,58 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL over xGMI (torch.distributed "nccl").
+
+The batch dimension shards across ranks (independent samples; no BatchNorm in G / D, the encoder's is in
+eval mode), so the only data-path exchange is the mean of the two flat gradient arenas, once per optimiser
+step each.  The all-reduce is enqueued on a dedicated side stream so it overlaps
+compute that does not depend on it; ``wait`` makes the compute stream depend on its completion
+(stream-ordered, no host sync).  With the "gloo" backend (CPU tensors, used by the CPU tests) the same class
+degrades to a blocking all-reduce.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class FlatGradAllReduce:
+    def __init__(self, process_group=None):
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self._stream: Optional[torch.cuda.Stream] = None
+
+    def launch(self, flat_grad: torch.Tensor):
+        """SUM all-reduce of the arena (the 1/world_size factor is folded into the AdamW kernel's grad_scale)."""
+        if not flat_grad.is_cuda:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat_grad.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(flat_grad.device))
+        self._stream.wait_event(ready)                      # gradients fully written before the exchange starts
+        with torch.cuda.stream(self._stream):
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        flat_grad.record_stream(self._stream)
+        return done
+
+    def wait(self, handle) -> None:
+        if handle is not None:
+            torch.cuda.current_stream().wait_event(handle)
+
+
+def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
+    """Contiguous batch-dimension shard of a DataType-keyed batch dict for this rank."""
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() >= 1:
+            n = v.shape[0]
+            if n % world_size:
+                raise ValueError(f"batch size {n} is not divisible by world size {world_size}")
+            per = n // world_size
+            out[k] = v[rank * per:(rank + 1) * per]
+        else:
+            out[k] = v
+    return out

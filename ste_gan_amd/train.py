@@ -1,0 +1,376 @@
+"""STE-GAN trainer for MI355X -- drop-in for ``ste_gan/train.py``.
+
+``train(cfg, model_directory, checkpoint, torch_device, debug, emg_enc_ckpt)``, ``main`` and
+``parse_args`` keep the reference's signatures and CLI flags (train.py:39-46,505-574).  The hot loop
+(train.py:165-268) lives in :class:`GANTrainStep`:
+
+* same order of operations -- G forward; D(fake.detach()), D(real); LSGAN D loss; optD step; then with the
+  UPDATED D: D(fake), D(real); adversarial + multi-TD + speech-unit + phoneme + feature-matching losses;
+  optG step; the spectral-norm power iteration runs on each of the four D forwards;
+* every arithmetic op is a libstegan_hip.so kernel; no ``.item()`` inside the step -- the loss scalars and the
+  phoneme counters are read back once, by :meth:`GANTrainStep.read_stats`;
+* work the reference does only to throw away is skipped: D's weight gradients inside ``loss_G.backward()``
+  (zeroed by the next ``zero_grad``) and the frozen encoder's weight gradients;
+* one process per GPU: with ``torch.distributed`` initialised, the two flat gradient arenas (G, D) are
+  all-reduced over RCCL on a side HIP stream; the D-gradient exchange overlaps the multi-TD and EMG-encoder
+  losses, which do not depend on D.
+
+On the CPU the reference's autocast/GradScaler disable themselves, i.e. its parity path is plain fp32
+(SURVEY.md 3.3 (v)); this trainer computes in fp32 throughout.
+"""
+from __future__ import annotations
+
+import argparse
+import itertools
+import logging
+import random
+import sys
+import time
+from pathlib import Path
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import constants as K
+from .constants import DataType
+from .losses.emg_encoder_loss import EMGEncoderLoss, EMGEncoderLossOutput
+from .losses.gan_losses import feature_matching_loss, lsgan_loss
+from .losses.time_domain_loss import MultiTimeDomainFeatureLoss
+from .models.discriminator import init_emg_discriminators
+from .models.emg_encoder import load_emg_encoder
+from .models.generator import init_emg_generator
+from .optim import ExponentialLR, FlatParams, FusedAdamW
+from .parallel import FlatGradAllReduce
+from .train_utils import (add_eval_hyperparams_to_parser, create_ste_gan_model_name, load_config, mean_error,
+                          phoneme_accuracy, phoneme_accuracy_no_silence)
+from .utils.common import load_latest_checkpoint
+
+
+def crop_to_hop(chunk_size: int) -> int:
+    """The generator emits 16 EMG samples per Soft-SU frame, so real EMG is cropped to (chunk//16)*16.
+
+    The reference's collate keeps ``chunk_size`` real samples (data/collate.py:44,81-83) and its own step
+    then fails for chunk sizes that are not multiples of 16."""
+    return (chunk_size // K.HOPSIZE) * K.HOPSIZE
+
+
+class GANTrainStep:
+    """One iteration of ``ste_gan/train.py:165-268`` on one GPU (one rank of a data-parallel job)."""
+
+    def __init__(self, cfg, netG, netD, emg_encoder_loss: Optional[EMGEncoderLoss], multi_td_loss,
+                 optG: FusedAdamW, optD: FusedAdamW, process_group=None):
+        self.cfg = cfg
+        self.netG, self.netD = netG, netD
+        self.emg_encoder_loss, self.multi_td_loss = emg_encoder_loss, multi_td_loss
+        self.optG, self.optD = optG, optD
+        self.speech_feature_type = cfg.model.speech_feature_type
+        self.d_params = [p for p in netD.parameters()]
+        self.comm = FlatGradAllReduce(process_group) if dist.is_available() and dist.is_initialized() else None
+        self.last: Dict[str, torch.Tensor] = {}
+
+    def _set_d_grad(self, flag: bool):
+        for p in self.d_params:
+            p.requires_grad_(flag)
+
+    def __call__(self, batch_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        cfg, t = self.cfg, self.cfg.train
+        netG, netD = self.netG, self.netD
+        self.optD.zero_grad()
+        self.optG.zero_grad()
+        x_t = batch_dict[DataType.REAL_EMG]
+        speech_units_t = batch_dict[DataType.SPEECH_UNITS]
+        sess_idx = batch_dict[DataType.SESSION_INDEX]
+        spk_mode_idx = batch_dict[DataType.SPEAKING_MODE_INDEX]
+        phoneme_targets = batch_dict[DataType.PHONEMES]
+        s_t1 = speech_units_t if self.speech_feature_type == DataType.SPEECH_UNITS else batch_dict[self.speech_feature_type]
+        out: Dict[str, torch.Tensor] = {}
+
+        netG.train()
+        x_pred_t = netG(s_t1, sess_idx, spk_mode_idx)                                   # train.py:182
+
+        # ---- discriminator step (train.py:189-199)
+        d_handle = None
+        if t.loss_adversarial:
+            D_fake_det = netD(x_pred_t.detach())
+            D_real = netD(x_t)
+            loss_D = lsgan_loss(D_fake_det, 0.0) + lsgan_loss(D_real, 1.0)
+            loss_D.backward()
+            out["discriminator"] = loss_D.detach()
+            if self.comm is not None:
+                d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
+
+        # ---- D-independent generator losses first: they overlap the D-gradient all-reduce
+        loss_G = 0
+        if t.loss_multi_td_error:
+            td_error = self.multi_td_loss(x_t, x_pred_t)
+            loss_G = loss_G + t.loss_multi_td_weight * td_error
+            out["multi_td"] = td_error.detach()
+        enc_out: Optional[EMGEncoderLossOutput] = None
+        if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
+            enc_out = self.emg_encoder_loss(x_pred_t, speech_units_t, phoneme_targets)
+            if t.loss_speech_unit_error:
+                loss_G = loss_G + t.loss_speech_unit_weight * enc_out.speech_unit_loss
+                out["speech_unit"] = enc_out.speech_unit_loss.detach()
+            if t.loss_phoneme_error:
+                loss_G = loss_G + t.loss_phoneme_weight * enc_out.phoneme_loss
+                out["phoneme"] = enc_out.phoneme_loss.detach()
+            out["phoneme_counters"] = enc_out._counters
+        if t.loss_waveform_error:
+            from . import ops
+            wave_loss = ops.mse_loss(x_pred_t, x_t)
+            loss_G = loss_G + t.loss_waveform_weight * wave_loss
+            out["waveform"] = wave_loss.detach()
+
+        if t.loss_adversarial:
+            if d_handle is not None:
+                self.comm.wait(d_handle)
+                self.optD.step(grad_scale=1.0 / self.comm.world_size)
+            else:
+                self.optD.step()                                                         # D weights change HERE
+
+        # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
+        self._set_d_grad(False)          # D's weight grads from loss_G are discarded by the reference: skip them
+        try:
+            D_fake = netD(x_pred_t)
+            with torch.no_grad():
+                D_real = netD(x_t)
+            if t.loss_adversarial:
+                loss_G = loss_G + lsgan_loss(D_fake, 1.0)
+            if t.loss_feat_match_error:
+                loss_feat = feature_matching_loss(D_fake, D_real)
+                loss_G = loss_G + t.loss_feat_match_weight * loss_feat
+                out["feature_matching"] = loss_feat.detach()
+            loss_G.backward()
+        finally:
+            self._set_d_grad(True)
+        if self.comm is not None:
+            self.comm.wait(self.comm.launch(self.optG.flat.grad))
+            self.optG.step(grad_scale=1.0 / self.comm.world_size)
+        else:
+            self.optG.step()
+        out["generator"] = loss_G.detach()
+        out["x_pred"] = x_pred_t.detach()
+        self.last = out
+        return out
+
+    @staticmethod
+    def read_stats(out: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        """Single synchronising readback of the step's scalars (the reference pays ~10 .item() syncs)."""
+        keys = [k for k in out if k not in ("x_pred", "phoneme_counters")]
+        vals = torch.stack([out[k].float().reshape(()) for k in keys]).tolist()
+        stats = dict(zip(keys, vals))
+        if "phoneme_counters" in out:
+            c = out["phoneme_counters"].tolist()
+            stats.update(num_phones=c[0], num_silence_phones=c[1], num_correct_phones=c[2],
+                         num_correct_phones_no_silence=c[3])
+        return stats
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    add_figure = add_scalar
+
+
+def _summary_writer(model_directory: Path):
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+        return SummaryWriter(str(model_directory.absolute()))
+    except Exception:                     # tensorboard is not installed in every image
+        logging.warning("tensorboard unavailable: scalars are logged to the text log only")
+        return _NullWriter()
+
+
+def build_training_objects(cfg, device, emg_enc_ckpt):
+    netG = init_emg_generator(cfg).to(device)
+    netD = init_emg_discriminators(cfg).to(device)
+    emg_encoder = load_emg_encoder(cfg, device, emg_enc_ckpt)
+    emg_encoder.eval().to(device)
+    multi_td_loss = MultiTimeDomainFeatureLoss(cfg.data.num_emg_channels).to(device)
+    emg_encoder_loss = EMGEncoderLoss(emg_encoder).to(device)
+    optG = FusedAdamW(FlatParams(netG))
+    optD = FusedAdamW(FlatParams(netD))
+    return netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD
+
+
+def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug: bool, emg_enc_ckpt: Path = None,
+          loaders=None):
+    """Full training run -- ste_gan/train.py:39-499.  ``loaders`` = (train, valid, test) DataLoaders whose batches
+    are dicts keyed by ``DataType`` (data/collate.py:54-61); when omitted they come from ``loaders_via_config``."""
+    device = torch.device(torch_device)
+    if device.type != "cuda":
+        raise RuntimeError("ste_gan_amd.train runs on MI355X (cuda device) only; there is no CPU fallback")
+    logging.info("Initializing Models")
+    netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD = build_training_objects(cfg, device, emg_enc_ckpt)
+    writer = _summary_writer(model_directory)
+    if checkpoint is not None:
+        logging.info(f"Loading checkpoint: {checkpoint}")
+        netG, netD, optG, optD, start_epoch, steps = load_latest_checkpoint(checkpoint, device, netG, netD, optG, optD)
+    else:
+        start_epoch, steps = -1, 0
+    scheduler_g = ExponentialLR(optG, gamma=.999, last_epoch=start_epoch if checkpoint is not None else -1)
+    scheduler_d = ExponentialLR(optD, gamma=.999, last_epoch=start_epoch if checkpoint is not None else -1)
+
+    np.random.seed(cfg.train.random_seed)
+    torch.cuda.manual_seed(cfg.train.random_seed)
+    torch.manual_seed(cfg.train.random_seed)
+    random.seed(cfg.train.random_seed)
+    if loaders is None:
+        try:
+            from .data.loader import loaders_via_config
+        except ImportError as e:
+            raise NotImplementedError("dataset loading (ste_gan/data) is outside the accelerated path this round: pass "
+                                      "loaders=(train, valid, test) yielding DataType-keyed batch dicts") from e
+        loaders = loaders_via_config(cfg)
+    train_loader, valid_loader, test_loader = loaders
+
+    step_fn = GANTrainStep(cfg, netG, netD, emg_encoder_loss, multi_td_loss, optG, optD)
+    speech_feature_type = cfg.model.speech_feature_type
+    crop = crop_to_hop(cfg.train.chunk_size)
+    if crop != cfg.train.chunk_size:
+        logging.warning(f"chunk_size {cfg.train.chunk_size} is not a multiple of {K.HOPSIZE}: real EMG is cropped to {crop}")
+    log_start = time.time()
+    best_su_loss = np.inf
+    tags = ("discriminator", "multi_td", "speech_unit", "phoneme", "waveform", "feature_matching", "generator")
+    for epoch in itertools.count(start_epoch):
+        logging.info(f"Starting epoch {epoch + 1}")
+        acc = dict(n=0, ok=0, sil=0, ok_ns=0)
+        for iterno, batch_dict in enumerate(train_loader):
+            batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch_dict.items()}
+            if batch[DataType.REAL_EMG].shape[1] > crop >= K.HOPSIZE:
+                batch[DataType.REAL_EMG] = batch[DataType.REAL_EMG][:, :crop].contiguous()
+            out = step_fn(batch)
+            stats = step_fn.read_stats(out)
+            for tag in tags:
+                if tag in stats:
+                    writer.add_scalar(f"train_loss/{tag}", stats[tag], steps)
+            if "num_phones" in stats:
+                acc["n"] += stats["num_phones"]; acc["ok"] += stats["num_correct_phones"]
+                acc["sil"] += stats["num_silence_phones"]; acc["ok_ns"] += stats["num_correct_phones_no_silence"]
+                writer.add_scalar("train_loss/phoneme_acc_batch",
+                                  phoneme_accuracy(stats["num_phones"], stats["num_correct_phones"]), steps)
+                writer.add_scalar("train_loss/phoneme_acc_batch_no_sil",
+                                  phoneme_accuracy_no_silence(stats["num_phones"], stats["num_correct_phones_no_silence"],
+                                                              stats["num_silence_phones"]), steps)
+            if steps % cfg.train.interval_log == 0:
+                pa = phoneme_accuracy(acc["n"], acc["ok"])
+                pa_ns = phoneme_accuracy_no_silence(acc["n"], acc["ok_ns"], acc["sil"])
+                logging.info(f"Epoch {epoch} ({iterno}/{len(train_loader)}) | Steps {steps} | ms/batch "
+                             f"{1e3 * (time.time() - log_start) / cfg.train.interval_log:5.2f} | Train Loss: "
+                             f"{stats['generator']:.4f} | Ph. Acc. (Avg.) {pa:.2f} | Ph. Acc. Avg. (No Sil) {pa_ns:.2f}")
+                writer.add_scalar("train_loss/phoneme_accuracy_avg", pa, steps)
+                writer.add_scalar("train_loss/phoneme_accuracy_avg_no_sil", pa_ns, steps)
+                log_start = time.time()
+
+            if steps % cfg.train.interval_valid == 0:
+                val = validate(netG, multi_td_loss, emg_encoder_loss, valid_loader, speech_feature_type, device)
+                for k, v in val.items():
+                    writer.add_scalar(f"val_loss/{k}", v, steps)
+                logging.info(" | ".join(f"val {k}: {v:.5f}" for k, v in val.items()))
+                if val["speech_unit"] < best_su_loss:
+                    best_su_loss = val["speech_unit"]
+                    torch.save(netG.state_dict(), model_directory / "best_netG.pt")
+                    torch.save(netD.state_dict(), model_directory / "best_netD.pt")
+
+            if steps % cfg.train.interval_save == 0:
+                save_checkpoint(model_directory, f"{steps:08d}", netG, netD, optG, optD, epoch, steps)
+            if steps >= cfg.train.max_steps:
+                save_checkpoint(model_directory, "final", netG, netD, optG, optD, epoch, steps)
+                (model_directory / ".done").touch()
+                return
+            steps += 1
+            if debug:
+                break
+        scheduler_g.step()
+        scheduler_d.step()
+        if epoch % 5 == 0:
+            save_checkpoint(model_directory, "last", netG, netD, optG, optD, epoch, steps)
+        if debug:
+            return
+
+
+def save_checkpoint(model_directory: Path, tag: str, netG, netD, optG, optD, epoch: int, steps: int):
+    """File naming of train.py:421-457,478-494: netG-*.pt, netD-*.pt, checkpoint-*.pt = {epoch, steps, optG, optD}."""
+    torch.save(netG.state_dict(), model_directory / f"netG-{tag}.pt")
+    torch.save(netD.state_dict(), model_directory / f"netD-{tag}.pt")
+    torch.save({"epoch": epoch, "steps": steps, "optG": optG.state_dict(), "optD": optD.state_dict()},
+               model_directory / f"checkpoint-{tag}.pt")
+
+
+@torch.no_grad()
+def validate(netG, multi_td_loss, emg_encoder_loss, valid_loader, speech_feature_type, device) -> Dict[str, float]:
+    """Validation pass of train.py:292-378 (fp32 here; the reference autocasts to fp16 on CUDA)."""
+    from . import ops
+    netG.eval()
+    td, su, ph, wav = [], [], [], []
+    n = ok = sil = ok_ns = 0
+    for feat_batch in valid_loader:
+        x_t = feat_batch[DataType.REAL_EMG].to(device)
+        s_t = feat_batch[speech_feature_type].to(device)
+        su_t = s_t if speech_feature_type == DataType.SPEECH_UNITS else feat_batch[DataType.SPEECH_UNITS].to(device)
+        x_pred = netG(s_t, feat_batch[DataType.SESSION_INDEX].to(device), feat_batch[DataType.SPEAKING_MODE_INDEX].to(device))
+        T = min(x_pred.shape[1], x_t.shape[1])
+        x_t, x_pred = x_t[:, :T].contiguous(), x_pred[:, :T].contiguous()
+        eo = emg_encoder_loss(x_pred, su_t, feat_batch[DataType.PHONEMES].to(device))
+        scal = torch.stack([ops.mse_loss(x_pred, x_t), multi_td_loss(x_t, x_pred), eo.speech_unit_loss, eo.phoneme_loss]).tolist()
+        wav.append(scal[0]); td.append(scal[1]); su.append(scal[2]); ph.append(scal[3])
+        n += eo.num_phones; ok += eo.num_correct_phones; sil += eo.num_silence_phones; ok_ns += eo.num_correct_phones_no_silence
+    return {"speech_unit": float(mean_error(su)), "multi_td": float(mean_error(td)), "phoneme": float(mean_error(ph)),
+            "phoneme_accuracy_avg": phoneme_accuracy(n, ok),
+            "phoneme_accuracy_avg_no_sil": phoneme_accuracy_no_silence(n, ok_ns, sil), "waveform": float(mean_error(wav))}
+
+
+def main(cfg, continue_run: bool, debug: bool, emg_enc_ckpt: Path, **kwargs):
+    """Entry point -- ste_gan/train.py:503-546 (same keyword arguments: ``main(**vars(args))``)."""
+    print(f"Data root: {cfg.data.dataset_root}\ncontinue_run: {continue_run}\nDebug (argparse): {debug}")
+    debug = debug or bool(cfg.train.debug)
+    output_directory = Path(cfg.model_base_dir) / create_ste_gan_model_name(cfg, add_timestamp=False, debug=debug)
+    checkpoint = output_directory if (output_directory.exists() and continue_run) else None
+    output_directory.mkdir(exist_ok=True, parents=True)
+    print(f"Output directory: {output_directory}")
+    done_file = output_directory / ".done"
+    if done_file.exists():
+        logging.warning(f"Exiting training script as '.done' file exists: {done_file.absolute()}")
+        sys.exit()
+    config_file = output_directory / "config.yaml"
+    if not config_file.exists():
+        import yaml
+        with open(config_file, "w") as fp:
+            yaml.safe_dump(_plain(cfg), fp)
+    logging.getLogger().setLevel(logging.INFO)
+    logging.getLogger().addHandler(logging.FileHandler(str((output_directory / "log.txt").absolute())))
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    train(cfg, output_directory, checkpoint, device, debug, emg_enc_ckpt)
+
+
+def _plain(d):
+    return {k: _plain(v) for k, v in d.items()} if isinstance(d, dict) else d
+
+
+def parse_args(argv=None):
+    """CLI of ste_gan/train.py:549-574."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--config", type=str, default="configs/ste_gan_base_gantts.yaml",
+                        help="The main training configuration for this run.")
+    parser.add_argument("--data", type=str, default="configs/data/gaddy_and_klein_corpus.yaml",
+                        help="A path to a data configuration file.")
+    parser.add_argument("--emg_enc_cfg", type=str, default="configs/emg_encoder/conv_transformer.yaml",
+                        help="A path to an EMG encoder configuration file.")
+    parser.add_argument("--emg_enc_ckpt", type=str,
+                        default="exp/emg_encoder/EMGEncoderTransformer_voiced_only__seq_len__200__data_gaddy_complete/"
+                                "best_val_loss_model.pt",
+                        help="Checkpoint of the pre-trained EMG encoder matching --emg_enc_cfg.")
+    parser.add_argument("--checkpoint", type=Path, help="Optional checkpoint to start training from")
+    parser.add_argument("--continue_run", action="store_true", help="Whether to continue training")
+    parser.add_argument("--debug", action="store_true", help="Run the training script in debug mode.")
+    parser = add_eval_hyperparams_to_parser(parser)
+    return parser.parse_args(argv)
+
+
+if __name__ == "__main__":
+    _args = parse_args()
+    _args.cfg = load_config(_args)
+    main(**vars(_args))

@@ -43,7 +43,10 @@ ENC_CASES = {
 }
 
 # ---- train-step cases: name -> (gen channels, enc (model_size, layers, ff), B, T_su, steps)
-STEP_CASES = {"step_c48_b2": (48, (64, 2, 128), 2, 4, 2)}
+# (gradients are discontinuous at ReLU / leaky-ReLU kinks: make_golden.py asserts that no pre-activation of the
+# chosen case lies within 1e-6 of zero (fp32 path differences are ~1e-7), so fp32 rounding differences cannot flip a mask -- the first candidate,
+# B=2 T_su=4, had one generator activation at 1.6e-7 and was rejected for that reason)
+STEP_CASES = {"step_c48_b3": (48, (64, 2, 128), 3, 5, 2)}
 
 
 def gen_inputs(name):

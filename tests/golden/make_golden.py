@@ -181,6 +181,10 @@ def step_cases():
         optG = ste_gan.OPTIMIZER(netG.parameters())
         optD = ste_gan.OPTIMIZER(netD.parameters())
         rec = {}
+        relu_in = []
+        for m in netG.modules():
+            if isinstance(m, torch.nn.ReLU):
+                m.register_forward_hook(lambda mod, inp, out: relu_in.append(float(inp[0].detach().abs().min())))
         for step in range(steps):
             b = cases.step_batch(name, step)
             netD.zero_grad(); netG.zero_grad()
@@ -217,6 +221,10 @@ def step_cases():
             loss_G.backward()
             g_gn, g_gh = grad_summary([(k, p.grad) for k, p in netG.named_parameters()])
             optG.step()
+            margin_g = min(relu_in); relu_in.clear()
+            margin_d = min(float(fm.detach().abs().min()) for out in (D_fake, D_real) for sc in out for fm in sc[:-1])
+            print(f"  step {step}: kink margins  G relu inputs {margin_g:.2e}   D lrelu outputs {margin_d:.2e}")
+            assert margin_g > 1e-6, "a generator pre-activation sits on the ReLU kink: pick another case"
             tag = f"s{step}."
             rec[tag + "losses"] = np.array([loss_D.item(), loss_G.item(), adv.item(), td.item(),
                                             eo.speech_unit_loss.item(), eo.phoneme_loss.item(), fm.item()], np.float64)

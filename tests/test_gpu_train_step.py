@@ -1,0 +1,115 @@
+"""-m gpu: the full GAN train step (GANTrainStep = ste_gan/train.py:165-268 on MI355X) for two consecutive
+steps against the golden fixture recorded from the reference modules + torch.optim.AdamW on CPU:
+loss scalars, phoneme counters (bit-exact), generated EMG, per-tensor gradient norms of G and D, and the
+per-tensor parameter norms after each optimiser step (incl. spectral-norm u / v buffers)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import shapes as oshapes
+from oracle.detfill import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol, what):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert err <= rtol, f"{what}: max err {err:.3e}"
+
+
+def make_cfg(channels):
+    from ste_gan_amd.train_utils import DictConfig
+    import yaml, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs/ste_gan_base_gantts.yaml")))
+    cfg["data"] = yaml.safe_load(open(os.path.join(root, "configs/data/gaddy_and_klein_corpus.yaml")))
+    cfg["model"]["params"] = {"channels": channels}
+    return DictConfig(cfg)
+
+
+def build(name):
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.discriminator import init_emg_discriminators
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.optim import FlatParams, FusedAdamW
+    from ste_gan_amd.train import GANTrainStep
+    ch, (ms, nl, ff), B, T, steps = cases.STEP_CASES[name]
+    cfg = make_cfg(ch)
+    netG = init_emg_generator(cfg)
+    netG.load_state_dict(fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", ch)))
+    netD = init_emg_discriminators(cfg)
+    netD.load_state_dict(fill_state_dict(oshapes.discriminator_shapes(True)))
+    enc = EMGEncoderTransformer(8, 256, 48, model_size=ms, num_transformer_layers=nl, dim_feedforward=ff)
+    enc.load_state_dict(fill_state_dict(oshapes.encoder_shapes(ms, 3, nl, dim_feedforward=ff)))
+    netG, netD, enc = netG.cuda(), netD.cuda(), enc.cuda().eval()
+    optG, optD = FusedAdamW(FlatParams(netG)), FusedAdamW(FlatParams(netD))
+    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
+    return cfg, netG, netD, optG, optD, step
+
+
+def to_batch(b):
+    from ste_gan_amd.constants import DataType
+    return {DataType.REAL_EMG: b["x_real"].cuda(), DataType.SPEECH_UNITS: b["su"].cuda(),
+            DataType.SESSION_INDEX: b["sess"].cuda(), DataType.SPEAKING_MODE_INDEX: torch.zeros_like(b["sess"]).cuda(),
+            DataType.PHONEMES: b["phonemes"].cuda()}
+
+
+def norms(tensors):
+    return np.array([float(t.double().norm()) for t in tensors])
+
+
+@pytest.mark.parametrize("name", list(cases.STEP_CASES))
+def test_train_step_vs_golden(name, golden):
+    g = golden(name)
+    cfg, netG, netD, optG, optD, step = build(name)
+    steps = cases.STEP_CASES[name][4]
+    for s in range(steps):
+        out = step(to_batch(cases.step_batch(name, s)))
+        st = step.read_stats(out)
+        t = f"s{s}."
+        ref = g[t + "losses"]        # [loss_D, loss_G, adv, td, su, ph, fm]
+        close([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"],
+               st["feature_matching"]], ref[[0, 1, 3, 4, 5, 6]], 1e-4, t + "losses")
+        assert [st["num_phones"], st["num_silence_phones"], st["num_correct_phones"],
+                st["num_correct_phones_no_silence"]] == g[t + "counters"].tolist()
+        torch.testing.assert_close(out["x_pred"].cpu(), torch.from_numpy(g[t + "x_pred"]), rtol=1e-4, atol=1e-5)
+        gG = norms([p.grad for p in netG.parameters()])
+        np.testing.assert_allclose(gG, g[t + "g_grad_norm"], rtol=2e-3, atol=2e-5 * g[t + "g_grad_norm"].max())
+        # after the G step, netD's .grad still holds the gradients of loss_D (this path never adds loss_G's D grads)
+        gD = norms([p.grad for p in netD.parameters()])
+        np.testing.assert_allclose(gD, g[t + "d_grad_norm"], rtol=2e-3, atol=2e-5 * g[t + "d_grad_norm"].max())
+        close(norms(netG.state_dict().values()), g[t + "g_param_norm"], 2e-5, t + "g_param_norm")
+        close(norms(netD.state_dict().values()), g[t + "d_param_norm"], 2e-5, t + "d_param_norm")
+        heads = np.stack([np.pad(v.flatten()[:4].double().cpu().numpy(), (0, max(0, 4 - v.numel())))
+                          for v in netG.state_dict().values()])
+        close(heads, g[t + "g_param_head"], 2e-4, t + "g_param_head")
+
+
+def test_optimizer_state_dict_roundtrip():
+    """FusedAdamW speaks torch.optim.AdamW's checkpoint format (checkpoint-*.pt interchange)."""
+    from ste_gan_amd.optim import FlatParams, FusedAdamW
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(7, 5).cuda()
+    ref = torch.nn.Linear(7, 5).cuda()
+    ref.load_state_dict(lin.state_dict())
+    opt = FusedAdamW(FlatParams(lin))
+    topt = torch.optim.AdamW(ref.parameters(), lr=2e-4, betas=(.8, .99))
+    x = torch.randn(3, 7, device="cuda")
+    for _ in range(3):
+        opt.zero_grad(); topt.zero_grad()
+        lin(x).square().sum().backward(); ref(x).square().sum().backward()
+        opt.step(); topt.step()
+    for a, b in zip(lin.parameters(), ref.parameters()):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+    sd = opt.state_dict()
+    topt2 = torch.optim.AdamW(ref.parameters(), lr=2e-4, betas=(.8, .99))
+    topt2.load_state_dict(sd)                       # torch accepts our format
+    opt2 = FusedAdamW(FlatParams(torch.nn.Linear(7, 5).cuda()))
+    opt2.load_state_dict(topt.state_dict())         # and we accept torch's
+    assert opt2.step_count == 3
+    torch.testing.assert_close(opt2.exp_avg, opt.exp_avg, rtol=2e-5, atol=1e-7)

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the STE-GAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One "step" = one full GAN train step (ste_gan/train.py:165-268: G fwd, 4 D fwd, both backward passes,
+all losses incl. the frozen EMG encoder, 2 fused AdamW steps) on one synthetic batch per GPU:
+B=64, chunk_size=200 -> T_su=12 Soft-SU frames / T_emg=192 EMG samples, random-init
+full-size networks (G 768 ch, small D, 768-d 6-layer encoder), inputs resident in HBM before timing.
+Metric: EMG frames/s = n_gpus * B * 192 * steps / wall time (weak scaling).  dtype f32 (the parity path).
+
+Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (per-launch HIP-event
+timing of every conv launch in a separate instrumented pass; algorithmic FLOPs = nominal dense MACs x 2,
+SURVEY.md section 8d) and "cpu_baseline" (the oracle's train step -- a torch-CPU restatement of the reference
+-- timed on this box's host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B, T_SU, T_EMG = 64, 12, 192
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def make_cfg(workload):
+    import yaml
+    from ste_gan_amd.train_utils import DictConfig
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ste_gan_base_gantts.yaml")))
+    cfg["data"] = yaml.safe_load(open(os.path.join(ROOT, "configs", "data", "gaddy_and_klein_corpus.yaml")))
+    cfg["emg_encoder"] = yaml.safe_load(open(os.path.join(ROOT, "configs", "emg_encoder", "conv_transformer.yaml")))
+    cfg["train"]["batch_size"], cfg["train"]["chunk_size"] = B, 200
+    return DictConfig(cfg)
+
+
+def synthetic_batch(device, seed):
+    from ste_gan_amd.constants import DataType
+    g = torch.Generator().manual_seed(seed)
+    return {DataType.SPEECH_UNITS: torch.randn(B, T_SU, 256, generator=g).to(device),
+            DataType.REAL_EMG: torch.tanh(torch.randn(B, T_EMG, 8, generator=g)).to(device),
+            DataType.SESSION_INDEX: torch.randint(0, 17, (B,), generator=g).to(device),
+            DataType.SPEAKING_MODE_INDEX: torch.zeros(B, dtype=torch.long).to(device),
+            DataType.PHONEMES: torch.randint(0, 48, (B, T_SU), generator=g).to(device)}
+
+
+def build_step(cfg, device):
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.discriminator import init_emg_discriminators
+    from ste_gan_amd.models.emg_encoder import init_emg_encoder
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.optim import FlatParams, FusedAdamW
+    from ste_gan_amd.train import GANTrainStep
+    torch.manual_seed(0)                                  # identical replicas on every rank
+    netG = init_emg_generator(cfg).to(device)
+    netD = init_emg_discriminators(cfg).to(device)
+    enc = init_emg_encoder(cfg, device).eval()
+    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8),
+                        FusedAdamW(FlatParams(netG)), FusedAdamW(FlatParams(netD)))
+    return step
+
+
+def cpu_baseline(steps=2):
+    """Oracle (CPU restatement of the reference step, torch ATen/oneDNN fp32) on a bounded sample: B=64, 1+steps steps."""
+    from oracle import shapes as oshapes
+    from oracle import stegan_oracle as O
+    torch.manual_seed(0)
+
+    def rnd(shapes):
+        sd = {}
+        for k, s in shapes.items():
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.zeros((), dtype=torch.long)
+            elif k.endswith("running_var") or k.endswith("weight_g"):
+                sd[k] = torch.rand(s) + 0.5
+            else:
+                fan = max(1, int(torch.tensor(s[1:]).prod())) if len(s) > 1 else 1
+                sd[k] = torch.randn(s) / fan ** 0.5
+        return sd
+
+    g_sd, d_sd, e_sd = rnd(oshapes.generator_shapes()), rnd(oshapes.discriminator_shapes(True)), rnd(oshapes.encoder_shapes())
+    for k in d_sd:
+        if O.is_sn_buffer(d_sd, k):
+            d_sd[k] = torch.nn.functional.normalize(d_sd[k], dim=0)
+    d_train = {k: v for k, v in d_sd.items() if not O.is_sn_buffer(d_sd, k)}
+    og, od = O.adamw_init(g_sd), O.adamw_init(d_train)
+    gen = torch.Generator().manual_seed(0)
+    batch = {"su": torch.randn(B, T_SU, 256, generator=gen), "x_real": torch.tanh(torch.randn(B, T_EMG, 8, generator=gen)),
+             "sess": torch.randint(0, 17, (B,), generator=gen), "phonemes": torch.randint(0, 48, (B, T_SU), generator=gen)}
+    batch["feats"] = batch["su"]
+    O.train_step(g_sd, d_sd, e_sd, og, od, batch)                      # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        O.train_step(g_sd, d_sd, e_sd, og, od, batch)
+    dt = (time.time() - t0) / steps
+    return {"value": B * T_EMG / dt, "unit": "EMG frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} full train steps at B=64, T_emg=192 after 1 warm-up (oracle/stegan_oracle.py train_step, "
+                      f"torch-CPU fp32, {dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+
+    from ste_gan_amd import ops
+    cfg = make_cfg("train_step")
+    step = build_step(cfg, device)
+    batch = synthetic_batch(device, seed=1000 + rank)      # rank-offset seeds: different data per replica
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(batch)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = step.read_stats(step.last)
+
+    # ---- roofline of the dominant kernel: instrumented pass, HIP events around every conv launch
+    roof = None
+    if rank == 0:
+        ops.PROFILER = ops.ConvProfiler()
+        for _ in range(args.profile_steps):
+            step(batch)
+        agg = ops.PROFILER.summary()
+        ops.PROFILER = None
+        name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = a["ms"] / a["launches"]
+        flops_per_launch = 2.0 * a["nominal_macs"] / a["launches"]
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        all_ms = sum(v["ms"] for v in agg.values())
+        all_fl = 2.0 * sum(v["nominal_macs"] for v in agg.values())
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches_per_step": a["launches"] // args.profile_steps, "avg_launch_us": round(avg_ms * 1e3, 2),
+                "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 4),
+                "live_tap_frac": round(a["live_macs"] / a["nominal_macs"], 4),
+                "all_conv_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12 / 1.0, 3),
+                                     "ms_per_step": round(all_ms / args.profile_steps, 3),
+                                     "per_kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 3) for k, v in agg.items()}}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        frames = world * B * T_EMG * args.steps
+        line = {"metric": "EMG frames/sec (gen+disc fwd+bwd) at B=64 chunk=200", "value": round(frames / dt, 1),
+                "unit": "EMG frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "full GAN train step (G + small MPD/MSD D + multi-TD/SU/phoneme/FM losses + 2x AdamW), "
+                                       "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, fp32 parity path",
+                           "global_batch": world * B, "parallelism": f"dp{world}"},
+                "roofline": roof, "cpu_baseline": cpu,
+                "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

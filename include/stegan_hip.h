@@ -91,6 +91,17 @@ int stegan_conv1d_bwd_data(const stegan_conv_desc* d, const float* dy, const flo
 int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* db, void* stream);
 
+/* db[c] += sum_{b,t} dy[b,c,t] -- the bias gradient alone (also folded into stegan_conv1d_bwd_weight). */
+int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream);
+
+/*
+ * Launch plan of the three conv entry points (mode 0 = fwd, 1 = bwd_data, 2 = bwd_weight): the block tile edge
+ * (64 or 128 -> kernel instantiation conv_igemm_kernel<mode, tile/64, tile/64>), the number of reduction splits
+ * and the multiply-accumulates the matrix cores issue once dead (all-padding) taps are skipped.  Host only;
+ * used by bench.py to attribute measured kernel time to algorithmic work.
+ */
+int stegan_conv1d_plan(const stegan_conv_desc* d, int32_t mode, int32_t* tile, int32_t* splits, int64_t* live_macs);
+
 /* ---- weight re-parametrisations ---------------------------------------------------------- */
 /*
  * Multi-tensor weight-norm scale: for every conv i, scale_i[co] = g_i[co] / ||v_i[co,:]||_2

@@ -33,6 +33,8 @@ SIGNATURES = {
     "stegan_conv1d_fwd": [_D, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data": [_D, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_weight": [_D, _P, _P, _P, _P, _P],
+    "stegan_bias_grad": [_P, _P, _I32, _I32, _I32, _P],
+    "stegan_conv1d_plan": [_D, _I32, _P, _P, _P],
     "stegan_wn_scales": [_I32, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_wn_backward": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_wn_scale1": [_P, _P, _P, _I32, _I32, _P],

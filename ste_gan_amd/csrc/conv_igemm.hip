@@ -287,12 +287,27 @@ int fill_common(const stegan_conv_desc* d, ConvK& p) {
     return STEGAN_OK;
 }
 
+// tile choice: 128x128 when that still gives every CU >= 2 blocks, else 64x64
+inline bool use_big_tile(const ConvK& p, int groups, int splits) {
+    const long tiles128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * groups * splits;
+    return tiles128 >= 512 && p.M >= 96;
+}
+
+inline int bwd_weight_splits(ConvK& p, int groups) {
+    // split the (b,t) reduction so the grid fills the chip; partial sums meet in fp32 atomics
+    const int chunks = ceil_div(p.R, KC);
+    const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * groups;
+    int splits = (int)((1024 + tiles - 1) / tiles);
+    if (splits > chunks) splits = chunks;
+    if (splits < 1) splits = 1;
+    p.r_chunks_per_split = ceil_div(chunks, splits);
+    return ceil_div(chunks, p.r_chunks_per_split);
+}
+
 template <int MODE>
 int launch(const ConvK& p, int groups, int splits, hipStream_t s) {
-    // tile choice: 128x128 when that still gives every CU >= 2 blocks, else 64x64
-    const long tiles128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128) * groups * splits;
     ConvK q = p;
-    if (tiles128 >= 512 && p.M >= 96) {
+    if (use_big_tile(p, groups, splits)) {
         q.m_tiles = ceil_div(p.M, 128);
         dim3 grid(ceil_div(p.N, 128), q.m_tiles * groups, splits);
         hipLaunchKernelGGL((conv_igemm_kernel<MODE, 2, 2>), grid, dim3(256), 0, s, q);
@@ -344,19 +359,35 @@ extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* 
     p.x = x; p.dy = dy; p.out = dw;
     p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout;
     p.fdT = make_fastdiv((uint32_t)d->Tout);
-    // split the (b,t) reduction so the grid fills the chip; partial sums meet in fp32 atomics
-    const int chunks = ceil_div(p.R, KC);
-    const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * d->groups;
-    int splits = (int)((1024 + tiles - 1) / tiles);
-    if (splits > chunks) splits = chunks;
-    if (splits < 1) splits = 1;
-    p.r_chunks_per_split = ceil_div(chunks, splits);
-    splits = ceil_div(chunks, p.r_chunks_per_split);
+    const int splits = bwd_weight_splits(p, d->groups);
     rc = launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
     if (rc) return rc;
     if (db) {
         hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, db, d->B, d->Cout, d->Tout);
         STEGAN_LAUNCH_CHECK();
     }
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_plan(const stegan_conv_desc* d, int32_t mode, int32_t* tile, int32_t* splits,
+                                  int64_t* live_macs) {
+    ConvK p;
+    int rc = fill_common(d, p);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(mode >= 0 && mode <= 2 && tile && splits && live_macs);
+    int sp = 1;
+    if (mode == MODE_FWD) { p.M = p.Cout_g; p.N = d->B * d->Tout; p.R = p.Cin_g * p.K_eff; }
+    else if (mode == MODE_BWD_DATA) { p.M = p.Cin_g; p.N = d->B * p.Te; p.R = p.Cout_g * p.K_eff; }
+    else { p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout; sp = bwd_weight_splits(p, d->groups); }
+    *tile = use_big_tile(p, d->groups, sp) ? 128 : 64;
+    *splits = sp;
+    *live_macs = (int64_t)p.M * p.N * p.R * d->groups;      // MACs the MFMA loop actually issues (dead taps skipped)
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(dy && db && B > 0 && C > 0 && T > 0);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
+    STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

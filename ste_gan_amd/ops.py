@@ -65,6 +65,49 @@ def _desc(cfg: ConvCfg, B: int, tin: int, tout: int) -> ConvDesc:
 
 
 # ---------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py): HIP events on the stream the kernel is launched on
+# ---------------------------------------------------------------------------------------------
+class ConvProfiler:
+    """Collects (kernel instantiation, nominal MACs, live MACs, start/end event) for every conv launch."""
+
+    def __init__(self):
+        self.records = []
+
+    def plan(self, d: ConvDesc, mode: int):
+        tile, splits, live = C.c_int32(), C.c_int32(), C.c_int64()
+        check(_lib.lib().stegan_conv1d_plan(C.byref(d), mode, C.byref(tile), C.byref(splits), C.byref(live)),
+              "stegan_conv1d_plan")
+        nominal = d.B * d.Tout * d.Cout * (d.Cin // d.groups) * d.K
+        return f"conv_igemm_kernel<{mode}, {tile.value // 64}, {tile.value // 64}>", nominal, live.value
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, nominal, live, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, nominal_macs=0, live_macs=0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["nominal_macs"] += nominal
+            a["live_macs"] += live
+        return agg
+
+
+PROFILER: Optional[ConvProfiler] = None
+
+
+def _timed(d: ConvDesc, mode: int, fn):
+    if PROFILER is None:
+        return fn()
+    name, nominal, live = PROFILER.plan(d, mode)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    PROFILER.records.append((name, nominal, live, e0, e1))
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
 def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Tensor],
@@ -82,8 +125,8 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
         if residual.shape != y.shape:
             raise RuntimeError(f"residual shape {list(residual.shape)} does not match conv output {list(y.shape)}")
     d = _desc(cfg, B, tin, tout)
-    check(_lib.lib().stegan_conv1d_fwd(C.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(residual), _p(y), _stream()),
-          "stegan_conv1d_fwd")
+    check(_timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd(C.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(residual),
+                                                            _p(y), _stream())), "stegan_conv1d_fwd")
     return y
 
 
@@ -93,8 +136,9 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     B, _, tout = dy.shape
     dx = torch.empty((B, cfg.cin, tin * cfg.upsample), device=dy.device, dtype=torch.float32)
     d = _desc(cfg, B, tin, tout)
-    check(_lib.lib().stegan_conv1d_bwd_data(C.byref(d), _p(dy), _p(w), _p(scale), _p(mask_src), _p(add_src), _p(dx),
-                                            _stream()), "stegan_conv1d_bwd_data")
+    check(_timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data(C.byref(d), _p(dy), _p(w), _p(scale), _p(mask_src),
+                                                                 _p(add_src), _p(dx), _stream())),
+          "stegan_conv1d_bwd_data")
     return dx
 
 
@@ -102,8 +146,12 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     """Accumulates into dw (and db)."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
-    check(_lib.lib().stegan_conv1d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream()),
+    # the bias-gradient kernel is launched without db here so the timed region holds the GEMM kernel alone
+    check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw),
+                                                                   None if PROFILER is not None else _p(db), _stream())),
           "stegan_conv1d_bwd_weight")
+    if PROFILER is not None and db is not None:
+        check(_lib.lib().stegan_bias_grad(_p(dy), _p(db), B, cfg.cout, dy.shape[2], _stream()), "stegan_bias_grad")
 
 
 def wn_scale(v: Tensor, g: Tensor) -> Tensor:

@@ -91,6 +91,37 @@ int stegan_conv1d_bwd_data(const stegan_conv_desc* d, const float* dy, const flo
 int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* db, void* stream);
 
+/*
+ * Fast path of stegan_conv1d_fwd / stegan_conv1d_bwd_data (same semantics, same descriptors): the direct
+ * convolution kernel that keeps halo'd input rows in LDS and takes K-major transposed copies of the direction
+ * tensor, produced once per weight version by stegan_conv_prep:
+ *     wf[g][k][ci][co] (leading dimension round_up(Cout/groups, 64))  for the forward pass,
+ *     wb[g][k][co][ci] (leading dimension round_up(Cin/groups, 64))   for the input gradient, pre-multiplied by the
+ *                      per-output-channel `scale` (nullable) -- the weight-norm / BatchNorm factor; in
+ *                      stegan_conv1d_bwd_data_t `scale` is then only a nullable pointer to ONE uniform factor
+ *                      (spectral norm's 1/sigma, which changes on every forward).
+ * Buffers of stegan_conv_prep_floats(d, 0 | 1) floats; they must be ZERO-initialised once by the caller (prep only
+ * writes the unpadded part).  The *_t launches return 1 (nothing enqueued) for a shape they do not cover (more
+ * than 48 live taps per phase, or an input window that does not fit the LDS budget); the caller then uses the
+ * generic entry points.  A strided convolution's input gradient is decomposed into `stride` dense phases, so no
+ * multiply-accumulates are spent on the zero-inserted positions.
+ */
+int64_t stegan_conv_prep_floats(const stegan_conv_desc* d, int32_t which);
+int stegan_conv_prep(const stegan_conv_desc* d, const float* v, const float* scale, float* wf, float* wb, void* stream);
+/*
+ * When a launch would leave most CUs idle (small B*T), the reduction over channels is split over up to 16 blocks
+ * per output tile; the raw partial sums go to `workspace` (caller-owned, stegan_conv_workspace_floats(d, mode)
+ * floats is always enough; a smaller or NULL workspace just lowers / disables the split) and a second kernel sums
+ * them in a fixed order and applies the fused epilogue -- results stay bit-reproducible (no float atomics).
+ */
+int64_t stegan_conv_workspace_floats(const stegan_conv_desc* d, int32_t mode);
+int stegan_conv1d_fwd_t(const stegan_conv_desc* d, const float* x, const float* wf, const float* scale,
+                        const float* bias, const float* residual, float* y, float* workspace,
+                        int64_t workspace_floats, void* stream);
+int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* dy, const float* wb, const float* scale,
+                             const float* mask_src, const float* add_src, float* dx, float* workspace,
+                             int64_t workspace_floats, void* stream);
+
 /* db[c] += sum_{b,t} dy[b,c,t] -- the bias gradient alone (also folded into stegan_conv1d_bwd_weight). */
 int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream);
 

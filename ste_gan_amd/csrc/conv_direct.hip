@@ -1,0 +1,506 @@
+// Direct (im2col-free) 1-D convolution on the fp32 matrix cores, v2: halo'd input rows in LDS.
+//
+// Forward and input-gradient convolutions are the same computation
+//
+//     out[b, m, to(u)] = sum_{c2, tap}  W[tap][c2][m] * src[b, c2, u*cs + off[tap]]        (zero outside [0, Tq))
+//
+//   FWD        m = co, c2 = ci, src = relu?(upsample?(x)), cs = stride, off[k] = k*dil - pad, to(u) = u
+//   BWD_DATA   m = ci, c2 = co, src = scale[co]*dy; for each output phase phi = te mod stride only the taps with
+//              (phi + pad - k*dil) % stride == 0 contribute, off[k] = (phi+pad-k*dil)/stride, cs = 1,
+//              to(u) = phi + u*stride  -> a strided conv's input gradient costs no wasted MACs (grid.z = phase)
+//
+// Per block (256 threads = 2x2 wave64, tile 64 (m) x BN (n = flattened (b,u)), BN = 64 or 128):
+//   * for a chunk of CC source channels, every (channel, batch-segment) input row the tile needs is copied ONCE,
+//     with its halo, into LDS (coalesced along time; zero padding, ReLU, nearest-x2 upsample and the per-channel
+//     dy scale are applied on the way in) -- each sample is read from HBM/L2 once per chunk instead of K times and
+//     the per-element index arithmetic of an im2col gather disappears (the lane -> source offsets are chunk
+//     invariant and live in registers);
+//   * the weight tile comes from a K-major, output-channel-contiguous copy of the direction tensor
+//     (stegan_conv_prep: Wf[g][k][ci][co], Wb[g][k][co][ci], leading dimension padded to 64) so staging is a
+//     pure 16-byte-per-lane copy into an unpadded [row][64] LDS image;
+//   * v_mfma_f32_32x32x2_f32 operands: A = Ws[row][m] (32 consecutive dwords per half-wave), B = Xs[xoff[row] +
+//     colbase(lane)] where xoff[row] = channel*XROW + tap offset comes from a small LDS table -- the tap shift is
+//     just an address offset into the halo'd row.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 48;
+constexpr int XE = 8;            // X-tile elements staged per thread and chunk: CC * XROW <= 256 * XE
+constexpr int WE = 4;            // W-tile float4 per thread and chunk: RC * 16 <= 256 * WE
+constexpr int BM2 = 64;
+
+struct DirP {
+    const float* src;     // (B, Csrc, Tsrc)
+    const float* wt;      // transposed weights: [G][K][C2_g][LD]
+    const float* scale;   // FWD: epilogue scale[co];  BWD: nullable pointer to ONE uniform factor (per-channel factors
+                          // are folded into wb by stegan_conv_prep)
+    const float* bias;    // FWD
+    const float* res;     // FWD residual / BWD add_src
+    const float* mask;    // BWD relu mask source (B, Cdst, Tmask)
+    float* out;
+    int B, Csrc, Cdst, Tsrc, Tq;        // Tq = valid source extent in q units (FWD: Tin*up, BWD: Tout)
+    int Tdst;                           // stored output length per (b, channel)  (FWD: Tout, BWD: Te)
+    int Tmask, ups;                     // BWD: mask length (Tin) and log2(upsample) for mask index; FWD: ups for src index
+    int C2_g, M_g, LD;                  // reduction channels / output channels per group, padded leading dim of wt
+    int K, stride, dil, pad, k_lo, k_hi;
+    int mode;                           // 0 FWD, 1 BWD_DATA
+    int in_relu, out_act, out_btc;
+    int m_tiles, CC, logCC;
+    int SEG, NSEG, XROW;
+    int U0;                             // columns per batch element for phase 0 (max over phases)
+    int splits, chunks_per_split;       // split-K over channel chunks: grid.z = phase*splits + split
+    float* partial;                     // splits > 1: raw accumulators [split][B*Cdst*Tdst], epilogue runs separately
+    FastDiv fdS;
+};
+
+__device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, int ch, int to) {
+    if (p.mode == 0) {
+        if (p.scale) v *= p.scale[ch];
+        if (p.bias) v += p.bias[ch];
+        const size_t idx = ((size_t)b * p.Cdst + ch) * p.Tdst + to;
+        if (p.res) v += p.res[idx];
+        if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+        else if (p.out_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
+        if (p.out_btc) p.out[((size_t)b * p.Tdst + to) * p.Cdst + ch] = v;
+        else p.out[idx] = v;
+    } else {
+        if (p.mask) {
+            const float xv = p.mask[((size_t)b * p.Cdst + ch) * p.Tmask + (to >> p.ups)];
+            if (!(xv > 0.f)) v = 0.f;
+        }
+        if (p.scale) v *= p.scale[0];
+        const size_t idx = ((size_t)b * p.Cdst + ch) * p.Tdst + to;
+        if (p.res) v += p.res[idx];
+        p.out[idx] = v;
+    }
+}
+
+// sums the split-K partials and applies the fused epilogue; one thread per output element (t fastest)
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const DirP p) {
+    const long total = (long)p.B * p.Cdst * p.Tdst;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * total + i];
+        const int to = (int)(i % p.Tdst);
+        const long r = i / p.Tdst;
+        epilogue_store(p, v, (int)(r / p.Cdst), (int)(r % p.Cdst), to);
+    }
+}
+
+template <int TN>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
+    constexpr int BN = 64 * TN;
+    extern __shared__ __align__(16) float smem[];
+    // layout: Ws[RCmax*64] | Xs[CC*XROW] | tables
+    __shared__ int s_off[MAX_TAPS];     // tap -> source offset (q units)
+    __shared__ int s_kidx[MAX_TAPS];    // tap -> k index in the weight tensor
+    __shared__ int s_xoff[2 * 64 + 2];  // chunk row -> LDS offset into Xs (channel*XROW + off - off_min)
+    __shared__ int s_meta[4];           // ntaps, off_min, off_max
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = blockIdx.y / p.m_tiles;
+    const int m0 = (blockIdx.y % p.m_tiles) * BM2;
+    const int phase = blockIdx.z / p.splits;
+    const int split = blockIdx.z - phase * p.splits;
+
+    // ---- per-phase geometry
+    int U, cs, os;
+    if (p.mode == 0) { U = p.U0; cs = p.stride; os = 1; }
+    else {
+        const int Te = p.Tdst;
+        U = (Te - phase + p.stride - 1) / p.stride;
+        cs = 1; os = p.stride;
+    }
+    const int N = p.B * U;
+    const int n0 = blockIdx.x * BN;
+    if (n0 >= N) return;
+
+    if (tid == 0) {
+        int nt = 0, omin = 1 << 30, omax = -(1 << 30);
+        for (int k = p.k_lo; k <= p.k_hi; ++k) {
+            int off;
+            if (p.mode == 0) off = k * p.dil - p.pad;
+            else {
+                const int a = phase + p.pad - k * p.dil;
+                // floor division / modulo that is correct for negative a
+                int q = a / p.stride, r = a % p.stride;
+                if (r < 0) { r += p.stride; q -= 1; }
+                if (r != 0) continue;
+                off = q;
+            }
+            s_off[nt] = off; s_kidx[nt] = k; ++nt;
+            omin = min(omin, off); omax = max(omax, off);
+        }
+        if (nt == 0) { omin = 0; omax = 0; }
+        s_meta[0] = nt; s_meta[1] = omin; s_meta[2] = omax;
+    }
+    __syncthreads();
+    const int ntaps = s_meta[0], off_min = s_meta[1];
+    const int CC = p.CC;
+    const int RC = (ntaps * CC + 1) & ~1;          // rows per chunk, even
+    float* Ws = smem;
+    float* Xs = smem + (size_t)(((MAX_TAPS < 64 ? 64 : MAX_TAPS) + 2) * 64);   // Ws region sized for 66 rows (fixed)
+    if (tid < RC) {
+        const int r = tid;
+        const int tap = r >> p.logCC, ci = r & (CC - 1);
+        s_xoff[r] = tap < ntaps ? ci * p.XROW + (s_off[tap] - off_min) : 0;
+    }
+
+    // ---- chunk-invariant part of the X staging: thread element e <-> tile index tid + 256 e = ci * XROW + slot
+    const int b_lo = n0 / U, u0 = n0 - b_lo * U;
+    int x_src[XE];      // source offset (without the chunk's channel base), -1 = zero fill
+    int x_ci[XE];       // channel within the chunk
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+        const int idx = tid + 256 * e;
+        x_src[e] = -1;
+        x_ci[e] = 1 << 20;
+        if (idx < CC * p.XROW) {
+            const int ci = idx / p.XROW, slot = idx - ci * p.XROW;
+            const int sg = slot / p.SEG, sl = slot - sg * p.SEG;
+            const int b = b_lo + sg;
+            const int q = (sg == 0 ? u0 : 0) * cs + off_min + sl;
+            x_ci[e] = ci;
+            if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
+                x_src[e] = (b * p.Csrc + ci) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q);
+        }
+    }
+    // ---- per-lane column bases for the B operand
+    int colbase[TN];
+    int col_valid = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jn = (wn * TN + j) * 32 + (lane & 31);
+        const int n = n0 + jn;
+        int cb = 0;
+        if (n < N) {
+            const int uu = u0 + jn;
+            const int sg = uu / U, u = uu - sg * U;
+            cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs;
+            col_valid |= 1 << j;
+        }
+        colbase[j] = cb;
+    }
+    (void)col_valid;
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) / CC : 0;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+    const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
+
+    // All global loads of a chunk are issued back to back into registers (one memory round trip per chunk),
+    // and the NEXT chunk's loads are in flight while the matrix cores work on the current one.
+    float4 rw[WE];
+    float rx[XE];
+    auto load_chunk = [&](int c) {
+        const int c0 = c * CC;
+#pragma unroll
+        for (int i = 0; i < WE; ++i) {
+            const int idx = tid + 256 * i;
+            const int r = idx >> 4, c4 = idx & 15;
+            const int tap = r >> p.logCC, ci = r & (CC - 1);
+            rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < RC && tap < ntaps && c0 + ci < p.C2_g)
+                rw[i] = *reinterpret_cast<const float4*>(wt_g + ((size_t)s_kidx[tap] * p.C2_g + c0 + ci) * p.LD + m0 + c4 * 4);
+        }
+        const size_t chunk_base = (size_t)(g * p.C2_g + c0) * p.Tsrc;
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            float v = 0.f;
+            if (x_src[e] >= 0 && c0 + x_ci[e] < p.C2_g) {
+                v = p.src[chunk_base + x_src[e]];
+                if (p.in_relu) v = fmaxf(v, 0.f);
+            }
+            rx[e] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < WE; ++i) {
+            const int idx = tid + 256 * i;
+            if ((idx >> 4) < RC) *reinterpret_cast<float4*>(Ws + idx * 4) = rw[i];
+        }
+#pragma unroll
+        for (int e = 0; e < XE; ++e) {
+            const int idx = tid + 256 * e;
+            if (idx < CC * p.XROW) Xs[idx] = rx[e];
+        }
+    };
+
+    if (c_begin < c_end) load_chunk(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        __syncthreads();                       // previous chunk's MFMA reads are done
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < c_end) load_chunk(c + 1);
+#pragma unroll 4
+        for (int r2 = 0; r2 < RC; r2 += 2) {
+            const int r = r2 + half;
+            const float a = Ws[r * 64 + wm * 32 + l31];
+            const int xo = s_xoff[r];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float b = Xs[xo + colbase[j]];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue
+    const size_t out_elems = (size_t)p.B * p.Cdst * p.Tdst;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jn = (wn * TN + j) * 32 + l31;
+        const int n = n0 + jn;
+        if (n >= N) continue;
+        const int b = n / U, u = n - b * U;
+        const int to = p.mode == 0 ? u : phase + u * os;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            if (m >= p.M_g) continue;
+            const int ch = g * p.M_g + m;
+            if (p.splits > 1) p.partial[(size_t)split * out_elems + ((size_t)b * p.Cdst + ch) * p.Tdst + to] = acc[j][e];
+            else epilogue_store(p, acc[j][e], b, ch, to);
+        }
+    }
+}
+
+// ---- weight transposition: v (Cout, Cin_g, K) -> Wf[g][k][ci][co_pad], Wb[g][k][co][ci_pad]
+__global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict__ v, const float* __restrict__ scale,
+                                                        float* __restrict__ wf, float* __restrict__ wb, int Cout_g,
+                                                        int Cin_g, int K, int G, int LDf, int LDb) {
+    // tile: 32 co x 32 e, e = ci*K + k   (reads coalesced along e, Wf writes coalesced along co)
+    __shared__ float t[32][33];
+    const int E = Cin_g * K;
+    const int e0 = blockIdx.x * 32, co0 = blockIdx.y * 32, g = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, e = e0 + tx;
+        t[r][tx] = (co < Cout_g && e < E) ? v[((size_t)(g * Cout_g + co)) * E + e] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        // Wf: row = e index r, column = co tx
+        const int e = e0 + r, co = co0 + tx;
+        if (e < E && co < Cout_g) {
+            const int ci = e / K, k = e - ci * K;
+            wf[(((size_t)g * K + k) * Cin_g + ci) * LDf + co] = t[tx][r];
+        }
+        // Wb: element (co = r-th row of tile, e = tx)
+        const int co2 = co0 + r, e2 = e0 + tx;
+        if (e2 < E && co2 < Cout_g) {
+            const int ci = e2 / K, k = e2 - ci * K;
+            wb[(((size_t)g * K + k) * Cout_g + co2) * LDb + ci] = t[r][tx] * (scale ? scale[g * Cout_g + co2] : 1.f);
+        }
+    }
+}
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct Geo { int CC, logCC, SEG, NSEG, XROW, BN; size_t lds; bool ok; };
+
+// geometry for one launch; ntaps_max bounds the taps of any phase
+Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks) {
+    Geo gm;
+    gm.ok = false;
+    if (ntaps_max > MAX_TAPS) return gm;
+    // BN: 128 when the grid still fills the chip, else 64
+    for (int BN : {128, 64}) {
+        const int UT = U < BN ? U : BN;
+        const int SEG = (UT - 1) * cs + span_off + 1;
+        // batch elements one tile can touch: worst case over the per-phase column counts U_min..U
+        int NSEG = 1;
+        for (int uu = (U_min < 1 ? 1 : U_min); uu <= U; ++uu) {
+            const int ns = (uu % BN == 0) ? 1 : ((BN + uu - 2) / uu + 1);
+            if (ns > NSEG) NSEG = ns;
+        }
+        const int XROW = SEG * NSEG;
+        int CC = 32;
+        while (CC > 1 && (ntaps_max * CC > 64 || CC * XROW > 256 * XE)) CC >>= 1;
+        if (CC * XROW > 256 * XE) continue;
+        const size_t lds = (size_t)66 * 64 * 4 + (size_t)CC * XROW * 4;
+        const long blocks = (N + BN - 1) / BN;
+        if (BN == 64 || blocks * other_blocks >= 768) {
+            gm.CC = CC;
+            gm.logCC = 0;
+            while ((1 << gm.logCC) < CC) ++gm.logCC;
+            gm.SEG = SEG; gm.NSEG = NSEG; gm.XROW = XROW; gm.BN = BN; gm.lds = lds; gm.ok = true;
+            return gm;
+        }
+    }
+    return gm;
+}
+
+int live_taps(const stegan_conv_desc* d, int& k_lo, int& k_hi) {
+    const int Te = d->Tin * d->upsample;
+    k_lo = d->K; k_hi = -1;
+    for (int k = 0; k < d->K; ++k) {
+        const int lo = k * d->dilation - d->pad, hi = (d->Tout - 1) * d->stride + lo;
+        if (hi >= 0 && lo < Te) { if (k < k_lo) k_lo = k; k_hi = k; }
+    }
+    return k_hi - k_lo + 1;
+}
+
+int check_desc(const stegan_conv_desc* d) {
+    STEGAN_CHECK_ARG(d != nullptr);
+    STEGAN_CHECK_ARG(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->groups > 0 && d->K > 0);
+    STEGAN_CHECK_ARG(d->Cin % d->groups == 0 && d->Cout % d->groups == 0);
+    STEGAN_CHECK_ARG(d->stride >= 1 && d->dilation >= 1 && d->pad >= 0 && d->Tin > 0);
+    STEGAN_CHECK_ARG(d->upsample == 1 || d->upsample == 2);
+    const int Te = d->Tin * d->upsample;
+    const int span = Te + 2 * d->pad - d->dilation * (d->K - 1) - 1;
+    STEGAN_CHECK_ARG(span >= 0 && d->Tout == span / d->stride + 1);
+    STEGAN_CHECK_ARG((int64_t)d->B * (d->Cin > d->Cout ? d->Cin : d->Cout) * (Te > d->Tout ? Te : d->Tout) < (1ll << 31));
+    return STEGAN_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t stegan_conv_prep_floats(const stegan_conv_desc* d, int32_t which) {
+    if (!d || d->groups <= 0) return -1;
+    const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+    if (which == 0) return (int64_t)d->groups * d->K * Cin_g * round_up(Cout_g, 64) + 64;
+    return (int64_t)d->groups * d->K * Cout_g * round_up(Cin_g, 64) + 64;
+}
+
+extern "C" int stegan_conv_prep(const stegan_conv_desc* d, const float* v, const float* scale, float* wf, float* wb,
+                                void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(v && wf && wb);
+    const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+    const int E = Cin_g * d->K;
+    // padding columns are never read into valid outputs (rows m >= M are masked), but keep them finite
+    hipStream_t s = (hipStream_t)stream;
+
+
+    hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(E, 32), ceil_div(Cout_g, 32), d->groups), dim3(256), 0, s, v, scale, wf,
+                       wb, Cout_g, Cin_g, d->K, d->groups, round_up(Cout_g, 64), round_up(Cin_g, 64));
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+// split-K factor: enough blocks to keep >= ~4 resident per CU (the loop is latency-bound at low occupancy)
+static int choose_splits(long base_blocks, int nchunks) {
+    static const char* env = getenv("STEGAN_SPLITK_TARGET");
+    const long target = env ? atol(env) : 1024;
+    if (target <= 0 || base_blocks * 2 > target || nchunks < 4) return 1;
+    long sp = (target + base_blocks - 1) / base_blocks;
+    if (sp > nchunks / 2) sp = nchunks / 2;
+    if (sp > 16) sp = 16;
+    return sp < 1 ? 1 : (int)sp;
+}
+
+// returns 1 when the v2 kernel cannot take this shape (caller falls back to the generic implicit-GEMM kernel)
+static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* workspace, int64_t workspace_floats,
+                         hipStream_t s) {
+    int k_lo, k_hi;
+    const int K_eff = live_taps(d, k_lo, k_hi);
+    if (K_eff <= 0) return STEGAN_E_ARG;
+    p.K = d->K; p.stride = d->stride; p.dil = d->dilation; p.pad = d->pad; p.k_lo = k_lo; p.k_hi = k_hi;
+    p.B = d->B; p.mode = mode;
+    p.fdS = make_fastdiv((uint32_t)d->stride);
+    const int Te = d->Tin * d->upsample;
+    int ntaps_max, span_off, cs, U, U_min, phases;
+    if (mode == 0) {
+        ntaps_max = K_eff; span_off = (k_hi - k_lo) * d->dilation; cs = d->stride; U = d->Tout; U_min = U; phases = 1;
+    } else {
+        // per phase: taps k with (phi + pad - k*dil) % s == 0; offsets (phi+pad-k*dil)/s
+        ntaps_max = 0; span_off = 0;
+        for (int phi = 0; phi < d->stride; ++phi) {
+            int nt = 0, omin = 1 << 30, omax = -(1 << 30);
+            for (int k = k_lo; k <= k_hi; ++k) {
+                const int a = phi + d->pad - k * d->dilation;
+                int q = a / d->stride, r = a % d->stride;
+                if (r < 0) { r += d->stride; q -= 1; }
+                if (r != 0) continue;
+                ++nt; omin = q < omin ? q : omin; omax = q > omax ? q : omax;
+            }
+            if (nt > ntaps_max) ntaps_max = nt;
+            if (nt > 0 && omax - omin > span_off) span_off = omax - omin;
+        }
+        if (ntaps_max == 0) ntaps_max = 1;
+        cs = 1; U = (Te + d->stride - 1) / d->stride; U_min = Te / d->stride; phases = d->stride;
+    }
+    const long N = (long)d->B * U;
+    Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases);
+    if (!gm.ok) return 1;
+    p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.U0 = U;
+    p.m_tiles = ceil_div(p.M_g, BM2);
+    const long nb = (N + gm.BN - 1) / gm.BN;
+    const int nchunks = ceil_div(p.C2_g, gm.CC);
+    int splits = choose_splits(nb * p.m_tiles * d->groups * phases, nchunks);
+    const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
+    if (splits > 1 && (!workspace || workspace_floats < out_elems * splits)) {
+        splits = workspace ? (int)(workspace_floats / out_elems) : 1;     // use what the caller provided
+        if (splits < 2) splits = 1;
+    }
+    p.splits = splits;
+    p.chunks_per_split = ceil_div(nchunks, splits);
+    p.splits = ceil_div(nchunks, p.chunks_per_split);
+    p.partial = workspace;
+    dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
+    if (gm.BN == 128) hipLaunchKernelGGL((conv_direct_kernel<2>), grid, dim3(256), gm.lds, s, p);
+    else hipLaunchKernelGGL((conv_direct_kernel<1>), grid, dim3(256), gm.lds, s, p);
+    if (p.splits > 1) {
+        long eb = (out_elems + 255) / 256;
+        if (eb > 4096) eb = 4096;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)eb), dim3(256), 0, s, p);
+    }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int64_t stegan_conv_workspace_floats(const stegan_conv_desc* d, int32_t mode) {
+    if (!d) return -1;
+    const int64_t out_elems = mode == 0 ? (int64_t)d->B * d->Cout * d->Tout : (int64_t)d->B * d->Cin * d->Tin * d->upsample;
+    return out_elems * 16;      // upper bound: at most 16 splits
+}
+
+extern "C" int stegan_conv1d_fwd_t(const stegan_conv_desc* d, const float* x, const float* wf, const float* scale,
+                                   const float* bias, const float* residual, float* y, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(x && wf && y);
+    STEGAN_CHECK_ARG(d->in_act == STEGAN_ACT_NONE || d->in_act == STEGAN_ACT_RELU);
+    STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
+    STEGAN_CHECK_ARG(!(d->out_btc && residual));
+    DirP p;
+    p.src = x; p.wt = wf; p.scale = scale; p.bias = bias; p.res = residual; p.mask = nullptr; p.out = y;
+    p.Csrc = d->Cin; p.Cdst = d->Cout; p.Tsrc = d->Tin; p.Tq = d->Tin * d->upsample; p.Tdst = d->Tout;
+    p.Tmask = 0; p.ups = d->upsample == 2 ? 1 : 0;
+    p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = round_up(p.M_g, 64);
+    p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
+    return launch_direct(d, 0, p, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* dy, const float* wb, const float* scale,
+                                        const float* mask_src, const float* add_src, float* dx, float* workspace,
+                                        int64_t workspace_floats, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(dy && wb && dx);
+    STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mask_src);
+    DirP p;
+    p.src = dy; p.wt = wb; p.scale = scale; p.bias = nullptr; p.res = add_src; p.out = dx;
+    p.mask = d->in_act == STEGAN_ACT_RELU ? mask_src : nullptr;
+    p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
+    p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
+    p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = round_up(p.M_g, 64);
+    p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
+    return launch_direct(d, 1, p, workspace, workspace_floats, (hipStream_t)stream);
+}

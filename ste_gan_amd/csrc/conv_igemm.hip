@@ -239,12 +239,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
 }
 
-// db[c] += sum_{b,t} dy[b,c,t] : one block per channel
+// db[c] += sum_{b,t} dy[b,c,t] : grid (channel, batch slice)
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
                                                         int B, int C, int T) {
     const int c = blockIdx.x;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const float* row = dy + ((size_t)b * C + c) * T;
         for (int t = threadIdx.x; t < T; t += 256) s += row[t];
     }
@@ -253,6 +253,13 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
+}
+
+inline int bias_grad_slices(int B, int C) {
+    int sl = 1024 / (C > 0 ? C : 1);
+    if (sl < 1) sl = 1;
+    if (sl > B) sl = B;
+    return sl;
 }
 
 int fill_common(const stegan_conv_desc* d, ConvK& p) {
@@ -363,7 +370,8 @@ extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* 
     rc = launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
     if (rc) return rc;
     if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout), dim3(256), 0, (hipStream_t)stream, dy, db, d->B, d->Cout, d->Tout);
+        hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, bias_grad_slices(d->B, d->Cout)), dim3(256), 0,
+                           (hipStream_t)stream, dy, db, d->B, d->Cout, d->Tout);
         STEGAN_LAUNCH_CHECK();
     }
     return STEGAN_OK;
@@ -387,7 +395,7 @@ extern "C" int stegan_conv1d_plan(const stegan_conv_desc* d, int32_t mode, int32
 
 extern "C" int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream) {
     STEGAN_CHECK_ARG(dy && db && B > 0 && C > 0 && T > 0);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C, bias_grad_slices(B, C)), dim3(256), 0, (hipStream_t)stream, dy, db, B, C, T);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

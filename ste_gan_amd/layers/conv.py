@@ -46,9 +46,24 @@ class WNConv1d(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, *([1] * kernel_dims)))
         self.weight_v = nn.Parameter(v)
+        self._prep = None
+
+    def prepared(self):
+        """(scale, wf, wb) for the current weights: the weight-norm factor g/||v|| and the K-major transposed copies
+        the direct-conv kernel reads.  Recomputed (3 small launches) only when the weights changed: torch-side writes
+        bump ``_version``; the fused AdamW kernel writes through raw pointers and bumps ``ops.WEIGHT_EPOCH`` instead."""
+        v, g = self.weight_v, self.weight_g
+        stamp = (ops.WEIGHT_EPOCH, v._version, g._version, v.data_ptr(), g.data_ptr())
+        if self._prep is None or self._prep[0] != stamp:
+            w3 = v.detach().reshape(v.shape[0], v.shape[1], -1)
+            scale = ops.wn_scale(v.detach(), g.detach())
+            bufs = ops.prep_weights(w3, self.cfg, self._prep[1][1:] if self._prep is not None and
+                                    self._prep[1][1].device == v.device else None, scale)
+            self._prep = (stamp, (scale, bufs[0], bufs[1]))
+        return self._prep[1]
 
     def forward(self, x, residual=None):
-        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg)
+        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared())
 
     def extra_repr(self):
         return str(self.cfg)
@@ -120,9 +135,19 @@ class SNConv1d(nn.Module):
         self.weight_orig = nn.Parameter(w)
         self.register_buffer("weight_u", nn.functional.normalize(torch.randn(out_channels), dim=0, eps=1e-12))
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=1e-12))
+        self._prep = None
+
+    def prepared(self):
+        w = self.weight_orig
+        stamp = (ops.WEIGHT_EPOCH, w._version, w.data_ptr())
+        if self._prep is None or self._prep[0] != stamp:
+            self._prep = (stamp, ops.prep_weights(w.detach(), self.cfg, self._prep[1] if self._prep is not None and
+                                                  self._prep[1][0].device == w.device else None))
+        return self._prep[1]
 
     def forward(self, x):
-        return ops.sn_conv1d(x, self.weight_orig, self.weight_u, self.weight_v, self.bias, self.cfg, self.training)
+        return ops.sn_conv1d(x, self.weight_orig, self.weight_u, self.weight_v, self.bias, self.cfg, self.training,
+                             self.prepared())
 
 
 def NormedConv1d(*args, **kwargs):

@@ -95,23 +95,65 @@ class ConvProfiler:
 PROFILER: Optional[ConvProfiler] = None
 
 
-def _timed(d: ConvDesc, mode: int, fn):
+def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     if PROFILER is None:
         return fn()
     name, nominal, live = PROFILER.plan(d, mode)
+    if kind == "direct":
+        name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = fn()
     e1.record()
-    PROFILER.records.append((name, nominal, live, e0, e1))
+    if rc != 1:
+        PROFILER.records.append((name, nominal, live, e0, e1))
     return rc
 
 
 # ---------------------------------------------------------------------------------------------
 # raw launches
 # ---------------------------------------------------------------------------------------------
+_SPLITK_MAX = 16
+_WORKSPACES = {}
+
+
+def _workspace(device, floats: int) -> Tensor:
+    """Split-K scratch shared by all conv launches of a (device, stream): launches are stream ordered, and the
+    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them."""
+    floats = min(floats, 1 << 27)                      # cap at 512 MiB; the kernel lowers the split to fit
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
+
+
+def bump_weight_epoch() -> None:
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+
+
+def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = None):
+    """K-major transposed copies (wf for the forward, wb for the input gradient) of a (Cout, Cin/g, K) tensor.
+    A per-output-channel ``scale`` (weight-norm / BatchNorm factor) is folded into wb."""
+    w3 = _gpu_f32(w3, "weight")
+    d = _desc(cfg, 1, cfg.k * cfg.dilation + 1, 1)          # only channel / K / groups fields matter here
+    d.Tin = max(1, cfg.dilation * (cfg.k - 1) + 1 - 2 * cfg.pad)
+    d.Tout = (d.Tin * cfg.upsample + 2 * cfg.pad - cfg.dilation * (cfg.k - 1) - 1) // cfg.stride + 1
+    L = _lib.lib()
+    if bufs is None:
+        bufs = (torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 0)), device=w3.device, dtype=torch.float32),
+                torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 1)), device=w3.device, dtype=torch.float32))
+    check(L.stegan_conv_prep(C.byref(d), _p(w3), _p(scale), _p(bufs[0]), _p(bufs[1]), _stream()), "stegan_conv_prep")
+    return bufs
+
+
 def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Tensor],
-               residual: Optional[Tensor], cfg: ConvCfg) -> Tensor:
+               residual: Optional[Tensor], cfg: ConvCfg, wf: Optional[Tensor] = None) -> Tensor:
     x = _gpu_f32(x, "x")
     w = _gpu_f32(w, "weight")
     if x.dim() != 3 or x.shape[1] != cfg.cin:
@@ -125,17 +167,37 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
         if residual.shape != y.shape:
             raise RuntimeError(f"residual shape {list(residual.shape)} does not match conv output {list(y.shape)}")
     d = _desc(cfg, B, tin, tout)
+    if wf is not None:
+        ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
+        rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_t(C.byref(d), _p(x), _p(wf), _p(scale), _p(bias),
+                                                                 _p(residual), _p(y), _p(ws), ws.numel(), _stream()),
+                    "direct")
+        if rc != 1:
+            check(rc, "stegan_conv1d_fwd_t")
+            return y
     check(_timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd(C.byref(d), _p(x), _p(w), _p(scale), _p(bias), _p(residual),
                                                             _p(y), _stream())), "stegan_conv1d_fwd")
     return y
 
 
 def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Optional[Tensor],
-                    add_src: Optional[Tensor], cfg: ConvCfg, tin: int) -> Tensor:
+                    add_src: Optional[Tensor], cfg: ConvCfg, tin: int, wb: Optional[Tensor] = None,
+                    uniform_scale: bool = False) -> Tensor:
+    """``wb`` (from prep_weights WITH the per-channel scale folded in) selects the direct kernel; ``uniform_scale``
+    says that ``scale`` holds one value repeated (spectral norm) and was NOT folded into wb."""
     dy = _gpu_f32(dy, "dy")
     B, _, tout = dy.shape
     dx = torch.empty((B, cfg.cin, tin * cfg.upsample), device=dy.device, dtype=torch.float32)
     d = _desc(cfg, B, tin, tout)
+    if wb is not None:
+        ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
+        us = scale if uniform_scale else None
+        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_t(C.byref(d), _p(dy), _p(wb), _p(us), _p(mask_src),
+                                                                      _p(add_src), _p(dx), _p(ws), ws.numel(), _stream()),
+                    "direct")
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_data_t")
+            return dx
     check(_timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data(C.byref(d), _p(dy), _p(w), _p(scale), _p(mask_src),
                                                                  _p(add_src), _p(dx), _stream())),
           "stegan_conv1d_bwd_data")
@@ -177,13 +239,17 @@ class _WNConvFn(torch.autograd.Function):
     """y = out_act( (g/||v||)[co] * (v (*) in_act(up(x))) + bias + residual ) with hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg):
-        scale = wn_scale(v, g)
+    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None):
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
-        y = conv1d_fwd(x, w3, scale, bias, residual, cfg)
+        if prepared is None:
+            scale, wf, wb = wn_scale(v, g), None, None
+        else:
+            scale, wf, wb = prepared
+        y = conv1d_fwd(x, w3, scale, bias, residual, cfg, wf)
         ctx.cfg = cfg
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
+        ctx.wb = wb
         ctx.save_for_backward(x, v, g, scale, y if cfg.out_act != ACT_NONE else None)
         return y
 
@@ -201,7 +267,7 @@ class _WNConvFn(torch.autograd.Function):
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         dx = dv = dg = db = dres = None
         if ctx.needs_input_grad[0]:
-            dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, None, cfg, x.shape[2])
+            dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, None, cfg, x.shape[2], ctx.wb)
             dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.zeros_like(w3)
@@ -216,11 +282,12 @@ class _WNConvFn(torch.autograd.Function):
             dg = dg.view_as(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dv, dg, db, dres, None
+        return dx, dv, dg, db, dres, None, None
 
 
-def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg) -> Tensor:
-    return _WNConvFn.apply(x, v, g, bias, residual, cfg)
+def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None) -> Tensor:
+    """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None."""
+    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared)
 
 
 def act_bwd(dy: Tensor, y: Tensor, act: int) -> Tensor:
@@ -237,7 +304,8 @@ class _SNConvFn(torch.autograd.Function):
     """y = out_act( (w_orig (*) x) / sigma + bias ), sigma = u^T W v after one in-place power iteration."""
 
     @staticmethod
-    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool):
+    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None):
+        wf, wb = prepared if prepared is not None else (None, None)
         rows = w_orig.shape[0]
         cols = w_orig.numel() // rows
         L = _lib.lib()
@@ -246,8 +314,9 @@ class _SNConvFn(torch.autograd.Function):
         sigma = torch.empty(1, device=x.device, dtype=torch.float32)
         check(L.stegan_spectral_norm_fwd(_p(w_orig), _p(u), _p(v), _p(scale), _p(sigma), _p(ws), rows, cols,
                                          int(training), _stream()), "stegan_spectral_norm_fwd")
-        y = conv1d_fwd(x, w_orig, scale, bias, None, cfg)
+        y = conv1d_fwd(x, w_orig, scale, bias, None, cfg, wf)
         ctx.cfg = cfg
+        ctx.wb = wb
         # u / v are cloned because the next forward power-iterates them in place (torch clones them too)
         ctx.save_for_backward(x, w_orig, u.clone(), v.clone(), scale, sigma, y if cfg.out_act != ACT_NONE else None)
         return y
@@ -261,7 +330,7 @@ class _SNConvFn(torch.autograd.Function):
             dy = act_bwd(dy, y, cfg.out_act)
         dx = dw_orig = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2])
+            dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
             dw = torch.zeros_like(w_orig)
             db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32)
@@ -272,11 +341,11 @@ class _SNConvFn(torch.autograd.Function):
             check(_lib.lib().stegan_spectral_norm_bwd(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
                                                       rows, w_orig.numel() // rows, _stream()),
                   "stegan_spectral_norm_bwd")
-        return dx, dw_orig, None, None, db, None, None
+        return dx, dw_orig, None, None, db, None, None, None
 
 
-def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool) -> Tensor:
-    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training)
+def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None) -> Tensor:
+    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -523,9 +592,11 @@ class _FrozenConvFn(torch.autograd.Function):
     """y = out_act(scale * (w (*) x) + bias + residual) with constant w / scale / bias: backward yields dx (+ dres)."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, bias, residual, cfg: ConvCfg):
-        y = conv1d_fwd(x, w, scale, bias, residual, cfg)
+    def forward(ctx, x, w, scale, bias, residual, cfg: ConvCfg, prepared=None):
+        wf, wb = prepared if prepared is not None else (None, None)
+        y = conv1d_fwd(x, w, scale, bias, residual, cfg, wf)
         ctx.cfg = cfg
+        ctx.wb = wb
         ctx.has_res = residual is not None
         ctx.tin = x.shape[2]
         ctx.save_for_backward(w, scale, y if cfg.out_act != ACT_NONE else None)
@@ -542,13 +613,27 @@ class _FrozenConvFn(torch.autograd.Function):
                 y = y.transpose(1, 2).contiguous()
         if cfg.out_act != ACT_NONE:
             dy = act_bwd(dy, y, cfg.out_act)
-        dx = conv1d_bwd_data(dy, w, scale, None, None, cfg, ctx.tin) if ctx.needs_input_grad[0] else None
+        dx = conv1d_bwd_data(dy, w, scale, None, None, cfg, ctx.tin, ctx.wb) if ctx.needs_input_grad[0] else None
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
-        return dx, None, None, None, dres, None
+        return dx, None, None, None, dres, None, None
+
+
+_FROZEN_PREP = {}
+
+
+def frozen_prepared(w: Tensor, scale: Optional[Tensor], cfg: ConvCfg):
+    """Transposed copies of a FROZEN weight (its constant per-channel scale folded into wb), cached by identity."""
+    key = (w.data_ptr(), tuple(w.shape), cfg.groups, scale.data_ptr() if scale is not None else 0)
+    ent = _FROZEN_PREP.get(key)
+    stamp = (w._version, scale._version if scale is not None else 0)
+    if ent is None or ent[0] != stamp:
+        ent = (stamp, prep_weights(w.detach(), cfg, ent[1] if ent is not None else None, scale))
+        _FROZEN_PREP[key] = ent
+    return ent[1]
 
 
 def frozen_conv1d(x, w, scale, bias, residual, cfg: ConvCfg) -> Tensor:
-    return _FrozenConvFn.apply(x, w, scale, bias, residual, cfg)
+    return _FrozenConvFn.apply(x, w, scale, bias, residual, cfg, frozen_prepared(w, scale, cfg))
 
 
 class _RelPosAttnFn(torch.autograd.Function):

@@ -94,6 +94,8 @@ class FusedAdamW:
             C.c_void_p(self.exp_avg_sq.data_ptr()), f.numel, C.c_void_p(self._hyper.data_ptr()),
             self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step")
+        from . import ops
+        ops.bump_weight_epoch()        # parameters changed behind torch's back: transposed weight copies are stale
 
     def step(self, grad_scale: float = 1.0):
         self.flat.gather_grads()

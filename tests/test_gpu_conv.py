@@ -28,6 +28,14 @@ CASES = [
     (1, 64, 64, 1, 2, 1, 0, 1, 1, False, 33),        # encoder residual 1x1 stride 2, odd T
     (1, 5, 7, 3, 1, 2, 2, 1, 1, False, 1),           # T=1, ragged channel counts
     (5, 70, 130, 3, 1, 1, 1, 1, 1, False, 50),       # ragged M/N/R tails
+    (64, 48, 48, 3, 1, 1, 1, 1, 1, True, 192),       # N = 12288: BN=128 tiles of the direct kernel
+    (64, 48, 24, 3, 1, 1, 1, 1, 2, True, 96),        # upsample with BN=128
+    (3, 16, 16, 3, 2, 1, 1, 1, 1, False, 7),         # stride 2, odd lengths: uneven bwd phases
+    (2, 8, 8, 1, 2, 1, 0, 1, 1, False, 9),           # k1 stride 2: one bwd phase has no taps (must write zeros)
+    (2, 64, 64, 41, 1, 1, 20, 16, 1, False, 24),     # full-D k41 grouped stride 1
+    (22, 256, 512, 3, 3, 1, 2, 1, 1, False, 11),     # MPD p=11 tail: bwd phases with 4,4,3 columns per row
+    (22, 512, 1, 3, 1, 1, 1, 1, 1, False, 4),        # MPD output conv at H=4
+    (4, 32, 32, 5, 4, 1, 2, 1, 1, False, 10),        # stride 4: phases with 3,3,2,2 columns
 ]
 
 
@@ -65,6 +73,14 @@ def test_conv_fwd_bwd(cfg):
     dxe = ops.conv1d_bwd_data(dyg, wg, sg, xg if relu else None, None, c, Tin)
     dx = ops.fold_upsample2(dxe) if up == 2 else dxe
     torch.testing.assert_close(dx.cpu(), dx_ref, rtol=2e-5, atol=2e-5 * float(dx_ref.abs().max()))
+    # fast path: direct-conv kernel on the K-major transposed weight copies (strided bwd runs as dense phases)
+    wf, wb = ops.prep_weights(wg, c, None, sg)
+    y2 = ops.conv1d_fwd(xg, wg, sg, bg, rg, c, wf)
+    torch.testing.assert_close(y2.cpu(), y_ref.detach(), **tol)
+    add = torch.randn(B, Cin, Tin * up, generator=gen)
+    dxe2 = ops.conv1d_bwd_data(dyg, wg, sg, xg if relu else None, add.cuda(), c, Tin, wb)
+    dxe_ref = (dxe + add.cuda()).cpu()
+    torch.testing.assert_close(dxe2.cpu(), dxe_ref, rtol=2e-5, atol=2e-5 * float(dxe_ref.abs().max()))
     # bwd-weight (+ bias grad), accumulate semantics: start from a non-zero buffer
     dw = torch.full_like(wg, 0.25)
     db = torch.full((Cout,), -1.0, device=dev)

@@ -91,15 +91,39 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const DirP p)
     }
 }
 
-template <int TN>
+// Per-phase tap progression.  The live taps of a launch (FWD) or of one output phase (BWD) form an arithmetic
+// progression: tap j uses weight index k = kbase + j*kstep and reads the source at offset off_min + j*step, so no
+// lookup tables are needed in the inner loop.
+struct Taps { int ntaps, kbase, kstep, off_min, step; };
+
+__device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
+    Taps t;
+    if (p.mode == 0) {
+        t.ntaps = p.k_hi - p.k_lo + 1; t.kbase = p.k_lo; t.kstep = 1;
+        t.off_min = p.k_lo * p.dil - p.pad; t.step = p.dil;
+        return t;
+    }
+    // BWD: taps k (descending) with (phase + pad - k*dil) % stride == 0; offsets (phase+pad-k*dil)/stride ascend
+    int gg = p.dil % p.stride, hh = p.stride;            // gcd(dil, stride)
+    while (gg) { const int tt = hh % gg; hh = gg; gg = tt; }
+    const int dk = p.stride / hh;
+    t.ntaps = 0; t.kbase = 0; t.kstep = -dk; t.off_min = 0; t.step = p.dil / hh;
+    for (int k = p.k_hi; k > p.k_hi - dk && k >= p.k_lo; --k) {
+        const int a = phase + p.pad - k * p.dil;
+        int q = a / p.stride, r = a - q * p.stride;
+        if (r < 0) { r += p.stride; q -= 1; }
+        if (r == 0) {
+            t.kbase = k; t.off_min = q; t.ntaps = (k - p.k_lo) / dk + 1;
+            break;
+        }
+    }
+    return t;
+}
+
+template <int TN, bool FAST>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BN = 64 * TN;
-    extern __shared__ __align__(16) float smem[];
-    // layout: Ws[RCmax*64] | Xs[CC*XROW] | tables
-    __shared__ int s_off[MAX_TAPS];     // tap -> source offset (q units)
-    __shared__ int s_kidx[MAX_TAPS];    // tap -> k index in the weight tensor
-    __shared__ int s_xoff[2 * 64 + 2];  // chunk row -> LDS offset into Xs (channel*XROW + off - off_min)
-    __shared__ int s_meta[4];           // ntaps, off_min, off_max
+    extern __shared__ __align__(16) float smem[];      // Ws[66*64] | Xs[CC*XROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -108,85 +132,67 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int phase = blockIdx.z / p.splits;
     const int split = blockIdx.z - phase * p.splits;
 
-    // ---- per-phase geometry
+    // ---- per-phase geometry (wave-uniform scalar work)
     int U, cs, os;
     if (p.mode == 0) { U = p.U0; cs = p.stride; os = 1; }
-    else {
-        const int Te = p.Tdst;
-        U = (Te - phase + p.stride - 1) / p.stride;
-        cs = 1; os = p.stride;
-    }
+    else { U = (p.Tdst - phase + p.stride - 1) / p.stride; cs = 1; os = p.stride; }
     const int N = p.B * U;
     const int n0 = blockIdx.x * BN;
     if (n0 >= N) return;
-
-    if (tid == 0) {
-        int nt = 0, omin = 1 << 30, omax = -(1 << 30);
-        for (int k = p.k_lo; k <= p.k_hi; ++k) {
-            int off;
-            if (p.mode == 0) off = k * p.dil - p.pad;
-            else {
-                const int a = phase + p.pad - k * p.dil;
-                // floor division / modulo that is correct for negative a
-                int q = a / p.stride, r = a % p.stride;
-                if (r < 0) { r += p.stride; q -= 1; }
-                if (r != 0) continue;
-                off = q;
-            }
-            s_off[nt] = off; s_kidx[nt] = k; ++nt;
-            omin = min(omin, off); omax = max(omax, off);
-        }
-        if (nt == 0) { omin = 0; omax = 0; }
-        s_meta[0] = nt; s_meta[1] = omin; s_meta[2] = omax;
-    }
-    __syncthreads();
-    const int ntaps = s_meta[0], off_min = s_meta[1];
+    const Taps tp = phase_taps(p, phase);
+    const int ntaps = tp.ntaps, off_min = tp.off_min;
     const int CC = p.CC;
-    const int RC = (ntaps * CC + 1) & ~1;          // rows per chunk, even
-    float* Ws = smem;
-    float* Xs = smem + (size_t)(((MAX_TAPS < 64 ? 64 : MAX_TAPS) + 2) * 64);   // Ws region sized for 66 rows (fixed)
-    if (tid < RC) {
-        const int r = tid;
-        const int tap = r >> p.logCC, ci = r & (CC - 1);
-        s_xoff[r] = tap < ntaps ? ci * p.XROW + (s_off[tap] - off_min) : 0;
-    }
+    const int RCV = ntaps * CC;                     // valid rows per chunk
+    const int RC = (RCV + 7) & ~7;                  // padded to the MFMA loop's unroll (zero weight rows)
 
     // ---- chunk-invariant part of the X staging: thread element e <-> tile index tid + 256 e = ci * XROW + slot
     const int b_lo = n0 / U, u0 = n0 - b_lo * U;
-    int x_src[XE];      // source offset (without the chunk's channel base), -1 = zero fill
-    int x_ci[XE];       // channel within the chunk
+    int x_src[XE];      // source offset (without the chunk's channel base); 0 with x_ci = big when zero-filled
+    int x_ci[XE];       // channel within the chunk (1<<20 = never valid)
 #pragma unroll
     for (int e = 0; e < XE; ++e) {
         const int idx = tid + 256 * e;
-        x_src[e] = -1;
+        x_src[e] = 0;
         x_ci[e] = 1 << 20;
         if (idx < CC * p.XROW) {
             const int ci = idx / p.XROW, slot = idx - ci * p.XROW;
             const int sg = slot / p.SEG, sl = slot - sg * p.SEG;
             const int b = b_lo + sg;
             const int q = (sg == 0 ? u0 : 0) * cs + off_min + sl;
-            x_ci[e] = ci;
-            if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
+            if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq) {
+                x_ci[e] = ci;
                 x_src[e] = (b * p.Csrc + ci) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q);
+            }
+        }
+    }
+    // ---- W staging: thread element i <-> float4 index tid + 256 i = row * 16 + c4
+    int w_off[WE];      // offset of the float4 inside the group's transposed weights, without the chunk term
+    int w_ci[WE];
+#pragma unroll
+    for (int i = 0; i < WE; ++i) {
+        const int idx = tid + 256 * i;
+        const int r = idx >> 4, c4 = idx & 15;
+        const int tap = r >> p.logCC, ci = r & (CC - 1);
+        w_ci[i] = 1 << 20;
+        w_off[i] = 0;
+        if (r < RCV) {
+            w_ci[i] = ci;
+            w_off[i] = ((tp.kbase + tap * tp.kstep) * p.C2_g + ci) * p.LD + m0 + c4 * 4;
         }
     }
     // ---- per-lane column bases for the B operand
     int colbase[TN];
-    int col_valid = 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int jn = (wn * TN + j) * 32 + (lane & 31);
-        const int n = n0 + jn;
         int cb = 0;
-        if (n < N) {
+        if (n0 + jn < N) {
             const int uu = u0 + jn;
             const int sg = uu / U, u = uu - sg * U;
             cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs;
-            col_valid |= 1 << j;
         }
         colbase[j] = cb;
     }
-    (void)col_valid;
 
     f32x16 acc[TN];
 #pragma unroll
@@ -200,81 +206,205 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int c_end = min(nchunks, c_begin + p.chunks_per_split);
     const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
 
-    // All global loads of a chunk are issued back to back into registers (one memory round trip per chunk),
+    // All global loads of a chunk are issued back to back, UNCONDITIONALLY (invalid elements read a safe address and
+    // are zeroed by a select afterwards: a branch around a load would make the compiler wait for every load in turn),
     // and the NEXT chunk's loads are in flight while the matrix cores work on the current one.
-    float4 rw[WE];
+    float rw[WE][4];
     float rx[XE];
-    auto load_chunk = [&](int c) {
-        const int c0 = c * CC;
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int idx = tid + 256 * i;
-            const int r = idx >> 4, c4 = idx & 15;
-            const int tap = r >> p.logCC, ci = r & (CC - 1);
-            rw[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < RC && tap < ntaps && c0 + ci < p.C2_g)
-                rw[i] = *reinterpret_cast<const float4*>(wt_g + ((size_t)s_kidx[tap] * p.C2_g + c0 + ci) * p.LD + m0 + c4 * 4);
-        }
-        const size_t chunk_base = (size_t)(g * p.C2_g + c0) * p.Tsrc;
-#pragma unroll
-        for (int e = 0; e < XE; ++e) {
-            float v = 0.f;
-            if (x_src[e] >= 0 && c0 + x_ci[e] < p.C2_g) {
-                v = p.src[chunk_base + x_src[e]];
-                if (p.in_relu) v = fmaxf(v, 0.f);
-            }
-            rx[e] = v;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < WE; ++i) {
-            const int idx = tid + 256 * i;
-            if ((idx >> 4) < RC) *reinterpret_cast<float4*>(Ws + idx * 4) = rw[i];
-        }
-#pragma unroll
-        for (int e = 0; e < XE; ++e) {
-            const int idx = tid + 256 * e;
-            if (idx < CC * p.XROW) Xs[idx] = rx[e];
-        }
-    };
+#define STEGAN_LOAD_CHUNK(c_)                                                                                  \
+    {                                                                                                          \
+        const int c0_ = (c_) * CC;                                                                             \
+        const int lim_ = p.C2_g - c0_; /* channels of this chunk that exist; others read offset 0 (in bounds) */ \
+        const float* wc_ = wt_g + (size_t)c0_ * p.LD;                                                          \
+        _Pragma("unroll") for (int i = 0; i < WE; ++i) {                                                       \
+            const float4 t4 = *reinterpret_cast<const float4*>(wc_ + (w_ci[i] < lim_ ? w_off[i] : 0));        \
+            rw[i][0] = t4.x; rw[i][1] = t4.y; rw[i][2] = t4.z; rw[i][3] = t4.w;                                \
+        }                                                                                                      \
+        const float* xc_ = p.src + (size_t)(g * p.C2_g + c0_) * p.Tsrc;                                        \
+        _Pragma("unroll") for (int e = 0; e < XE; ++e) rx[e] = xc_[x_ci[e] < lim_ ? x_src[e] : 0];            \
+    }
+#define STEGAN_STORE_CHUNK(c_)                                                                                 \
+    {                                                                                                          \
+        const int lim_ = p.C2_g - (c_) * CC;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < WE; ++i) {                                                       \
+            const int idx = tid + 256 * i;                                                                     \
+            const bool ok = w_ci[i] < lim_;                                                                    \
+            float4 t4;                                                                                         \
+            t4.x = ok ? rw[i][0] : 0.f; t4.y = ok ? rw[i][1] : 0.f;                                            \
+            t4.z = ok ? rw[i][2] : 0.f; t4.w = ok ? rw[i][3] : 0.f;                                            \
+            if ((idx >> 4) < RC) *reinterpret_cast<float4*>(Ws + idx * 4) = t4;                                \
+        }                                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < XE; ++e) {                                                       \
+            const int idx = tid + 256 * e;                                                                     \
+            float v = (x_ci[e] < lim_) ? rx[e] : 0.f;                                                          \
+            if (p.in_relu) v = fmaxf(v, 0.f);                                                                  \
+            if (idx < CC * p.XROW) Xs[idx] = v;                                                                \
+        }                                                                                                      \
+    }
 
-    if (c_begin < c_end) load_chunk(c_begin);
+#define STEGAN_LOAD_BODY(a_, b_, r2_)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                            \
+        const int r = (r2_) + 2 * k + half;                                                                    \
+        a_[k] = Wcur[r * 64 + wm * 32 + l31];                                                                  \
+        const int tap = r >> p.logCC, ci = r & (CC - 1);                                                       \
+        const int xo = r < RCV ? ci * p.XROW + tap * tp.step : 0;                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = Xcur[xo + colbase[j]];                       \
+    }
+#define STEGAN_MFMA_BODY(a_, b_)                                                                               \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k], b_[k][j], acc[j], 0, 0, 0);
+
+    // Two LDS buffers, ONE barrier per chunk: chunk c+1 is written into the other buffer (from registers whose loads
+    // were issued a whole MFMA phase earlier) and chunk c+2's global loads are issued, then the matrix cores run
+    // over chunk c with the LDS reads of the next 4-MFMA body always in flight behind the current body's MFMAs.
+    const int buf_floats = 66 * 64 + CC * p.XROW;
+    if (c_begin < c_end) {
+        STEGAN_LOAD_CHUNK(c_begin)
+        { float* Ws = smem; float* Xs = smem + 66 * 64; STEGAN_STORE_CHUNK(c_begin) }
+        if (c_begin + 1 < c_end) STEGAN_LOAD_CHUNK(c_begin + 1)
+    }
     for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();                       // previous chunk's MFMA reads are done
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < c_end) load_chunk(c + 1);
-#pragma unroll 4
-        for (int r2 = 0; r2 < RC; r2 += 2) {
-            const int r = r2 + half;
-            const float a = Ws[r * 64 + wm * 32 + l31];
-            const int xo = s_xoff[r];
+        const int cur = (c - c_begin) & 1;
+        __syncthreads();                       // buffer `cur` is complete; nobody still reads buffer `cur ^ 1`
+        if (c + 1 < c_end) {
+            float* Ws = smem + (cur ^ 1) * buf_floats;
+            float* Xs = Ws + 66 * 64;
+            STEGAN_STORE_CHUNK(c + 1)
+            if (c + 2 < c_end) STEGAN_LOAD_CHUNK(c + 2)
+        }
+        const float* Wcur = smem + cur * buf_floats;
+        const float* Xcur = Wcur + 66 * 64;
+        if constexpr (FAST) {
+            // Fast path (host guarantees CC >= 8) (K_eff*CC is a multiple of 8, a body of 8 rows never straddles a tap): the B address is
+            // colb2 + scalar, the A address abase + immediate.  Loads of the NEXT body are interleaved one row pair at
+            // a time with the MFMAs of the current body, so LDS latency and address math hide under the matrix pipe.
+            const float* abase = Wcur + half * 64 + wm * 32 + l31;
+            int colb2[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float b = Xs[xo + colbase[j]];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) colb2[j] = colbase[j] + half * p.XROW;
+            float a0[4], b0[4][TN], a1[4], b1[4][TN];
+#define STEGAN_FAST_LOAD(a_, b_, r2_, k_)                                                                      \
+            {                                                                                                  \
+                const int xb_ = ((r2_) & (CC - 1)) * p.XROW + ((r2_) >> p.logCC) * tp.step + 2 * (k_) * p.XROW; \
+                a_[k_] = abase[((r2_) + 2 * (k_)) * 64];                                                       \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = Xcur[xb_ + colb2[j]];               \
+            }
+#define STEGAN_FAST_MFMA(a_, b_, k_)                                                                           \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k_], b_[k_][j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) STEGAN_FAST_LOAD(a0, b0, 0, k)
+            for (int r2 = 0; r2 < RC; r2 += 16) {
+                const bool has1 = r2 + 8 < RC, has2 = r2 + 16 < RC;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (has1) STEGAN_FAST_LOAD(a1, b1, r2 + 8, k)
+                    STEGAN_FAST_MFMA(a0, b0, k)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (has1) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (has2) STEGAN_FAST_LOAD(a0, b0, r2 + 16, k)
+                        STEGAN_FAST_MFMA(a1, b1, k)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#undef STEGAN_FAST_LOAD
+#undef STEGAN_FAST_MFMA
+        } else {
+            float a0[4], b0[4][TN], a1[4], b1[4][TN];
+            STEGAN_LOAD_BODY(a0, b0, 0)
+            for (int r2 = 0; r2 < RC; r2 += 16) {
+                if (r2 + 8 < RC) STEGAN_LOAD_BODY(a1, b1, r2 + 8)
+                STEGAN_MFMA_BODY(a0, b0)
+                if (r2 + 8 < RC) {
+                    if (r2 + 16 < RC) STEGAN_LOAD_BODY(a0, b0, r2 + 16)
+                    STEGAN_MFMA_BODY(a1, b1)
+                }
             }
         }
     }
 
-    // ---- epilogue
+#undef STEGAN_LOAD_BODY
+#undef STEGAN_MFMA_BODY
+#undef STEGAN_LOAD_CHUNK
+#undef STEGAN_STORE_CHUNK
+
+    // ---- epilogue.  Every global read (scale / bias / residual / mask) is issued unconditionally on a clamped
+    // index and in batches of 16 before it is used, so the loads overlap instead of serialising on per-element
+    // branches; only the stores are predicated.
     const size_t out_elems = (size_t)p.B * p.Cdst * p.Tdst;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int jn = (wn * TN + j) * 32 + l31;
-        const int n = n0 + jn;
-        if (n >= N) continue;
+        const bool n_ok = n0 + jn < N;
+        const int n = n_ok ? n0 + jn : N - 1;
         const int b = n / U, u = n - b * U;
         const int to = p.mode == 0 ? u : phase + u * os;
+        const int mrow0 = m0 + wm * 32 + 4 * half;
+        if (p.splits > 1) {
+            float* dst = p.partial + (size_t)split * out_elems;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            if (m >= p.M_g) continue;
-            const int ch = g * p.M_g + m;
-            if (p.splits > 1) p.partial[(size_t)split * out_elems + ((size_t)b * p.Cdst + ch) * p.Tdst + to] = acc[j][e];
-            else epilogue_store(p, acc[j][e], b, ch, to);
+            for (int e = 0; e < 16; ++e) {
+                const int m = mrow0 + (e & 3) + 8 * (e >> 2);
+                if (n_ok && m < p.M_g) dst[((size_t)b * p.Cdst + g * p.M_g + m) * p.Tdst + to] = acc[j][e];
+            }
+            continue;
         }
+#pragma unroll
+      for (int e0 = 0; e0 < 16; e0 += 8) {
+        float sc[8], bi[8], rs[8];
+        int chn[8], oidx[8];                         // element counts are checked < 2^31 on the host
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int m = mrow0 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+            chn[e] = g * p.M_g + (m < p.M_g ? m : p.M_g - 1);
+            oidx[e] = (b * p.Cdst + chn[e]) * p.Tdst + to;
+            sc[e] = 1.f; bi[e] = 0.f; rs[e] = 0.f;
+        }
+        if (p.mode == 0) {
+            if (p.scale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc[e] = p.scale[chn[e]];
+            }
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bi[e] = p.bias[chn[e]];
+            }
+        } else {
+            if (p.scale) {
+                const float us = p.scale[0];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc[e] = us;
+            }
+            if (p.mask) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xv = p.mask[(b * p.Cdst + chn[e]) * p.Tmask + (to >> p.ups)];
+                    if (!(xv > 0.f)) sc[e] = 0.f;
+                }
+            }
+        }
+        if (p.res) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rs[e] = p.res[oidx[e]];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int m = mrow0 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
+            float v = acc[j][e0 + e] * sc[e] + bi[e] + rs[e];
+            if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
+            else if (p.out_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
+            if (n_ok && m < p.M_g) {
+                if (p.out_btc) p.out[((size_t)b * p.Tdst + to) * p.Cdst + g * p.M_g + m] = v;
+                else p.out[oidx[e]] = v;
+            }
+        }
+      }
     }
 }
 
@@ -331,9 +461,11 @@ Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long
         int CC = 32;
         while (CC > 1 && (ntaps_max * CC > 64 || CC * XROW > 256 * XE)) CC >>= 1;
         if (CC * XROW > 256 * XE) continue;
-        const size_t lds = (size_t)66 * 64 * 4 + (size_t)CC * XROW * 4;
+        const size_t lds = 2 * ((size_t)66 * 64 * 4 + (size_t)CC * XROW * 4);
         const long blocks = (N + BN - 1) / BN;
-        if (BN == 64 || blocks * other_blocks >= 768) {
+        static const char* env128 = getenv("STEGAN_BN128_MIN_BLOCKS");
+        const long min128 = env128 ? atol(env128) : 768;
+        if (BN == 64 || blocks * other_blocks >= min128) {
             gm.CC = CC;
             gm.logCC = 0;
             while ((1 << gm.logCC) < CC) ++gm.logCC;
@@ -453,8 +585,14 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     p.splits = ceil_div(nchunks, p.chunks_per_split);
     p.partial = workspace;
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
-    if (gm.BN == 128) hipLaunchKernelGGL((conv_direct_kernel<2>), grid, dim3(256), gm.lds, s, p);
-    else hipLaunchKernelGGL((conv_direct_kernel<1>), grid, dim3(256), gm.lds, s, p);
+    const bool fast = gm.CC >= 8;
+    if (gm.BN == 128) {
+        if (fast) hipLaunchKernelGGL((conv_direct_kernel<2, true>), grid, dim3(256), gm.lds, s, p);
+        else hipLaunchKernelGGL((conv_direct_kernel<2, false>), grid, dim3(256), gm.lds, s, p);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_direct_kernel<1, true>), grid, dim3(256), gm.lds, s, p);
+        else hipLaunchKernelGGL((conv_direct_kernel<1, false>), grid, dim3(256), gm.lds, s, p);
+    }
     if (p.splits > 1) {
         long eb = (out_elems + 255) / 256;
         if (eb > 4096) eb = 4096;

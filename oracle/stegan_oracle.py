@@ -414,7 +414,7 @@ class LossWeights:          # configs/ste_gan_base_gantts.yaml:17-41
 def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_d: AdamWState,
                batch: Dict[str, Tensor], small_d: bool = True,
                speech_feature_type: str = "SPEECH_UNITS", weights: LossWeights = LossWeights(),
-               lr: float = 2e-4, keep_grads: bool = False) -> Dict[str, object]:
+               lr: float = 2e-4, keep_grads: bool = False, grad_sync=None) -> Dict[str, object]:
     """One iteration of the hot loop, in place on g_sd / d_sd / optimiser state.
 
     Follows ste_gan/train.py:165-268 exactly, including the ordering facts of SURVEY.md 3.3:
@@ -422,6 +422,8 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
     D; the spectral-norm power iteration runs on each of the 4 D forwards; D grads produced by
     loss_G.backward() are discarded.  ``batch`` keys: su (B,T,256) [SU targets], feats
     (generator input; == su for Soft-SU), x_real (B,16T,8), sess (B,), phonemes (B,T).
+    ``grad_sync(dict of grads) -> dict`` (optional) stands in for the data-parallel gradient average between
+    backward and optimiser step (the reference itself is single-process).
     """
     out: Dict[str, object] = {}
     g_params = {k: v.detach().requires_grad_(True) for k, v in g_sd.items()}
@@ -447,6 +449,8 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
         for k in sn:
             d_sd[k] = sn[k].detach().clone()
     trainable = {k: d_sd[k] for k in d_keys}
+    if grad_sync is not None:
+        d_grads = grad_sync(d_grads)
     adamw_step(trainable, d_grads, opt_d, lr=lr)
     out["loss_d"] = float(loss_d)
 
@@ -475,6 +479,8 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
     out["loss_fm"], out["loss_g"] = float(fm), float(loss_g)
     g_keys = list(g_params)
     g_grads = dict(zip(g_keys, torch.autograd.grad(loss_g, [g_params[k] for k in g_keys])))
+    if grad_sync is not None:
+        g_grads = grad_sync(g_grads)
     adamw_step(g_sd, g_grads, opt_g, lr=lr)
     if keep_grads:
         out["g_grads"], out["d_grads"] = g_grads, d_grads

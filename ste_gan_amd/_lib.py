@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstegan_hip.so")
+LIB_PATH = os.environ.get("STEGAN_HIP_LIB", os.path.join(_HERE, "libstegan_hip.so"))   # override: diagnostic builds only
 ABI_VERSION = 1
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3

@@ -45,6 +45,7 @@ struct DirP {
     int Tdst;                           // stored output length per (b, channel)  (FWD: Tout, BWD: Te)
     int Tmask, ups;                     // BWD: mask length (Tin) and log2(upsample) for mask index; FWD: ups for src index
     int C2_g, M_g, LD;                  // reduction channels / output channels per group, padded leading dim of wt
+    long zero_off;                      // float offset (from wt) of >= 64 zero floats behind the transposed weights
     int K, stride, dil, pad, k_lo, k_hi;
     int mode;                           // 0 FWD, 1 BWD_DATA
     int in_relu, out_act, out_btc;
@@ -53,7 +54,9 @@ struct DirP {
     int U0;                             // columns per batch element for phase 0 (max over phases)
     int splits, chunks_per_split;       // split-K over channel chunks: grid.z = phase*splits + split
     float* partial;                     // splits > 1: raw accumulators [split][B*Cdst*Tdst], epilogue runs separately
+    unsigned long long* stamps;         // diagnostic builds only (STEGAN_STAMPS): 8 s_memtime stamps per block
     FastDiv fdS;
+    FastDiv fdXROW, fdSEG, fdU0, fdU1;  // magic division by XROW, SEG, U0 and U0-1 (the two per-phase column counts)
 };
 
 __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, int ch, int to) {
@@ -126,6 +129,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     extern __shared__ __align__(16) float smem[];      // Ws[66*64] | Xs[CC*XROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef STEGAN_STAMPS
+#define STAMP(i_) if (p.stamps && tid == 0) p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i_)
+#endif
+    STAMP(0)
     const int wm = wave >> 1, wn = wave & 1;
     const int g = blockIdx.y / p.m_tiles;
     const int m0 = (blockIdx.y % p.m_tiles) * BM2;
@@ -139,6 +148,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int N = p.B * U;
     const int n0 = blockIdx.x * BN;
     if (n0 >= N) return;
+    const FastDiv fdU = (U == p.U0) ? p.fdU0 : p.fdU1;
     const Taps tp = phase_taps(p, phase);
     const int ntaps = tp.ntaps, off_min = tp.off_min;
     const int CC = p.CC;
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int RC = (RCV + 7) & ~7;                  // padded to the MFMA loop's unroll (zero weight rows)
 
     // ---- chunk-invariant part of the X staging: thread element e <-> tile index tid + 256 e = ci * XROW + slot
-    const int b_lo = n0 / U, u0 = n0 - b_lo * U;
+    const int b_lo = (int)fd_div((uint32_t)n0, fdU), u0 = n0 - b_lo * U;
     int x_src[XE];      // source offset (without the chunk's channel base); 0 with x_ci = big when zero-filled
     int x_ci[XE];       // channel within the chunk (1<<20 = never valid)
 #pragma unroll
@@ -155,8 +165,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         x_src[e] = 0;
         x_ci[e] = 1 << 20;
         if (idx < CC * p.XROW) {
-            const int ci = idx / p.XROW, slot = idx - ci * p.XROW;
-            const int sg = slot / p.SEG, sl = slot - sg * p.SEG;
+            const int ci = (int)fd_div((uint32_t)idx, p.fdXROW), slot = idx - ci * p.XROW;
+            const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
             const int b = b_lo + sg;
             const int q = (sg == 0 ? u0 : 0) * cs + off_min + sl;
             if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq) {
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         int cb = 0;
         if (n0 + jn < N) {
             const int uu = u0 + jn;
-            const int sg = uu / U, u = uu - sg * U;
+            const int sg = (int)fd_div((uint32_t)uu, fdU), u = uu - sg * U;
             cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs;
         }
         colbase[j] = cb;
@@ -206,41 +216,37 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int c_end = min(nchunks, c_begin + p.chunks_per_split);
     const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
 
-    // All global loads of a chunk are issued back to back, UNCONDITIONALLY (invalid elements read a safe address and
-    // are zeroed by a select afterwards: a branch around a load would make the compiler wait for every load in turn),
-    // and the NEXT chunk's loads are in flight while the matrix cores work on the current one.
-    float rw[WE][4];
-    float rx[XE];
-#define STEGAN_LOAD_CHUNK(c_)                                                                                  \
+    // Staging is LDS-DMA (global_load_lds): every lane hands the DMA engine its own global address and the data lands
+    // at wave-uniform LDS base + lane * size -- no staging registers, no ds_write, no selects.  Elements that must be
+    // zero (halo, out-of-range rows, channels past C2_g) read a zero word / a zero row kept behind the transposed
+    // weights (stegan_conv_prep leaves >= 64 zero floats of slack), so the copy stays branch-free.
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    const float* zero_row = p.wt + p.zero_off;
+#define STEGAN_DMA_CHUNK(c_, buf_)                                                                             \
     {                                                                                                          \
         const int c0_ = (c_) * CC;                                                                             \
-        const int lim_ = p.C2_g - c0_; /* channels of this chunk that exist; others read offset 0 (in bounds) */ \
+        const int lim_ = p.C2_g - c0_;                                                                         \
+        float* Wd_ = smem + (buf_) * buf_floats;                                                               \
+        float* Xd_ = Wd_ + 66 * 64;                                                                            \
         const float* wc_ = wt_g + (size_t)c0_ * p.LD;                                                          \
         _Pragma("unroll") for (int i = 0; i < WE; ++i) {                                                       \
-            const float4 t4 = *reinterpret_cast<const float4*>(wc_ + (w_ci[i] < lim_ ? w_off[i] : 0));        \
-            rw[i][0] = t4.x; rw[i][1] = t4.y; rw[i][2] = t4.z; rw[i][3] = t4.w;                                \
+            const int idx = tid + 256 * i;                                                                     \
+            if ((idx >> 4) < RC) {                                                                             \
+                const float* src_ = (w_ci[i] < lim_) ? wc_ + w_off[i] : zero_row + (idx & 15) * 4;             \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (wave * 64 + 256 * i) * 4), 16, 0, 0); \
+            }                                                                                                  \
         }                                                                                                      \
         const float* xc_ = p.src + (size_t)(g * p.C2_g + c0_) * p.Tsrc;                                        \
-        _Pragma("unroll") for (int e = 0; e < XE; ++e) rx[e] = xc_[x_ci[e] < lim_ ? x_src[e] : 0];            \
-    }
-#define STEGAN_STORE_CHUNK(c_)                                                                                 \
-    {                                                                                                          \
-        const int lim_ = p.C2_g - (c_) * CC;                                                                   \
-        _Pragma("unroll") for (int i = 0; i < WE; ++i) {                                                       \
-            const int idx = tid + 256 * i;                                                                     \
-            const bool ok = w_ci[i] < lim_;                                                                    \
-            float4 t4;                                                                                         \
-            t4.x = ok ? rw[i][0] : 0.f; t4.y = ok ? rw[i][1] : 0.f;                                            \
-            t4.z = ok ? rw[i][2] : 0.f; t4.w = ok ? rw[i][3] : 0.f;                                            \
-            if ((idx >> 4) < RC) *reinterpret_cast<float4*>(Ws + idx * 4) = t4;                                \
-        }                                                                                                      \
         _Pragma("unroll") for (int e = 0; e < XE; ++e) {                                                       \
             const int idx = tid + 256 * e;                                                                     \
-            float v = (x_ci[e] < lim_) ? rx[e] : 0.f;                                                          \
-            if (p.in_relu) v = fmaxf(v, 0.f);                                                                  \
-            if (idx < CC * p.XROW) Xs[idx] = v;                                                                \
+            if (idx < CC * p.XROW) {                                                                           \
+                const float* src_ = (x_ci[e] < lim_) ? xc_ + x_src[e] : zero_row;                              \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + wave * 64 + 256 * e), 4, 0, 0); \
+            }                                                                                                  \
         }                                                                                                      \
     }
+    const float relu_floor = p.in_relu ? 0.f : -INFINITY;     // B operand = max(x, floor): the input ReLU costs one v_max
 
 #define STEGAN_LOAD_BODY(a_, b_, r2_)                                                                          \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                            \
@@ -248,31 +254,27 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         a_[k] = Wcur[r * 64 + wm * 32 + l31];                                                                  \
         const int tap = r >> p.logCC, ci = r & (CC - 1);                                                       \
         const int xo = r < RCV ? ci * p.XROW + tap * tp.step : 0;                                              \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = Xcur[xo + colbase[j]];                       \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = fmaxf(Xcur[xo + colbase[j]], relu_floor);    \
     }
 #define STEGAN_MFMA_BODY(a_, b_)                                                                               \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                              \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k], b_[k][j], acc[j], 0, 0, 0);
 
-    // Two LDS buffers, ONE barrier per chunk: chunk c+1 is written into the other buffer (from registers whose loads
-    // were issued a whole MFMA phase earlier) and chunk c+2's global loads are issued, then the matrix cores run
-    // over chunk c with the LDS reads of the next 4-MFMA body always in flight behind the current body's MFMAs.
+    // Two LDS buffers, ONE barrier per chunk: the DMA of chunk c+1 is issued right behind the barrier and stays in
+    // flight while the matrix cores run over chunk c (LDS reads of the next 4-MFMA body interleaved with the MFMAs).
     const int buf_floats = 66 * 64 + CC * p.XROW;
-    if (c_begin < c_end) {
-        STEGAN_LOAD_CHUNK(c_begin)
-        { float* Ws = smem; float* Xs = smem + 66 * 64; STEGAN_STORE_CHUNK(c_begin) }
-        if (c_begin + 1 < c_end) STEGAN_LOAD_CHUNK(c_begin + 1)
-    }
+    STAMP(1)
+    if (c_begin < c_end) STEGAN_DMA_CHUNK(c_begin, 0)
+    STAMP(2)
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
-        __syncthreads();                       // buffer `cur` is complete; nobody still reads buffer `cur ^ 1`
-        if (c + 1 < c_end) {
-            float* Ws = smem + (cur ^ 1) * buf_floats;
-            float* Xs = Ws + 66 * 64;
-            STEGAN_STORE_CHUNK(c + 1)
-            if (c + 2 < c_end) STEGAN_LOAD_CHUNK(c + 2)
-        }
+        if (c == c_begin + 3) { STAMP(3) }
+        __syncthreads();        // hipcc drains vmcnt(0) here: this wave's DMA of chunk c has landed, and after the
+                                // barrier so has everyone's; nobody still reads buffer cur ^ 1
+        if (c == c_begin + 3) { STAMP(4) }
+        if (c + 1 < c_end) STEGAN_DMA_CHUNK(c + 1, cur ^ 1)
+        if (c == c_begin + 3) { STAMP(6) }
         const float* Wcur = smem + cur * buf_floats;
         const float* Xcur = Wcur + 66 * 64;
         if constexpr (FAST) {
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             {                                                                                                  \
                 const int xb_ = ((r2_) & (CC - 1)) * p.XROW + ((r2_) >> p.logCC) * tp.step + 2 * (k_) * p.XROW; \
                 a_[k_] = abase[((r2_) + 2 * (k_)) * 64];                                                       \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = Xcur[xb_ + colb2[j]];               \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = fmaxf(Xcur[xb_ + colb2[j]], relu_floor); \
             }
 #define STEGAN_FAST_MFMA(a_, b_, k_)                                                                           \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
@@ -326,12 +328,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
                 }
             }
         }
+        if (c == c_begin + 3) { STAMP(7) }
     }
 
 #undef STEGAN_LOAD_BODY
 #undef STEGAN_MFMA_BODY
-#undef STEGAN_LOAD_CHUNK
-#undef STEGAN_STORE_CHUNK
+#undef STEGAN_DMA_CHUNK
 
     // ---- epilogue.  Every global read (scale / bias / residual / mask) is issued unconditionally on a clamped
     // index and in batches of 16 before it is used, so the loads overlap instead of serialising on per-element
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         const int jn = (wn * TN + j) * 32 + l31;
         const bool n_ok = n0 + jn < N;
         const int n = n_ok ? n0 + jn : N - 1;
-        const int b = n / U, u = n - b * U;
+        const int b = (int)fd_div((uint32_t)n, fdU), u = n - b * U;
         const int to = p.mode == 0 ? u : phase + u * os;
         const int mrow0 = m0 + wm * 32 + 4 * half;
         if (p.splits > 1) {
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         }
       }
     }
+#undef STAMP
 }
 
 // ---- weight transposition: v (Cout, Cin_g, K) -> Wf[g][k][ci][co_pad], Wb[g][k][co][ci_pad]
@@ -571,6 +574,8 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases);
     if (!gm.ok) return 1;
     p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.U0 = U;
+    p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
+    p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
     p.m_tiles = ceil_div(p.M_g, BM2);
     const long nb = (N + gm.BN - 1) / gm.BN;
     const int nchunks = ceil_div(p.C2_g, gm.CC);
@@ -584,6 +589,10 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     p.chunks_per_split = ceil_div(nchunks, splits);
     p.splits = ceil_div(nchunks, p.chunks_per_split);
     p.partial = workspace;
+    {
+        static const char* se = getenv("STEGAN_STAMP_PTR");     // diagnostic builds: device buffer address (decimal)
+        p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr;
+    }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
     const bool fast = gm.CC >= 8;
     if (gm.BN == 128) {
@@ -622,6 +631,7 @@ extern "C" int stegan_conv1d_fwd_t(const stegan_conv_desc* d, const float* x, co
     p.Csrc = d->Cin; p.Cdst = d->Cout; p.Tsrc = d->Tin; p.Tq = d->Tin * d->upsample; p.Tdst = d->Tout;
     p.Tmask = 0; p.ups = d->upsample == 2 ? 1 : 0;
     p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = round_up(p.M_g, 64);
+    p.zero_off = (long)d->groups * d->K * p.C2_g * p.LD;
     p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
     return launch_direct(d, 0, p, workspace, workspace_floats, (hipStream_t)stream);
 }
@@ -639,6 +649,7 @@ extern "C" int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* 
     p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
     p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
     p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = round_up(p.M_g, 64);
+    p.zero_off = (long)d->groups * d->K * p.C2_g * p.LD;
     p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
     return launch_direct(d, 1, p, workspace, workspace_floats, (hipStream_t)stream);
 }

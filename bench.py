@@ -62,8 +62,9 @@ def build_step(cfg, device):
     netG = init_emg_generator(cfg).to(device)
     netD = init_emg_discriminators(cfg).to(device)
     enc = init_emg_encoder(cfg, device).eval()
-    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8),
-                        FusedAdamW(FlatParams(netG)), FusedAdamW(FlatParams(netD)))
+    from ste_gan_amd.train import make_optimizers
+    optG, optD = make_optimizers(netG, netD)
+    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
     return step
 
 

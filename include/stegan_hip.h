@@ -109,6 +109,13 @@ int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const fl
 int64_t stegan_conv_prep_floats(const stegan_conv_desc* d, int32_t which);
 int stegan_conv_prep(const stegan_conv_desc* d, const float* v, const float* scale, float* wf, float* wb, void* stream);
 /*
+ * Multi-tensor stegan_conv_prep: one launch for all n convs of a network.  table_dev = device array of n
+ *   struct { const float* v; const float* scale; float* wf; float* wb;
+ *            int32 Cout_g, Cin_g, K, G, LDf, LDb, tiles_e, tiles_co; }      (LD* = round_up(.,64), tiles_* = ceil(./32))
+ * max_tiles = max over entries of G * tiles_e * tiles_co.
+ */
+int stegan_conv_prep_multi(int32_t n, const void* table_dev, int32_t max_tiles, void* stream);
+/*
  * When a launch would leave most CUs idle (small B*T), the reduction over channels is split over up to 16 blocks
  * per output tile; the raw partial sums go to `workspace` (caller-owned, stegan_conv_workspace_floats(d, mode)
  * floats is always enough; a smaller or NULL workspace just lowers / disables the split) and a second kernel sums

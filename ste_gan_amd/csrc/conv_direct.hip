@@ -441,6 +441,44 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict_
     }
 }
 
+// multi-tensor form: one launch transposes every conv of a network (grid.y = conv, grid.x = tile of the largest conv)
+struct PrepEntry {
+    const float* v;
+    const float* scale;
+    float* wf;
+    float* wb;
+    int Cout_g, Cin_g, K, G, LDf, LDb, tiles_e, tiles_co;
+};
+
+__global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepEntry* __restrict__ table) {
+    const PrepEntry t0 = table[blockIdx.y];
+    const int per_group = t0.tiles_e * t0.tiles_co;
+    if ((int)blockIdx.x >= per_group * t0.G) return;
+    __shared__ float t[32][33];
+    const int g = blockIdx.x / per_group, rem = blockIdx.x - g * per_group;
+    const int e0 = (rem % t0.tiles_e) * 32, co0 = (rem / t0.tiles_e) * 32;
+    const int E = t0.Cin_g * t0.K;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, e = e0 + tx;
+        t[r][tx] = (co < t0.Cout_g && e < E) ? t0.v[((size_t)(g * t0.Cout_g + co)) * E + e] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int e = e0 + r, co = co0 + tx;
+        if (e < E && co < t0.Cout_g) {
+            const int ci = e / t0.K, k = e - ci * t0.K;
+            t0.wf[(((size_t)g * t0.K + k) * t0.Cin_g + ci) * t0.LDf + co] = t[tx][r];
+        }
+        const int co2 = co0 + r, e2 = e0 + tx;
+        if (e2 < E && co2 < t0.Cout_g) {
+            const int ci = e2 / t0.K, k = e2 - ci * t0.K;
+            t0.wb[(((size_t)g * t0.K + k) * t0.Cout_g + co2) * t0.LDb + ci] =
+                t[r][tx] * (t0.scale ? t0.scale[g * t0.Cout_g + co2] : 1.f);
+        }
+    }
+}
+
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 struct Geo { int CC, logCC, SEG, NSEG, XROW, BN; size_t lds; bool ok; };
@@ -524,6 +562,14 @@ extern "C" int stegan_conv_prep(const stegan_conv_desc* d, const float* v, const
 
     hipLaunchKernelGGL(conv_prep_kernel, dim3(ceil_div(E, 32), ceil_div(Cout_g, 32), d->groups), dim3(256), 0, s, v, scale, wf,
                        wb, Cout_g, Cin_g, d->K, d->groups, round_up(Cout_g, 64), round_up(Cin_g, 64));
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv_prep_multi(int32_t n, const void* table_dev, int32_t max_tiles, void* stream) {
+    STEGAN_CHECK_ARG(n > 0 && table_dev && max_tiles > 0);
+    hipLaunchKernelGGL(conv_prep_multi_kernel, dim3(max_tiles, n), dim3(256), 0, (hipStream_t)stream,
+                       (const PrepEntry*)table_dev);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

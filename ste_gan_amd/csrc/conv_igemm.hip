@@ -34,6 +34,7 @@ struct ConvK {
     const float* res;    // residual / add_src or null
     const float* mask;   // BWD_DATA: pre-activation input (B,Cin,Tin) or null
     float* out;          // FWD: y, BWD_DATA: dx (B,Cin,Te), BWD_WEIGHT: dw (atomic accumulate)
+    float* db;           // BWD_WEIGHT: bias gradient (atomic accumulate) or null -- row sums of the dy tile
     int B, Cin, Cout, K, stride, dil, pad, Tin, Tout, Te, ups;  // ups = log2(upsample)
     int in_act, out_act, out_btc;
     int Cin_g, Cout_g;
@@ -174,10 +175,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         }
     };
 
+    float bsum = 0.f;                     // BWD_WEIGHT, first N tile only: sum over (b,t) of dy[co = m0 + tid]
+    const bool do_bias = MODE == MODE_BWD_WEIGHT && p.db != nullptr && blockIdx.x == 0 && tid < BM;
     load_chunk(chunk_lo * KC);
     for (int c = chunk_lo; c < chunk_hi; ++c) {
         store_chunk();
         __syncthreads();
+        if (do_bias) {
+#pragma unroll 8
+            for (int r = 0; r < KC; ++r) bsum += As[r * LDA + tid];
+        }
         if (c + 1 < chunk_hi) load_chunk((c + 1) * KC);   // global loads in flight under the MFMAs
         const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll 4
@@ -196,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         __syncthreads();
     }
 
+    if (do_bias && m0 + tid < p.M) atomicAdd(&p.db[g * p.Cout_g + m0 + tid], bsum);
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -291,6 +299,7 @@ int fill_common(const stegan_conv_desc* d, ConvK& p) {
     p.r_chunks_per_split = 1 << 30;
     p.x = p.w = p.dy = p.scale = p.bias = p.res = p.mask = nullptr;
     p.out = nullptr;
+    p.db = nullptr;
     return STEGAN_OK;
 }
 
@@ -363,18 +372,11 @@ extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* 
     int rc = fill_common(d, p);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
-    p.x = x; p.dy = dy; p.out = dw;
+    p.x = x; p.dy = dy; p.out = dw; p.db = db;
     p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout;
     p.fdT = make_fastdiv((uint32_t)d->Tout);
     const int splits = bwd_weight_splits(p, d->groups);
-    rc = launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
-    if (rc) return rc;
-    if (db) {
-        hipLaunchKernelGGL(bias_grad_kernel, dim3(d->Cout, bias_grad_slices(d->B, d->Cout)), dim3(256), 0,
-                           (hipStream_t)stream, dy, db, d->B, d->Cout, d->Tout);
-        STEGAN_LAUNCH_CHECK();
-    }
-    return STEGAN_OK;
+    return launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
 }
 
 extern "C" int stegan_conv1d_plan(const stegan_conv_desc* d, int32_t mode, int32_t* tile, int32_t* splits,

@@ -47,11 +47,16 @@ class WNConv1d(nn.Module):
         self.weight_g = nn.Parameter(v.flatten(1).norm(dim=1).view(-1, 1, *([1] * kernel_dims)))
         self.weight_v = nn.Parameter(v)
         self._prep = None
+        self._pack = None           # set by optim.ConvPack: (pack, scale, wf, wb, dw_slice)
 
     def prepared(self):
         """(scale, wf, wb) for the current weights: the weight-norm factor g/||v|| and the K-major transposed copies
         the direct-conv kernel reads.  Recomputed (3 small launches) only when the weights changed: torch-side writes
         bump ``_version``; the fused AdamW kernel writes through raw pointers and bumps ``ops.WEIGHT_EPOCH`` instead."""
+        if self._pack is not None:
+            pack, scale, wf, wb, _ = self._pack
+            pack.prepare()
+            return scale, wf, wb
         v, g = self.weight_v, self.weight_g
         stamp = (ops.WEIGHT_EPOCH, v._version, g._version, v.data_ptr(), g.data_ptr())
         if self._prep is None or self._prep[0] != stamp:
@@ -63,7 +68,10 @@ class WNConv1d(nn.Module):
         return self._prep[1]
 
     def forward(self, x, residual=None):
-        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared())
+        sink = None
+        if self._pack is not None and torch.is_grad_enabled() and self.weight_v.requires_grad:
+            sink = (self._pack[4], self.bias.grad)          # raw dw slice, bias-gradient view
+        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared(), sink)
 
     def extra_repr(self):
         return str(self.cfg)

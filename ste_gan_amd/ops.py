@@ -208,12 +208,8 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     """Accumulates into dw (and db)."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
-    # the bias-gradient kernel is launched without db here so the timed region holds the GEMM kernel alone
-    check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw),
-                                                                   None if PROFILER is not None else _p(db), _stream())),
+    check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream())),
           "stegan_conv1d_bwd_weight")
-    if PROFILER is not None and db is not None:
-        check(_lib.lib().stegan_bias_grad(_p(dy), _p(db), B, cfg.cout, dy.shape[2], _stream()), "stegan_bias_grad")
 
 
 def wn_scale(v: Tensor, g: Tensor) -> Tensor:
@@ -239,7 +235,8 @@ class _WNConvFn(torch.autograd.Function):
     """y = out_act( (g/||v||)[co] * (v (*) in_act(up(x))) + bias + residual ) with hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None):
+    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None):
+        ctx.sink = sink
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         if prepared is None:
             scale, wf, wb = wn_scale(v, g), None, None
@@ -269,7 +266,10 @@ class _WNConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, None, cfg, x.shape[2], ctx.wb)
             dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+        if ctx.sink is not None and ctx.needs_input_grad[1]:
+            # fused mode: accumulate the raw gradients into the network's arenas; (dv, dg) follow in ConvPack.finalize_grads
+            conv1d_bwd_weight(x, dy, cfg, ctx.sink[0], ctx.sink[1] if ctx.has_bias else None)
+        elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.zeros_like(w3)
             db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             conv1d_bwd_weight(x, dy, cfg, dw, db)
@@ -282,12 +282,13 @@ class _WNConvFn(torch.autograd.Function):
             dg = dg.view_as(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = dy
-        return dx, dv, dg, db, dres, None, None
+        return dx, dv, dg, db, dres, None, None, None
 
 
-def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None) -> Tensor:
-    """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None."""
-    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared)
+def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None) -> Tensor:
+    """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None;
+    sink = (raw dw arena slice, bias-gradient view) switches the backward to fused accumulation (optim.ConvPack)."""
+    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink)
 
 
 def act_bwd(dy: Tensor, y: Tensor, act: int) -> Tensor:

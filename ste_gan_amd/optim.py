@@ -61,11 +61,116 @@ class FlatParams:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
 
 
+class ConvPack:
+    """Network-wide (multi-tensor) handling of the weight-normalised convolutions of one module tree.
+
+    * ``prepare()``: ONE launch computes every weight-norm factor g/||v||, one more writes every K-major transposed
+      weight copy (instead of three small launches per conv and weight version);
+    * gradient sink: during backward each conv accumulates its raw weight gradient into a slice of one zeroed arena
+      and its bias gradient straight into ``bias.grad`` (a view of the FlatParams gradient arena); ``finalize_grads()``
+      then converts all raw gradients to (dv, dg) in one launch, writing into the ``.grad`` views.  Valid because dv, dg
+      are linear in the raw gradient for fixed (v, g), so contributions of several forward passes (D sees two per
+      step) can be summed first.  Spectral-norm convs keep their per-call path (their factor changes every forward).
+    """
+
+    def __init__(self, module: nn.Module, flat: "FlatParams"):
+        from . import ops
+        from .layers.conv import WNConv1d
+        self.convs = [m for m in module.modules() if isinstance(m, WNConv1d)]
+        if not self.convs:
+            raise ValueError("no weight-normalised convolutions in this module")
+        dev = flat.flat.device
+        L = _lib.lib()
+        self.flat = flat
+        sizes = [c.weight_v.numel() for c in self.convs]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + (n + _ALIGN - 1) // _ALIGN * _ALIGN)
+        self.dw = torch.zeros(offs[-1], device=dev, dtype=torch.float32)
+        rows = [c.cfg.cout for c in self.convs]
+        self.scale = torch.empty(sum(rows), device=dev, dtype=torch.float32)
+        so = [0]
+        for r in rows:
+            so.append(so[-1] + r)
+        self.max_rows = max(rows)
+        n = len(self.convs)
+        self.n = n
+
+        def ptrs(vals):
+            return torch.tensor(vals, dtype=torch.int64).to(dev)
+
+        v_p, g_p, s_p, dw_p, dv_p, dg_p, cols = [], [], [], [], [], [], []
+        prep_rows, self.max_tiles = [], 1
+        self._keep = []
+        for i, c in enumerate(self.convs):
+            v, g = c.weight_v, c.weight_g
+            if v.grad is None or g.grad is None or c.bias.grad is None:
+                raise RuntimeError("ConvPack needs FlatParams gradient views on every parameter")
+            d = ops._desc(c.cfg, 1, 1, 1)
+            wf = torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 0)), device=dev, dtype=torch.float32)
+            wb = torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 1)), device=dev, dtype=torch.float32)
+            sc = self.scale[so[i]:so[i + 1]]
+            dwi = self.dw[offs[i]:offs[i] + sizes[i]]
+            c._pack = (self, sc, wf, wb, dwi)
+            self._keep.append((wf, wb))
+            v_p.append(v.data_ptr()); g_p.append(g.data_ptr()); s_p.append(sc.data_ptr()); dw_p.append(dwi.data_ptr())
+            dv_p.append(v.grad.data_ptr()); dg_p.append(g.grad.data_ptr()); cols.append(v.numel() // v.shape[0])
+            G = c.cfg.groups
+            cog, cig, K = c.cfg.cout // G, c.cfg.cin // G, c.cfg.k
+            te, tc = (cig * K + 31) // 32, (cog + 31) // 32
+            self.max_tiles = max(self.max_tiles, G * te * tc)
+            ldf, ldb = (cog + 63) // 64 * 64, (cig + 63) // 64 * 64
+            prep_rows.append((v.data_ptr(), sc.data_ptr(), wf.data_ptr(), wb.data_ptr(), cog, cig, K, G, ldf, ldb, te, tc))
+        self.t_v, self.t_g, self.t_s, self.t_dw, self.t_dv, self.t_dg = map(ptrs, (v_p, g_p, s_p, dw_p, dv_p, dg_p))
+        self.t_rows = torch.tensor(rows, dtype=torch.int32).to(dev)
+        self.t_cols = torch.tensor(cols, dtype=torch.int32).to(dev)
+        import struct
+        raw = b"".join(struct.pack("<4q8i", *r) for r in prep_rows)
+        self.t_prep = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._ptr_key = tuple(v_p + g_p + dv_p + dg_p)
+        self.version = 0                 # bumped whenever this network's weights change (optimizer step, load_state_dict)
+        self.prepared_version = None
+        module.register_load_state_dict_post_hook(lambda mod, keys: self.invalidate())
+
+    def invalidate(self):
+        self.version += 1
+
+    def _check(self):
+        key = tuple([c.weight_v.data_ptr() for c in self.convs] + [c.weight_g.data_ptr() for c in self.convs] +
+                    [c.weight_v.grad.data_ptr() for c in self.convs] + [c.weight_g.grad.data_ptr() for c in self.convs])
+        if key != self._ptr_key:
+            raise RuntimeError("parameter storage moved after ConvPack was built (rebuild FlatParams / FusedAdamW)")
+
+    def prepare(self):
+        """Scales + transposed copies for the CURRENT weights (2 launches for the whole network)."""
+        if self.prepared_version == self.version:
+            return
+        self._check()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        L = _lib.lib()
+        check(L.stegan_wn_scales(self.n, P(self.t_v), P(self.t_g), P(self.t_s), P(self.t_rows), P(self.t_cols),
+                                 self.max_rows, s), "stegan_wn_scales")
+        check(L.stegan_conv_prep_multi(self.n, P(self.t_prep), self.max_tiles, s), "stegan_conv_prep_multi")
+        self.prepared_version = self.version
+
+    def zero(self):
+        self.dw.zero_()
+
+    def finalize_grads(self):
+        """raw dw -> (dv, dg) for every conv, written into the .grad views (1 launch)."""
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: C.c_void_p(t.data_ptr())
+        check(_lib.lib().stegan_wn_backward(self.n, P(self.t_v), P(self.t_g), P(self.t_dw), P(self.t_dv), P(self.t_dg),
+                                            P(self.t_rows), P(self.t_cols), self.max_rows, s), "stegan_wn_backward")
+
+
 class FusedAdamW:
     """AdamW(lr=2e-4, betas=(.8,.99), eps=1e-8, weight_decay=1e-2) over a FlatParams arena."""
 
-    def __init__(self, flat: FlatParams, lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, flat: FlatParams, lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=1e-2, pack: "ConvPack" = None):
         self.flat = flat
+        self.pack = pack            # optional multi-tensor conv handling (see ConvPack)
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.initial_lr = lr
         self.exp_avg = torch.zeros_like(flat.flat)
@@ -77,6 +182,13 @@ class FusedAdamW:
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
+        if self.pack is not None:
+            self.pack.zero()
+
+    def finalize_grads(self):
+        """Call between backward() and step() / the gradient all-reduce when a ConvPack is attached."""
+        if self.pack is not None:
+            self.pack.finalize_grads()
 
     def stage_hyper(self):
         """Advance the step counter and upload {lr, 1-b1^t, 1-b2^t} (async H2D from pinned memory)."""
@@ -96,8 +208,12 @@ class FusedAdamW:
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step")
         from . import ops
         ops.bump_weight_epoch()        # parameters changed behind torch's back: transposed weight copies are stale
+        if self.pack is not None:
+            self.pack.invalidate()
 
-    def step(self, grad_scale: float = 1.0):
+    def step(self, grad_scale: float = 1.0, finalized: bool = False):
+        if not finalized:
+            self.finalize_grads()
         self.flat.gather_grads()
         self.stage_hyper()
         self.launch(grad_scale)

@@ -97,6 +97,7 @@ class GANTrainStep:
             D_real = netD(x_t)
             loss_D = lsgan_loss(D_fake_det, 0.0) + lsgan_loss(D_real, 1.0)
             loss_D.backward()
+            self.optD.finalize_grads()
             out["discriminator"] = loss_D.detach()
             if self.comm is not None:
                 d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
@@ -126,9 +127,9 @@ class GANTrainStep:
         if t.loss_adversarial:
             if d_handle is not None:
                 self.comm.wait(d_handle)
-                self.optD.step(grad_scale=1.0 / self.comm.world_size)
+                self.optD.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
             else:
-                self.optD.step()                                                         # D weights change HERE
+                self.optD.step(finalized=True)                                           # D weights change HERE
 
         # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
         self._set_d_grad(False)          # D's weight grads from loss_G are discarded by the reference: skip them
@@ -145,11 +146,12 @@ class GANTrainStep:
             loss_G.backward()
         finally:
             self._set_d_grad(True)
+        self.optG.finalize_grads()
         if self.comm is not None:
             self.comm.wait(self.comm.launch(self.optG.flat.grad))
-            self.optG.step(grad_scale=1.0 / self.comm.world_size)
+            self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
         else:
-            self.optG.step()
+            self.optG.step(finalized=True)
         out["generator"] = loss_G.detach()
         out["x_pred"] = x_pred_t.detach()
         self.last = out
@@ -184,6 +186,13 @@ def _summary_writer(model_directory: Path):
         return _NullWriter()
 
 
+def make_optimizers(netG, netD):
+    """Flat arenas + fused AdamW + multi-tensor conv handling (ConvPack) for both networks."""
+    from .optim import ConvPack
+    fg, fd = FlatParams(netG), FlatParams(netD)
+    return FusedAdamW(fg, pack=ConvPack(netG, fg)), FusedAdamW(fd, pack=ConvPack(netD, fd))
+
+
 def build_training_objects(cfg, device, emg_enc_ckpt):
     netG = init_emg_generator(cfg).to(device)
     netD = init_emg_discriminators(cfg).to(device)
@@ -191,8 +200,7 @@ def build_training_objects(cfg, device, emg_enc_ckpt):
     emg_encoder.eval().to(device)
     multi_td_loss = MultiTimeDomainFeatureLoss(cfg.data.num_emg_channels).to(device)
     emg_encoder_loss = EMGEncoderLoss(emg_encoder).to(device)
-    optG = FusedAdamW(FlatParams(netG))
-    optD = FusedAdamW(FlatParams(netD))
+    optG, optD = make_optimizers(netG, netD)
     return netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD
 
 

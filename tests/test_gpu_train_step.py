@@ -47,7 +47,8 @@ def build(name):
     enc = EMGEncoderTransformer(8, 256, 48, model_size=ms, num_transformer_layers=nl, dim_feedforward=ff)
     enc.load_state_dict(fill_state_dict(oshapes.encoder_shapes(ms, 3, nl, dim_feedforward=ff)))
     netG, netD, enc = netG.cuda(), netD.cuda(), enc.cuda().eval()
-    optG, optD = FusedAdamW(FlatParams(netG)), FusedAdamW(FlatParams(netD))
+    from ste_gan_amd.train import make_optimizers
+    optG, optD = make_optimizers(netG, netD)
     step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
     return cfg, netG, netD, optG, optD, step
 

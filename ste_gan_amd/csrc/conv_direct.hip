@@ -123,7 +123,7 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
     return t;
 }
 
-template <int TN, bool FAST>
+template <int TN, bool FAST, bool XVEC>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BN = 64 * TN;
     extern __shared__ __align__(16) float smem[];      // Ws[66*64] | Xs[CC*XROW]
@@ -155,20 +155,26 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     const int RCV = ntaps * CC;                     // valid rows per chunk
     const int RC = (RCV + 7) & ~7;                  // padded to the MFMA loop's unroll (zero weight rows)
 
-    // ---- chunk-invariant part of the X staging: thread element e <-> tile index tid + 256 e = ci * XROW + slot
+    // ---- chunk-invariant part of the X staging.  Scalar form: thread element e <-> tile index tid + 256 e =
+    // ci * XROW + slot.  Vector form (XVEC: row length and valid extent are multiples of 4 floats, no upsample): every
+    // segment starts at the source position rounded DOWN to a multiple of 4, so one 16-byte DMA moves 4 slots that
+    // are all valid or all zero; the rounding (0..3 slots) is added to the lane's column base instead.
     const int b_lo = (int)fd_div((uint32_t)n0, fdU), u0 = n0 - b_lo * U;
-    int x_src[XE];      // source offset (without the chunk's channel base); 0 with x_ci = big when zero-filled
-    int x_ci[XE];       // channel within the chunk (1<<20 = never valid)
+    const int qbase0 = u0 * cs + off_min, qbaseN = off_min;                 // first / later segments
+    const int qal0 = XVEC ? (qbase0 & ~3) : qbase0, qalN = XVEC ? (qbaseN & ~3) : qbaseN;
+    constexpr int XN = XVEC ? XE / 4 : XE;
+    int x_src[XN];      // source offset (without the chunk's channel base); x_ci = big marks zero fill
+    int x_ci[XN];       // channel within the chunk (1<<20 = never valid)
 #pragma unroll
-    for (int e = 0; e < XE; ++e) {
-        const int idx = tid + 256 * e;
+    for (int e = 0; e < XN; ++e) {
+        const int idx = (tid + 256 * e) * (XVEC ? 4 : 1);
         x_src[e] = 0;
         x_ci[e] = 1 << 20;
         if (idx < CC * p.XROW) {
             const int ci = (int)fd_div((uint32_t)idx, p.fdXROW), slot = idx - ci * p.XROW;
             const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
             const int b = b_lo + sg;
-            const int q = (sg == 0 ? u0 : 0) * cs + off_min + sl;
+            const int q = (sg == 0 ? qal0 : qalN) + sl;
             if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq) {
                 x_ci[e] = ci;
                 x_src[e] = (b * p.Csrc + ci) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q);
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         if (n0 + jn < N) {
             const int uu = u0 + jn;
             const int sg = (int)fd_div((uint32_t)uu, fdU), u = uu - sg * U;
-            cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs;
+            cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs + (sg == 0 ? qbase0 - qal0 : qbaseN - qalN);
         }
         colbase[j] = cb;
     }
@@ -238,11 +244,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             }                                                                                                  \
         }                                                                                                      \
         const float* xc_ = p.src + (size_t)(g * p.C2_g + c0_) * p.Tsrc;                                        \
-        _Pragma("unroll") for (int e = 0; e < XE; ++e) {                                                       \
-            const int idx = tid + 256 * e;                                                                     \
+        _Pragma("unroll") for (int e = 0; e < XN; ++e) {                                                       \
+            const int idx = (tid + 256 * e) * (XVEC ? 4 : 1);                                                  \
             if (idx < CC * p.XROW) {                                                                           \
                 const float* src_ = (x_ci[e] < lim_) ? xc_ + x_src[e] : zero_row;                              \
-                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + wave * 64 + 256 * e), 4, 0, 0); \
+                if (XVEC) __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + (wave * 64 + 256 * e) * 4), 16, 0, 0); \
+                else __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + wave * 64 + 256 * e), 4, 0, 0); \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -484,14 +491,15 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 struct Geo { int CC, logCC, SEG, NSEG, XROW, BN; size_t lds; bool ok; };
 
 // geometry for one launch; ntaps_max bounds the taps of any phase
-Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks) {
+Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks, bool xvec) {
     Geo gm;
     gm.ok = false;
     if (ntaps_max > MAX_TAPS) return gm;
     // BN: 128 when the grid still fills the chip, else 64
     for (int BN : {128, 64}) {
         const int UT = U < BN ? U : BN;
-        const int SEG = (UT - 1) * cs + span_off + 1;
+        int SEG = (UT - 1) * cs + span_off + 1;
+        if (xvec) SEG = (SEG + 3 + 3) & ~3;          // + up to 3 slots of down-rounding, padded to whole float4s
         // batch elements one tile can touch: worst case over the per-phase column counts U_min..U
         int NSEG = 1;
         for (int uu = (U_min < 1 ? 1 : U_min); uu <= U; ++uu) {
@@ -574,15 +582,23 @@ extern "C" int stegan_conv_prep_multi(int32_t n, const void* table_dev, int32_t 
     return STEGAN_OK;
 }
 
-// split-K factor: enough blocks to keep >= ~4 resident per CU (the loop is latency-bound at low occupancy)
+// split-K factor from a small cost model.  All blocks of a launch are co-resident (<= ~3 per CU) and share their CU's
+// matrix pipes, so time ~ (max blocks on one CU) x (chunks per block + fixed per-block overhead, ~2.5 chunk
+// equivalents for prologue + first DMA latency + epilogue) + the extra pass that sums the partial tiles.
 static int choose_splits(long base_blocks, int nchunks) {
-    static const char* env = getenv("STEGAN_SPLITK_TARGET");
-    const long target = env ? atol(env) : 1024;
-    if (target <= 0 || base_blocks * 2 > target || nchunks < 4) return 1;
-    long sp = (target + base_blocks - 1) / base_blocks;
-    if (sp > nchunks / 2) sp = nchunks / 2;
-    if (sp > 16) sp = 16;
-    return sp < 1 ? 1 : (int)sp;
+    static const char* env = getenv("STEGAN_SPLITK");
+    if (env) { int f = atoi(env); return f < 1 ? 1 : (f > nchunks ? nchunks : f); }
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 16 && s <= nchunks; ++s) {
+        const int per = (nchunks + s - 1) / s;
+        if (s > 1 && per < 2) break;
+        const long blocks = base_blocks * ((nchunks + per - 1) / per);
+        const double rounds = (double)((blocks + 255) / 256);
+        const double cost = rounds * (per + 2.5) + (s > 1 ? 1.5 : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 // returns 1 when the v2 kernel cannot take this shape (caller falls back to the generic implicit-GEMM kernel)
@@ -617,7 +633,10 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         cs = 1; U = (Te + d->stride - 1) / d->stride; U_min = Te / d->stride; phases = d->stride;
     }
     const long N = (long)d->B * U;
-    Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases);
+    // 16-byte X DMA needs float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
+    const bool xvec = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
+                      !getenv("STEGAN_NO_XVEC");
+    Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
     if (!gm.ok) return 1;
     p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.U0 = U;
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
@@ -641,13 +660,15 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
     const bool fast = gm.CC >= 8;
+#define STEGAN_LAUNCH(TN_, F_, V_) hipLaunchKernelGGL((conv_direct_kernel<TN_, F_, V_>), grid, dim3(256), gm.lds, s, p)
     if (gm.BN == 128) {
-        if (fast) hipLaunchKernelGGL((conv_direct_kernel<2, true>), grid, dim3(256), gm.lds, s, p);
-        else hipLaunchKernelGGL((conv_direct_kernel<2, false>), grid, dim3(256), gm.lds, s, p);
+        if (fast) { if (xvec) STEGAN_LAUNCH(2, true, true); else STEGAN_LAUNCH(2, true, false); }
+        else      { if (xvec) STEGAN_LAUNCH(2, false, true); else STEGAN_LAUNCH(2, false, false); }
     } else {
-        if (fast) hipLaunchKernelGGL((conv_direct_kernel<1, true>), grid, dim3(256), gm.lds, s, p);
-        else hipLaunchKernelGGL((conv_direct_kernel<1, false>), grid, dim3(256), gm.lds, s, p);
+        if (fast) { if (xvec) STEGAN_LAUNCH(1, true, true); else STEGAN_LAUNCH(1, true, false); }
+        else      { if (xvec) STEGAN_LAUNCH(1, false, true); else STEGAN_LAUNCH(1, false, false); }
     }
+#undef STEGAN_LAUNCH
     if (p.splits > 1) {
         long eb = (out_elems + 255) / 256;
         if (eb > 4096) eb = 4096;

@@ -280,7 +280,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         __syncthreads();        // hipcc drains vmcnt(0) here: this wave's DMA of chunk c has landed, and after the
                                 // barrier so has everyone's; nobody still reads buffer cur ^ 1
         if (c == c_begin + 3) { STAMP(4) }
-        if (c + 1 < c_end) STEGAN_DMA_CHUNK(c + 1, cur ^ 1)
+        if (c + 1 < c_end) {
+            // the short DMA-issue phase runs at raised priority so it is not starved by the co-resident waves' MFMA
+            // streams (they keep the matrix pipe busy meanwhile)
+            __builtin_amdgcn_s_setprio(2);
+            STEGAN_DMA_CHUNK(c + 1, cur ^ 1)
+            __builtin_amdgcn_s_setprio(0);
+        }
         if (c == c_begin + 3) { STAMP(6) }
         const float* Wcur = smem + cur * buf_floats;
         const float* Xcur = Wcur + 66 * 64;

@@ -83,7 +83,7 @@ class ConvProfiler:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, nominal, live, e0, e1 in self.records:
+        for name, nominal, live, e0, e1, *_ in self.records:
             a = agg.setdefault(name, dict(launches=0, ms=0.0, nominal_macs=0, live_macs=0))
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
@@ -106,8 +106,18 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     rc = fn()
     e1.record()
     if rc != 1:
-        PROFILER.records.append((name, nominal, live, e0, e1))
+        PROFILER.records.append((name, nominal, live, e0, e1,
+                                 (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout)))
     return rc
+
+def profiler_by_shape(prof: "ConvProfiler"):
+    """(mode, shape) -> [launches, total ms, nominal MACs] for diagnostics."""
+    torch.cuda.synchronize()
+    agg = {}
+    for name, nominal, live, e0, e1, shape in prof.records:
+        a = agg.setdefault(shape, [0, 0.0, 0])
+        a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += nominal
+    return agg
 
 
 # ---------------------------------------------------------------------------------------------

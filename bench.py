@@ -173,8 +173,15 @@ def main():
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         all_ms = sum(v["ms"] for v in agg.values())
         all_fl = 2.0 * sum(v["nominal_macs"] for v in agg.values())
+        traffic = None      # HBM bytes per launch from the committed PMC passes (bench.py itself cannot run rocprofv3)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            key = "conv_direct_kernel" if name.startswith("conv_direct_kernel") else name
+            traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": a["launches"] // args.profile_steps, "avg_launch_us": round(avg_ms * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 4),
                 "live_tap_frac": round(a["live_macs"] / a["nominal_macs"], 4),

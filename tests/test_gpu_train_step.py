@@ -114,3 +114,27 @@ def test_optimizer_state_dict_roundtrip():
     opt2.load_state_dict(topt.state_dict())         # and we accept torch's
     assert opt2.step_count == 3
     torch.testing.assert_close(opt2.exp_avg, opt.exp_avg, rtol=2e-5, atol=1e-7)
+
+
+def test_train_step_with_rccl_process_group(golden):
+    """The data-parallel code path on the GPU (RCCL all-reduce of the flat gradient arenas on a side stream, 1/world folded
+    into AdamW), exercised with a 1-rank "nccl" group: must reproduce the golden two-step fixture exactly like the
+    single-process path.  (Multi-rank equivalence is covered on CPU/gloo in tests/test_ddp_gloo.py.)"""
+    import os
+    import torch.distributed as dist
+    name = "step_c48_b3"
+    g = golden(name)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg, netG, netD, optG, optD, step = build(name)
+        assert step.comm is not None and step.comm.world_size == 1
+        for s in range(2):
+            out = step(to_batch(cases.step_batch(name, s)))
+            st = step.read_stats(out)
+            ref = g[f"s{s}.losses"]
+            close([st["discriminator"], st["generator"]], ref[[0, 1]], 1e-4, f"s{s}.losses")
+            close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
+            close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
+    finally:
+        dist.destroy_process_group()

@@ -123,9 +123,12 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
     return t;
 }
 
-template <int TN, bool FAST, bool XVEC>
+template <int TM, int TN, bool FAST, bool XVEC>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BN = 64 * TN;
+    constexpr int BM = 64 * TM;                 // 2x2 waves, wave tile (32*TM) x (32*TN)
+    constexpr int WEt = WE * TM;                // W-tile float4 per thread and chunk
+    constexpr int WROW4 = 16 * TM;              // float4 per W row
     extern __shared__ __align__(16) float smem[];      // Ws[66*64] | Xs[CC*XROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     STAMP(0)
     const int wm = wave >> 1, wn = wave & 1;
     const int g = blockIdx.y / p.m_tiles;
-    const int m0 = (blockIdx.y % p.m_tiles) * BM2;
+    const int m0 = (blockIdx.y % p.m_tiles) * BM;
     const int phase = blockIdx.z / p.splits;
     const int split = blockIdx.z - phase * p.splits;
 
@@ -182,12 +185,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         }
     }
     // ---- W staging: thread element i <-> float4 index tid + 256 i = row * 16 + c4
-    int w_off[WE];      // offset of the float4 inside the group's transposed weights, without the chunk term
-    int w_ci[WE];
+    int w_off[WEt];     // offset of the float4 inside the group's transposed weights, without the chunk term
+    int w_ci[WEt];
 #pragma unroll
-    for (int i = 0; i < WE; ++i) {
+    for (int i = 0; i < WEt; ++i) {
         const int idx = tid + 256 * i;
-        const int r = idx >> 4, c4 = idx & 15;
+        const int r = idx / WROW4, c4 = idx % WROW4;
         const int tap = r >> p.logCC, ci = r & (CC - 1);
         w_ci[i] = 1 << 20;
         w_off[i] = 0;
@@ -210,11 +213,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         colbase[j] = cb;
     }
 
-    f32x16 acc[TN];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int half = lane >> 5, l31 = lane & 31;
     const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) / CC : 0;
@@ -234,12 +239,12 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         const int c0_ = (c_) * CC;                                                                             \
         const int lim_ = p.C2_g - c0_;                                                                         \
         float* Wd_ = smem + (buf_) * buf_floats;                                                               \
-        float* Xd_ = Wd_ + 66 * 64;                                                                            \
+        float* Xd_ = Wd_ + 66 * BM;                                                                            \
         const float* wc_ = wt_g + (size_t)c0_ * p.LD;                                                          \
-        _Pragma("unroll") for (int i = 0; i < WE; ++i) {                                                       \
+        _Pragma("unroll") for (int i = 0; i < WEt; ++i) {                                                      \
             const int idx = tid + 256 * i;                                                                     \
-            if ((idx >> 4) < RC) {                                                                             \
-                const float* src_ = (w_ci[i] < lim_) ? wc_ + w_off[i] : zero_row + (idx & 15) * 4;             \
+            if ((idx / WROW4) < RC) {                                                                          \
+                const float* src_ = (w_ci[i] < lim_) ? wc_ + w_off[i] : zero_row + (idx % WROW4) * 4;          \
                 __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (wave * 64 + 256 * i) * 4), 16, 0, 0); \
             }                                                                                                  \
         }                                                                                                      \
@@ -258,19 +263,20 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #define STEGAN_LOAD_BODY(a_, b_, r2_)                                                                          \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                            \
         const int r = (r2_) + 2 * k + half;                                                                    \
-        a_[k] = Wcur[r * 64 + wm * 32 + l31];                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[k][i] = Wcur[r * BM + (wm * TM + i) * 32 + l31];     \
         const int tap = r >> p.logCC, ci = r & (CC - 1);                                                       \
         const int xo = r < RCV ? ci * p.XROW + tap * tp.step : 0;                                              \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = fmaxf(Xcur[xo + colbase[j]], relu_floor);    \
     }
 #define STEGAN_MFMA_BODY(a_, b_)                                                                               \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                              \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                         \
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k], b_[k][j], acc[j], 0, 0, 0);
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k][i], b_[k][j], acc[i][j], 0, 0, 0);
 
     // Two LDS buffers, ONE barrier per chunk: the DMA of chunk c+1 is issued right behind the barrier and stays in
     // flight while the matrix cores run over chunk c (LDS reads of the next 4-MFMA body interleaved with the MFMAs).
-    const int buf_floats = 66 * 64 + CC * p.XROW;
+    const int buf_floats = 66 * BM + CC * p.XROW;
     STAMP(1)
     if (c_begin < c_end) STEGAN_DMA_CHUNK(c_begin, 0)
     STAMP(2)
@@ -289,25 +295,26 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         }
         if (c == c_begin + 3) { STAMP(6) }
         const float* Wcur = smem + cur * buf_floats;
-        const float* Xcur = Wcur + 66 * 64;
+        const float* Xcur = Wcur + 66 * BM;
         if constexpr (FAST) {
             // Fast path (host guarantees CC >= 8) (K_eff*CC is a multiple of 8, a body of 8 rows never straddles a tap): the B address is
             // colb2 + scalar, the A address abase + immediate.  Loads of the NEXT body are interleaved one row pair at
             // a time with the MFMAs of the current body, so LDS latency and address math hide under the matrix pipe.
-            const float* abase = Wcur + half * 64 + wm * 32 + l31;
+            const float* abase = Wcur + half * BM + wm * TM * 32 + l31;
             int colb2[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) colb2[j] = colbase[j] + half * p.XROW;
-            float a0[4], b0[4][TN], a1[4], b1[4][TN];
+            float a0[4][TM], b0[4][TN], a1[4][TM], b1[4][TN];
 #define STEGAN_FAST_LOAD(a_, b_, r2_, k_)                                                                      \
             {                                                                                                  \
                 const int xb_ = ((r2_) & (CC - 1)) * p.XROW + ((r2_) >> p.logCC) * tp.step + 2 * (k_) * p.XROW; \
-                a_[k_] = abase[((r2_) + 2 * (k_)) * 64];                                                       \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[k_][i] = abase[((r2_) + 2 * (k_)) * BM + i * 32]; \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = fmaxf(Xcur[xb_ + colb2[j]], relu_floor); \
             }
 #define STEGAN_FAST_MFMA(a_, b_, k_)                                                                           \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k_], b_[k_][j], acc[j], 0, 0, 0);
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k_][i], b_[k_][j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) STEGAN_FAST_LOAD(a0, b0, 0, k)
             for (int r2 = 0; r2 < RC; r2 += 16) {
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #undef STEGAN_FAST_LOAD
 #undef STEGAN_FAST_MFMA
         } else {
-            float a0[4], b0[4][TN], a1[4], b1[4][TN];
+            float a0[4][TM], b0[4][TN], a1[4][TM], b1[4][TN];
             STEGAN_LOAD_BODY(a0, b0, 0)
             for (int r2 = 0; r2 < RC; r2 += 16) {
                 if (r2 + 8 < RC) STEGAN_LOAD_BODY(a1, b1, r2 + 8)
@@ -359,13 +366,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         const int n = n_ok ? n0 + jn : N - 1;
         const int b = (int)fd_div((uint32_t)n, fdU), u = n - b * U;
         const int to = p.mode == 0 ? u : phase + u * os;
-        const int mrow0 = m0 + wm * 32 + 4 * half;
+#pragma unroll
+     for (int im = 0; im < TM; ++im) {
+        const int mrow0 = m0 + (wm * TM + im) * 32 + 4 * half;
         if (p.splits > 1) {
             float* dst = p.partial + (size_t)split * out_elems;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mrow0 + (e & 3) + 8 * (e >> 2);
-                if (n_ok && m < p.M_g) dst[((size_t)b * p.Cdst + g * p.M_g + m) * p.Tdst + to] = acc[j][e];
+                if (n_ok && m < p.M_g) dst[((size_t)b * p.Cdst + g * p.M_g + m) * p.Tdst + to] = acc[im][j][e];
             }
             continue;
         }
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int m = mrow0 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
-            float v = acc[j][e0 + e] * sc[e] + bi[e] + rs[e];
+            float v = acc[im][j][e0 + e] * sc[e] + bi[e] + rs[e];
             if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
             else if (p.out_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
             else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             }
         }
       }
+     }
     }
 #undef STAMP
 }
@@ -559,8 +569,8 @@ int check_desc(const stegan_conv_desc* d) {
 extern "C" int64_t stegan_conv_prep_floats(const stegan_conv_desc* d, int32_t which) {
     if (!d || d->groups <= 0) return -1;
     const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
-    if (which == 0) return (int64_t)d->groups * d->K * Cin_g * round_up(Cout_g, 64) + 64;
-    return (int64_t)d->groups * d->K * Cout_g * round_up(Cin_g, 64) + 64;
+    if (which == 0) return (int64_t)d->groups * d->K * Cin_g * round_up(Cout_g, 64) + 128;
+    return (int64_t)d->groups * d->K * Cout_g * round_up(Cin_g, 64) + 128;
 }
 
 extern "C" int stegan_conv_prep(const stegan_conv_desc* d, const float* v, const float* scale, float* wf, float* wb,
@@ -591,9 +601,8 @@ extern "C" int stegan_conv_prep_multi(int32_t n, const void* table_dev, int32_t 
 // split-K factor from a small cost model.  All blocks of a launch are co-resident (<= ~3 per CU) and share their CU's
 // matrix pipes, so time ~ (max blocks on one CU) x (chunks per block + fixed per-block overhead, ~2.5 chunk
 // equivalents for prologue + first DMA latency + epilogue) + the extra pass that sums the partial tiles.
-static int choose_splits(long base_blocks, int nchunks) {
+static int choose_splits(long base_blocks, int nchunks, double chunk_cost = 1.0, double* cost_out = nullptr) {
     static const char* env = getenv("STEGAN_SPLITK");
-    if (env) { int f = atoi(env); return f < 1 ? 1 : (f > nchunks ? nchunks : f); }
     int best = 1;
     double best_cost = 1e30;
     for (int s = 1; s <= 16 && s <= nchunks; ++s) {
@@ -601,9 +610,11 @@ static int choose_splits(long base_blocks, int nchunks) {
         if (s > 1 && per < 2) break;
         const long blocks = base_blocks * ((nchunks + per - 1) / per);
         const double rounds = (double)((blocks + 255) / 256);
-        const double cost = rounds * (per + 2.5) + (s > 1 ? 1.5 : 0.0);
+        const double cost = rounds * (per * chunk_cost + 2.5) + (s > 1 ? 1.5 : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
+    if (env) { int f = atoi(env); best = f < 1 ? 1 : (f > nchunks ? nchunks : f); }
+    if (cost_out) *cost_out = best_cost;
     return best;
 }
 
@@ -647,10 +658,24 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.U0 = U;
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
-    p.m_tiles = ceil_div(p.M_g, BM2);
     const long nb = (N + gm.BN - 1) / gm.BN;
     const int nchunks = ceil_div(p.C2_g, gm.CC);
-    int splits = choose_splits(nb * p.m_tiles * d->groups * phases, nchunks);
+    const bool fast = gm.CC >= 8;
+    // M tile: 128 rows (two MFMA row tiles per wave: twice the matrix work per staged X element, per barrier and per
+    // block prologue / epilogue) when the channel count allows it and the cost model does not lose to 64-row tiles
+    double cost1 = 0, cost2 = 1e30;
+    int splits = choose_splits(nb * ceil_div(p.M_g, 64) * d->groups * phases, nchunks, 1.0, &cost1);
+    int tm = 1;
+    static const char* env_tm = getenv("STEGAN_TM");
+    // measured (scripts/conv_microbench.py): 128-row tiles win only on the small-N layers (few output tiles, deep
+    // reductions); with plenty of tiles the smaller LDS footprint of 64-row tiles (3 resident blocks per CU) wins
+    const long base1 = nb * ceil_div(p.M_g, 64) * d->groups * phases;
+    if (fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
+        const int s2 = choose_splits(nb * (p.M_g / 128) * d->groups * phases, nchunks, 1.7, &cost2);
+        tm = 2; splits = s2;
+    }
+    if (tm == 2) gm.lds = 2 * ((size_t)66 * 128 * 4 + (size_t)gm.CC * gm.XROW * 4);
+    p.m_tiles = ceil_div(p.M_g, 64 * tm);
     const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
     if (splits > 1 && (!workspace || workspace_floats < out_elems * splits)) {
         splits = workspace ? (int)(workspace_floats / out_elems) : 1;     // use what the caller provided
@@ -665,14 +690,23 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr;
     }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
-    const bool fast = gm.CC >= 8;
-#define STEGAN_LAUNCH(TN_, F_, V_) hipLaunchKernelGGL((conv_direct_kernel<TN_, F_, V_>), grid, dim3(256), gm.lds, s, p)
-    if (gm.BN == 128) {
-        if (fast) { if (xvec) STEGAN_LAUNCH(2, true, true); else STEGAN_LAUNCH(2, true, false); }
-        else      { if (xvec) STEGAN_LAUNCH(2, false, true); else STEGAN_LAUNCH(2, false, false); }
+    if (gm.lds > 64 * 1024) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<2, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_direct_kernel<2, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            attr_done = true;
+        }
+    }
+#define STEGAN_LAUNCH(TM_, TN_, F_, V_) hipLaunchKernelGGL((conv_direct_kernel<TM_, TN_, F_, V_>), grid, dim3(256), gm.lds, s, p)
+    if (tm == 2) {
+        if (xvec) STEGAN_LAUNCH(2, 1, true, true); else STEGAN_LAUNCH(2, 1, true, false);
+    } else if (gm.BN == 128) {
+        if (fast) { if (xvec) STEGAN_LAUNCH(1, 2, true, true); else STEGAN_LAUNCH(1, 2, true, false); }
+        else      { if (xvec) STEGAN_LAUNCH(1, 2, false, true); else STEGAN_LAUNCH(1, 2, false, false); }
     } else {
-        if (fast) { if (xvec) STEGAN_LAUNCH(1, true, true); else STEGAN_LAUNCH(1, true, false); }
-        else      { if (xvec) STEGAN_LAUNCH(1, false, true); else STEGAN_LAUNCH(1, false, false); }
+        if (fast) { if (xvec) STEGAN_LAUNCH(1, 1, true, true); else STEGAN_LAUNCH(1, 1, true, false); }
+        else      { if (xvec) STEGAN_LAUNCH(1, 1, false, true); else STEGAN_LAUNCH(1, 1, false, false); }
     }
 #undef STEGAN_LAUNCH
     if (p.splits > 1) {

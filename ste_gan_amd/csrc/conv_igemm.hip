@@ -47,60 +47,63 @@ struct ConvK {
     FastDiv fdS;         // / stride
 };
 
+// Address generation is separated from the loads: every element yields (pointer, valid) and the kernel then issues all
+// loads of a chunk back to back on clamped, always-in-bounds addresses and zeroes the invalid ones with a select when
+// it writes LDS.  (A branch around a load makes hipcc wait for each load in turn: 16 serialised round trips per chunk.)
 template <int MODE>
-__device__ __forceinline__ float load_a(const ConvK& p, int g, int m, int r) {
-    // m, r are group-local indices; caller guarantees nothing -> predicate here
-    if (m >= p.M || r >= p.R) return 0.f;
+__device__ __forceinline__ const float* addr_a(const ConvK& p, int g, int m, int r, bool& ok) {
+    ok = m < p.M && r < p.R;
+    const int mm = ok ? m : 0, rr = ok ? r : 0;
     if (MODE == MODE_FWD) {
         uint32_t ci, ke;
-        fd_divmod((uint32_t)r, p.fdK, ci, ke);
-        return p.w[((size_t)(g * p.Cout_g + m) * p.Cin_g + ci) * p.K + ke + p.k_lo];
+        fd_divmod((uint32_t)rr, p.fdK, ci, ke);
+        return p.w + ((size_t)(g * p.Cout_g + mm) * p.Cin_g + ci) * p.K + ke + p.k_lo;
     } else if (MODE == MODE_BWD_DATA) {
         uint32_t co, ke;
-        fd_divmod((uint32_t)r, p.fdK, co, ke);
-        return p.w[((size_t)(g * p.Cout_g + co) * p.Cin_g + m) * p.K + ke + p.k_lo];
+        fd_divmod((uint32_t)rr, p.fdK, co, ke);
+        return p.w + ((size_t)(g * p.Cout_g + co) * p.Cin_g + mm) * p.K + ke + p.k_lo;
     } else {
         uint32_t b, t;
-        fd_divmod((uint32_t)r, p.fdT, b, t);
-        return p.dy[((size_t)b * p.Cout + g * p.Cout_g + m) * p.Tout + t];
+        fd_divmod((uint32_t)rr, p.fdT, b, t);
+        return p.dy + ((size_t)b * p.Cout + g * p.Cout_g + mm) * p.Tout + t;
     }
 }
 
-// gather of the (activated, upsampled, zero padded) conv input for channel ci (group local), tap index ke
-__device__ __forceinline__ float gather_x(const ConvK& p, int g, uint32_t b, uint32_t t, uint32_t ci, uint32_t ke) {
-    int tin = (int)t * p.stride + (int)(ke + p.k_lo) * p.dil - p.pad;
-    if (tin < 0 || tin >= p.Te) return 0.f;
-    float v = p.x[((size_t)b * p.Cin + g * p.Cin_g + ci) * p.Tin + (tin >> p.ups)];
-    if (p.in_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
-    return v;
+// (activated, upsampled, zero padded) conv input for group-local channel ci, live-tap index ke
+__device__ __forceinline__ const float* addr_x(const ConvK& p, int g, uint32_t b, uint32_t t, uint32_t ci, uint32_t ke,
+                                               bool& ok) {
+    const int tin = (int)t * p.stride + (int)(ke + p.k_lo) * p.dil - p.pad;
+    ok = ok && tin >= 0 && tin < p.Te;
+    const int tt = ok ? tin : 0;
+    return p.x + ((size_t)b * p.Cin + g * p.Cin_g + ci) * p.Tin + (tt >> p.ups);
 }
 
 template <int MODE>
-__device__ __forceinline__ float load_b(const ConvK& p, int g, int r, int n) {
-    if (r >= p.R || n >= p.N) return 0.f;
+__device__ __forceinline__ const float* addr_b(const ConvK& p, int g, int r, int n, bool& ok, const float*& scale_ptr) {
+    ok = r < p.R && n < p.N;
+    const int rr = ok ? r : 0, nn = ok ? n : 0;
+    scale_ptr = nullptr;
     if (MODE == MODE_FWD) {
         uint32_t ci, ke, b, t;
-        fd_divmod((uint32_t)r, p.fdK, ci, ke);
-        fd_divmod((uint32_t)n, p.fdT, b, t);
-        return gather_x(p, g, b, t, ci, ke);
+        fd_divmod((uint32_t)rr, p.fdK, ci, ke);
+        fd_divmod((uint32_t)nn, p.fdT, b, t);
+        return addr_x(p, g, b, t, ci, ke, ok);
     } else if (MODE == MODE_BWD_DATA) {
         uint32_t co, ke, b, te;
-        fd_divmod((uint32_t)r, p.fdK, co, ke);
-        fd_divmod((uint32_t)n, p.fdT, b, te);
-        int tt = (int)te + p.pad - (int)(ke + p.k_lo) * p.dil;
-        if (tt < 0) return 0.f;
+        fd_divmod((uint32_t)rr, p.fdK, co, ke);
+        fd_divmod((uint32_t)nn, p.fdT, b, te);
+        const int tt = (int)te + p.pad - (int)(ke + p.k_lo) * p.dil;
         uint32_t q, rem;
-        fd_divmod((uint32_t)tt, p.fdS, q, rem);
-        if (rem != 0 || (int)q >= p.Tout) return 0.f;
-        int cog = g * p.Cout_g + co;
-        float v = p.dy[((size_t)b * p.Cout + cog) * p.Tout + q];
-        if (p.scale) v *= p.scale[cog];
-        return v;
+        fd_divmod((uint32_t)(tt < 0 ? 0 : tt), p.fdS, q, rem);
+        ok = ok && tt >= 0 && rem == 0 && (int)q < p.Tout;
+        const int cog = g * p.Cout_g + co;
+        if (p.scale) scale_ptr = p.scale + cog;
+        return p.dy + ((size_t)b * p.Cout + cog) * p.Tout + (ok ? q : 0);
     } else {
         uint32_t ci, ke, b, t;
-        fd_divmod((uint32_t)n, p.fdK, ci, ke);
-        fd_divmod((uint32_t)r, p.fdT, b, t);
-        return gather_x(p, g, b, t, ci, ke);
+        fd_divmod((uint32_t)nn, p.fdK, ci, ke);
+        fd_divmod((uint32_t)rr, p.fdT, b, t);
+        return addr_x(p, g, b, t, ci, ke, ok);
     }
 }
 
@@ -140,22 +143,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float ra[A_PER], rb[B_PER];
+    float ra[A_PER], rb[B_PER], rs[MODE == MODE_BWD_DATA ? B_PER : 1];
+    unsigned ok_a = 0, ok_b = 0;          // validity bits of the staged elements (applied when LDS is written)
 
     auto load_chunk = [&](int r0) {
+        ok_a = 0; ok_b = 0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             int m, r;
             if (A_RFAST) { r = tid & 31; m = (tid >> 5) + 8 * i; }
             else         { m = tid % BM; r = tid / BM + (256 / BM) * i; }
-            ra[i] = load_a<MODE>(p, g, m0 + m, r0 + r);
+            bool ok;
+            const float* ptr = addr_a<MODE>(p, g, m0 + m, r0 + r, ok);
+            ra[i] = *ptr;
+            ok_a |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             int n, r;
             if (B_RFAST) { r = tid & 31; n = (tid >> 5) + 8 * i; }
             else         { n = tid % BN; r = tid / BN + (256 / BN) * i; }
-            rb[i] = load_b<MODE>(p, g, r0 + r, n0 + n);
+            bool ok;
+            const float* sp;
+            const float* ptr = addr_b<MODE>(p, g, r0 + r, n0 + n, ok, sp);
+            rb[i] = *ptr;
+            if (MODE == MODE_BWD_DATA) rs[i] = sp ? *sp : 1.f;
+            ok_b |= (ok ? 1u : 0u) << i;
         }
     };
     auto store_chunk = [&]() {
@@ -164,14 +177,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
             int m, r;
             if (A_RFAST) { r = tid & 31; m = (tid >> 5) + 8 * i; }
             else         { m = tid % BM; r = tid / BM + (256 / BM) * i; }
-            As[r * LDA + m] = ra[i];
+            As[r * LDA + m] = ((ok_a >> i) & 1u) ? ra[i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < B_PER; ++i) {
             int n, r;
             if (B_RFAST) { r = tid & 31; n = (tid >> 5) + 8 * i; }
             else         { n = tid % BN; r = tid / BN + (256 / BN) * i; }
-            Bs[r * LDB + n] = rb[i];
+            float v = rb[i];
+            if (MODE != MODE_BWD_DATA && p.in_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
+            if (MODE == MODE_BWD_DATA) v *= rs[i];
+            Bs[r * LDB + n] = ((ok_b >> i) & 1u) ? v : 0.f;
         }
     };
 

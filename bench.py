@@ -106,6 +106,30 @@ def cpu_baseline(steps=2):
                       f"torch-CPU fp32, {dt:.2f} s/step)"}
 
 
+def gen_infer(args, cfg, device):
+    """BASELINE config 2: Generator.generate on (64, 12, 256) Soft-SU -> (64, 192, 8), fp32 (not the headline metric)."""
+    from ste_gan_amd.constants import DataType
+    from ste_gan_amd.models.generator import init_emg_generator
+    torch.manual_seed(0)
+    netG = init_emg_generator(cfg).to(device).eval()
+    b = synthetic_batch(device, 1000)
+    run = lambda: netG.generate(b[DataType.SPEECH_UNITS], b[DataType.SESSION_INDEX], b[DataType.SPEAKING_MODE_INDEX])
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "EMG frames/sec, generator-only inference at B=64 chunk=200 (BASELINE config 2)",
+                      "value": round(B * T_EMG * args.steps / dt, 1), "unit": "EMG frames/s", "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                      "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "Generator.generate, B=64, T_su=12 -> T_emg=192, fp32"},
+                      "algorithmic_tflops": round(2 * 53.02e9 * args.steps / dt / 1e12, 2)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +137,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
+                    help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,6 +154,8 @@ def main():
 
     from ste_gan_amd import ops
     cfg = make_cfg("train_step")
+    if args.workload == "gen_infer":
+        return gen_infer(args, cfg, device)
     step = build_step(cfg, device)
     batch = synthetic_batch(device, seed=1000 + rank)      # rank-offset seeds: different data per replica
 

@@ -138,3 +138,45 @@ def test_train_step_with_rccl_process_group(golden):
             close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
     finally:
         dist.destroy_process_group()
+
+
+def test_mfcc_variant_step_vs_oracle():
+    """BASELINE config 5 geometry (MFCC input at 100 Hz, chunk 400 -> 50 MFCC frames / 25 SU frames / 400 EMG samples),
+    reduced batch and widths: one full train step against the CPU oracle (no golden fixture for this variant: the oracle
+    itself is pinned by the generator MFCC fixture and the SU-feature train-step fixture)."""
+    from oracle import stegan_oracle as O
+    from oracle.detfill import det_input, det_ints
+    from ste_gan_amd.constants import DataType
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.discriminator import init_emg_discriminators
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.train import GANTrainStep, make_optimizers
+    B, T = 2, 25
+    cfg = make_cfg(32)
+    cfg.model.speech_feature_type = "MFCCS"
+    g_sd = fill_state_dict(oshapes.generator_shapes("MFCCS", 32))
+    d_sd = fill_state_dict(oshapes.discriminator_shapes(True))
+    e_sd = fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128))
+    netG = init_emg_generator(cfg); netG.load_state_dict(g_sd)
+    netD = init_emg_discriminators(cfg); netD.load_state_dict(d_sd)
+    enc = EMGEncoderTransformer(8, 256, 48, model_size=64, num_transformer_layers=2, dim_feedforward=128); enc.load_state_dict(e_sd)
+    netG, netD, enc = netG.cuda(), netD.cuda(), enc.cuda().eval()
+    optG, optD = make_optimizers(netG, netD)
+    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
+    mfcc = det_input("mf.feats", (B, 2 * T, 25)); su = det_input("mf.su", (B, T, 256))
+    x_real = det_input("mf.x", (B, 16 * T, 8), "tanh"); sess = det_ints("mf.s", (B,), 17); ph = det_ints("mf.ph", (B, T), 48)
+    batch = {DataType.REAL_EMG: x_real.cuda(), DataType.SPEECH_UNITS: su.cuda(), DataType.MFCCS: mfcc.cuda(),
+             DataType.SESSION_INDEX: sess.cuda(), DataType.SPEAKING_MODE_INDEX: torch.zeros_like(sess).cuda(),
+             DataType.PHONEMES: ph.cuda()}
+    st = step.read_stats(step(batch))
+    d_train = {k: v for k, v in d_sd.items() if not O.is_sn_buffer(d_sd, k)}
+    o = O.train_step(g_sd, d_sd, e_sd, O.adamw_init(g_sd), O.adamw_init(d_train),
+                     {"su": su, "feats": mfcc, "x_real": x_real, "sess": sess, "phonemes": ph}, speech_feature_type="MFCCS")
+    assert step.last["x_pred"].shape == (B, 400, 8)
+    close([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"], st["feature_matching"]],
+          [o["loss_d"], o["loss_g"], o["loss_td"], o["loss_su"], o["loss_ph"], o["loss_fm"]], 1e-4, "losses")
+    assert st["num_correct_phones"] == o["num_correct_phones"] and st["num_silence_phones"] == o["num_silence_phones"]
+    close(norms(netG.state_dict().values()), norms(g_sd.values()), 2e-5, "g params after step")
+    close(norms(netD.state_dict().values()), norms(d_sd.values()), 2e-5, "d params after step")

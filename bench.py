@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph")
     ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
                     help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
@@ -158,6 +159,11 @@ def main():
         return gen_infer(args, cfg, device)
     step = build_step(cfg, device)
     batch = synthetic_batch(device, seed=1000 + rank)      # rank-offset seeds: different data per replica
+    eager_step = step
+    graphed = world == 1 and not args.no_graph
+    if graphed:                                            # single process: the whole step is one captured hipGraph
+        from ste_gan_amd.train import GraphedTrainStep
+        step = GraphedTrainStep(eager_step, batch, warmup=2)
 
     def barrier():
         if world > 1:
@@ -186,7 +192,7 @@ def main():
     if rank == 0:
         ops.PROFILER = ops.ConvProfiler()
         for _ in range(args.profile_steps):
-            step(batch)
+            eager_step(batch)                              # instrumented pass: eager launches, HIP events per conv
         agg = ops.PROFILER.summary()
         if os.environ.get("STEGAN_BENCH_DETAIL"):
             by = ops.profiler_by_shape(ops.PROFILER)
@@ -229,7 +235,8 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "full GAN train step (G + small MPD/MSD D + multi-TD/SU/phoneme/FM losses + 2x AdamW), "
                                        "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, fp32 parity path",
-                           "global_batch": world * B, "parallelism": f"dp{world}"},
+                           "global_batch": world * B, "parallelism": f"dp{world}",
+                           "launch": "hipGraph replay" if graphed else "eager"},
                 "roofline": roof, "cpu_baseline": cpu,
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)

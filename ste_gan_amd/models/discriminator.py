@@ -127,7 +127,11 @@ class _MultiDisc(nn.Module):
         self.discriminator_names = [d.name for d in self.multi_pooled_disc] + [d.name for d in self.multi_scale_disc]
 
     def forward(self, x):
-        """x: (B, T, C) -> [[fmaps..., logits] for 5 MPD + 3 MSD]  (discriminator.py:144-155 / 180-191)."""
+        """x: (B, T, C) -> [[fmaps..., logits] for 5 MPD + 3 MSD]  (discriminator.py:144-155 / 180-191).
+
+        (Running the eight sub-discriminators on separate HIP streams was measured and rejected: 31.3 vs 29.0 ms/step
+        inside the captured graph -- the convs already split their reductions to fill the chip, so concurrent
+        kernels only compete for LDS and matrix pipes.)"""
         results = [disc(x) for disc in self.multi_pooled_disc]
         xs = ops.btc_to_bct(x)
         for disc in self.multi_scale_disc:

@@ -170,6 +170,55 @@ class GANTrainStep:
         return stats
 
 
+class GraphedTrainStep:
+    """The whole train step captured once into a hipGraph and replayed per batch.
+
+    A step is ~2 900 small launches; captured, the host only refreshes the static input buffers and the three AdamW
+    scalars per optimiser (pinned host words that the captured H2D copies read at replay time) and calls one
+    ``hipGraphLaunch``.  Requirements: fixed batch shapes, single process (the RCCL exchange stays on the eager path).
+    """
+
+    def __init__(self, step: GANTrainStep, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
+        if step.comm is not None:
+            raise RuntimeError("GraphedTrainStep is single-process; use the eager GANTrainStep under torch.distributed")
+        self.step = step
+        self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step(self.static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._counts = (step.optG.step_count, step.optD.step_count)
+        for opt in (step.optG, step.optD):      # make the captured step re-derive scales / transposed weight copies from
+            if opt.pack is not None:            # the live weights at its start: replay stays valid after a checkpoint load
+                opt.pack.invalidate()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = step(self.static)
+        # capture ran the Python side once without executing kernels: undo its optimiser step counts
+        step.optG.step_count, step.optD.step_count = self._counts
+        self.last = self.out
+
+    def _stage(self, opt: FusedAdamW):
+        opt.step_count += 1
+        opt._hyper_host[0] = opt.param_groups[0]["lr"]
+        opt._hyper_host[1] = 1.0 - opt.betas[0] ** opt.step_count
+        opt._hyper_host[2] = 1.0 - opt.betas[1] ** opt.step_count
+
+    def __call__(self, batch_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        for k, v in batch_dict.items():
+            if torch.is_tensor(v):
+                self.static[k].copy_(v, non_blocking=True)
+        self._stage(self.step.optD)
+        self._stage(self.step.optG)
+        self.graph.replay()
+        return self.out
+
+    read_stats = staticmethod(GANTrainStep.read_stats)
+
+
 class _NullWriter:
     def add_scalar(self, *a, **k):
         pass

@@ -180,3 +180,28 @@ def test_mfcc_variant_step_vs_oracle():
     assert st["num_correct_phones"] == o["num_correct_phones"] and st["num_silence_phones"] == o["num_silence_phones"]
     close(norms(netG.state_dict().values()), norms(g_sd.values()), 2e-5, "g params after step")
     close(norms(netD.state_dict().values()), norms(d_sd.values()), 2e-5, "d params after step")
+
+
+def test_graph_replay_matches_golden(golden):
+    """hipGraph capture of the whole step: replaying it for the two fixture batches must give the eager results."""
+    from ste_gan_amd.train import GraphedTrainStep
+    name = "step_c48_b3"
+    g = golden(name)
+    cfg, netG, netD, optG, optD, step = build(name)
+    sdG = {k: v.clone() for k, v in netG.state_dict().items()}
+    sdD = {k: v.clone() for k, v in netD.state_dict().items()}
+    gs = GraphedTrainStep(step, to_batch(cases.step_batch(name, 0)), warmup=2)
+    # warm-up steps trained the nets: restore the fixture's initial state (in place: captured pointers stay valid)
+    netG.load_state_dict(sdG); netD.load_state_dict(sdD)
+    for opt in (optG, optD):
+        opt.exp_avg.zero_(); opt.exp_avg_sq.zero_(); opt.step_count = 0
+    for s in range(2):
+        out = gs(to_batch(cases.step_batch(name, s)))
+        st = gs.read_stats(out)
+        ref = g[f"s{s}.losses"]
+        close([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"], st["feature_matching"]],
+              ref[[0, 1, 3, 4, 5, 6]], 1e-4, f"s{s}.losses")
+        assert [st["num_phones"], st["num_silence_phones"], st["num_correct_phones"],
+                st["num_correct_phones_no_silence"]] == g[f"s{s}.counters"].tolist()
+        close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
+        close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")

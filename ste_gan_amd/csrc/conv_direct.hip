@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     if (n0 >= N) return;
     const FastDiv fdU = (U == p.U0) ? p.fdU0 : p.fdU1;
     const Taps tp = phase_taps(p, phase);
+#ifdef STEGAN_STAMPS_PROLOGUE
+    STAMP(3)
+#endif
     const int ntaps = tp.ntaps, off_min = tp.off_min;
     const int CC = p.CC;
     const int RCV = ntaps * CC;                     // valid rows per chunk
@@ -184,6 +187,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             }
         }
     }
+#ifdef STEGAN_STAMPS_PROLOGUE
+    STAMP(4)
+#endif
     // ---- W staging: thread element i <-> float4 index tid + 256 i = row * 16 + c4
     int w_off[WEt];     // offset of the float4 inside the group's transposed weights, without the chunk term
     int w_ci[WEt];
@@ -199,6 +205,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             w_off[i] = ((tp.kbase + tap * tp.kstep) * p.C2_g + ci) * p.LD + m0 + c4 * 4;
         }
     }
+#ifdef STEGAN_STAMPS_PROLOGUE
+    STAMP(5)
+#endif
     // ---- per-lane column bases for the B operand
     int colbase[TN];
 #pragma unroll
@@ -221,6 +230,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+#ifdef STEGAN_STAMPS_PROLOGUE
+    STAMP(6)
+#endif
     const int half = lane >> 5, l31 = lane & 31;
     const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) / CC : 0;
     const int c_begin = split * p.chunks_per_split;
@@ -282,10 +294,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     STAMP(2)
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
+#ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(3) }
+#endif
         __syncthreads();        // hipcc drains vmcnt(0) here: this wave's DMA of chunk c has landed, and after the
                                 // barrier so has everyone's; nobody still reads buffer cur ^ 1
+#ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(4) }
+#endif
         if (c + 1 < c_end) {
             // the short DMA-issue phase runs at raised priority so it is not starved by the co-resident waves' MFMA
             // streams (they keep the matrix pipe busy meanwhile)
@@ -293,7 +309,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             STEGAN_DMA_CHUNK(c + 1, cur ^ 1)
             __builtin_amdgcn_s_setprio(0);
         }
+#ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(6) }
+#endif
         const float* Wcur = smem + cur * buf_floats;
         const float* Xcur = Wcur + 66 * BM;
         if constexpr (FAST) {
@@ -348,7 +366,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
                 }
             }
         }
+#ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(7) }
+#endif
     }
 
 #undef STEGAN_LOAD_BODY

@@ -125,37 +125,6 @@ def profiler_by_shape(prof: "ConvProfiler"):
 # ---------------------------------------------------------------------------------------------
 _SPLITK_MAX = 16
 _WORKSPACES = {}
-_SIDE_STREAMS = {}
-WGRAD_SIDE_STREAM = bool(int(__import__("os").environ.get("STEGAN_WGRAD_SIDE_STREAM", "1")))
-
-
-def _side_stream(device):
-    """Second HIP stream of `device` for the weight-gradient kernels (None when the overlap is switched off)."""
-    if not WGRAD_SIDE_STREAM:
-        return None
-    st = _SIDE_STREAMS.get(device)
-    if st is None:
-        st = _SIDE_STREAMS[device] = torch.cuda.Stream(device=device)
-    return st
-
-
-def join_side_stream(device) -> None:
-    """Make the current stream wait for everything enqueued on the weight-gradient side stream."""
-    st = _SIDE_STREAMS.get(device)
-    if st is not None:
-        torch.cuda.current_stream(device).wait_stream(st)
-
-
-def _workspace(device, floats: int) -> Tensor:
-    """Split-K scratch shared by all conv launches of a (device, stream): launches are stream ordered, and the
-    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them."""
-    floats = min(floats, 1 << 27)                      # cap at 512 MiB; the kernel lowers the split to fit
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _WORKSPACES.get(key)
-    if ws is None or ws.numel() < floats:
-        ws = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)
-        _WORKSPACES[key] = ws
-    return ws
 
 
 WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
@@ -297,17 +266,7 @@ class _WNConvFn(torch.autograd.Function):
             dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
         if ctx.sink is not None and ctx.needs_input_grad[1]:
             # fused mode: accumulate the raw gradients into the network's arenas; (dv, dg) follow in ConvPack.finalize_grads.
-            # Nothing downstream of backward() needs dw before the optimiser, so the weight-gradient GEMM runs on a side
-            # stream and fills the CUs that the input-gradient kernels' tails leave idle.
-            side = _side_stream(dy.device)
-            if side is not None:
-                side.wait_event(torch.cuda.current_stream(dy.device).record_event())
-                with torch.cuda.stream(side):
-                    conv1d_bwd_weight(x, dy, cfg, ctx.sink[0], ctx.sink[1] if ctx.has_bias else None)
-                x.record_stream(side)
-                dy.record_stream(side)
-            else:
-                conv1d_bwd_weight(x, dy, cfg, ctx.sink[0], ctx.sink[1] if ctx.has_bias else None)
+            conv1d_bwd_weight(x, dy, cfg, ctx.sink[0], ctx.sink[1] if ctx.has_bias else None)
         elif ctx.needs_input_grad[1] or ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             dw = torch.zeros_like(w3)
             db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32) if ctx.has_bias else None

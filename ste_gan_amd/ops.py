@@ -127,6 +127,18 @@ _SPLITK_MAX = 16
 _WORKSPACES = {}
 
 
+def _workspace(device, floats: int) -> Tensor:
+    """Split-K scratch shared by all conv launches of a (device, stream): launches are stream ordered, and the
+    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them."""
+    floats = min(floats, 1 << 27)                      # cap at 512 MiB; the kernel lowers the split to fit
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < floats:
+        ws = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
 
 

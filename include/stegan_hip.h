@@ -263,17 +263,64 @@ int stegan_phoneme_ce_fwd_bwd(const float* logits, const int64_t* targets, int32
                               int32_t silence_index, float weight, float* loss_slot, int32_t* counters,
                               float* dlogits, int64_t* argmax_out, float* workspace, void* stream);
 
+/* ---- batch assembly ---------------------------------------------------------------------- */
+/*
+ * The corpus resident in HBM: every utterance's fields concatenated along time, with row-offset tables
+ * (n_utts + 1 entries, in rows) beside them.  Field shapes per utterance follow EMGDataset.__getitem__
+ * (ste_gan/data/emg_dataset.py:277-294): EMG (T, emg_channels) fp32, soft speech units (F, unit_dim) fp32,
+ * phoneme ids (F,) int64, MFCCs (M, mfcc_dim) fp32 (NULL when the corpus has none), session / speaking-mode
+ * indices int64 scalars.
+ */
+typedef struct stegan_corpus {
+    const float* emg;
+    const int64_t* emg_row_off;
+    const float* units;
+    const int64_t* phonemes;
+    const int64_t* frame_off;      /* shared by units and phonemes */
+    const float* mfcc;
+    const int64_t* mfcc_row_off;
+    const int64_t* session_idx;
+    const int64_t* mode_idx;
+    int32_t n_utts, emg_channels, unit_dim, mfcc_dim;
+} stegan_corpus;
+
+/*
+ * Crop-and-stack of one batch -- replaces ste_gan_collate's per-utterance slicing + torch.stack
+ * (ste_gan/data/collate.py:77-83 EMG, :124-129 units / phonemes / MFCCs, :101-102 indices) and the
+ * DataLoader worker hop in front of it (data/loader.py:66-73).  For batch row b, utterance utt[b] and
+ * window start start_frame[b] (feature frames; the host draws it as collate.py:118-121 does):
+ *   emg_out[b]      (n_emg, emg_channels)      = emg[start*hopsize : start*hopsize + n_emg]
+ *   units_out[b]    (n_frames, unit_dim)       = units[start : start + n_frames]
+ *   phonemes_out[b] (n_frames)                 = phonemes[start : start + n_frames]
+ *   mfcc_out[b]     (2*n_frames, mfcc_dim)     = mfcc[2*start : 2*start + 2*n_frames]   (skipped when NULL)
+ *   session_out[b], mode_out[b]                = the utterance's indices
+ * utt / start_frame are device int32[B].  The host must have checked that every window lies inside its
+ * utterance (the reference's torch.stack raises otherwise); the kernel never reads outside an utterance
+ * and zero-fills what a bad window would have read.
+ */
+int stegan_assemble_batch(const stegan_corpus* corpus, const int32_t* utt, const int32_t* start_frame, int32_t B,
+                          int32_t n_frames, int32_t n_emg, int32_t hopsize, float* emg_out, float* units_out,
+                          int64_t* phonemes_out, float* mfcc_out, int64_t* session_out, int64_t* mode_out,
+                          void* stream);
+
 /* ---- optimiser -------------------------------------------------------------------------------- */
 /*
  * One AdamW step (decoupled weight decay; torch.optim.AdamW single-tensor arithmetic) over a flat
  * arena of n fp32 parameters -- replaces ste_gan.OPTIMIZER(...).step() (constants.py:57, train.py:199,267).
- * hyper_dev = device float[3] {lr, 1-beta1^t, 1-beta2^t} (kept on the device so a captured graph
- * can be replayed with new values).  grads are multiplied by grad_scale first (1/world_size after a
- * sum all-reduce).  All arenas 16-byte aligned.
+ * hyper_dev = device float[4] {lr, 1-beta1^t, 1-beta2^t, t as int32 bits} (kept on the device so a
+ * captured graph can be replayed with new values).  grads are multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce).  All arenas 16-byte aligned.
  */
 int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                       const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
                       float grad_scale, void* stream);
+
+/*
+ * t += 1 and the two bias corrections 1-beta^t (evaluated in double, like torch's Python-side
+ * `1 - beta ** step`, optim/adamw.py) on the device, stream-ordered ahead of stegan_adamw_step: the host never
+ * writes step-dependent scalars, so eager steps and graph replays may queue arbitrarily far ahead.
+ */
+int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2, void* stream);
 
 /* ---- elementwise helpers of the backward pass --------------------------------------------- */
 /* dx[b,c,t] = dxe[b,c,2t] + dxe[b,c,2t+1]   (backward of nn.Upsample(scale_factor=2), conv.py:40,55) */

@@ -21,6 +21,13 @@ class ConvDesc(C.Structure):
         "upsample", "in_act", "out_act", "out_btc")]
 
 
+class Corpus(C.Structure):
+    """Mirrors struct stegan_corpus."""
+    _fields_ = [(n, C.c_void_p) for n in ("emg", "emg_row_off", "units", "phonemes", "frame_off", "mfcc", "mfcc_row_off",
+                                          "session_idx", "mode_idx")] + \
+               [(n, C.c_int32) for n in ("n_utts", "emg_channels", "unit_dim", "mfcc_dim")]
+
+
 _P = C.c_void_p
 _I32 = C.c_int32
 _I64 = C.c_int64
@@ -61,6 +68,8 @@ SIGNATURES = {
     "stegan_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float, _P],
     "stegan_add_layernorm_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stegan_adamw_step": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P],
+    "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
 }

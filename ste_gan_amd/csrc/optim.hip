@@ -5,7 +5,17 @@
 
 namespace {
 
-// hyper = {lr, 1 - beta1^t, 1 - beta2^t}
+// hyper = {lr, 1 - beta1^t, 1 - beta2^t, t (int32 bits)}.  The step counter lives on the device and is advanced by a
+// kernel, not by a host write: a stream may run many steps (or graph replays) behind the host, and an async copy from
+// a host staging word would read whatever the host has written by the time the copy executes.
+__global__ void adamw_advance_kernel(float* hyper, double beta1, double beta2) {
+    int* ti = reinterpret_cast<int*>(hyper + 3);
+    const int t = *ti + 1;
+    *ti = t;
+    hyper[1] = (float)(1.0 - pow(beta1, (double)t));
+    hyper[2] = (float)(1.0 - pow(beta2, (double)t));
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     const float* __restrict__ hyper, float beta1, float beta2,
@@ -48,6 +58,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 }  // namespace
+
+extern "C" int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2, void* stream) {
+    STEGAN_CHECK_ARG(hyper_dev && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0);
+    hipLaunchKernelGGL(adamw_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, hyper_dev, beta1, beta2);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
 
 extern "C" int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                  const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,

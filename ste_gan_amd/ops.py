@@ -633,12 +633,14 @@ _FROZEN_PREP = {}
 
 
 def frozen_prepared(w: Tensor, scale: Optional[Tensor], cfg: ConvCfg):
-    """Transposed copies of a FROZEN weight (its constant per-channel scale folded into wb), cached by identity."""
+    """Transposed copies of a FROZEN weight (its constant per-channel scale folded into wb), cached by storage address
+    + in-place version.  The entry keeps `w` and `scale` alive, so their addresses cannot be handed to another tensor
+    (a freed-and-reused address with an equal version counter would otherwise serve a stale copy)."""
     key = (w.data_ptr(), tuple(w.shape), cfg.groups, scale.data_ptr() if scale is not None else 0)
     ent = _FROZEN_PREP.get(key)
     stamp = (w._version, scale._version if scale is not None else 0)
     if ent is None or ent[0] != stamp:
-        ent = (stamp, prep_weights(w.detach(), cfg, ent[1] if ent is not None else None, scale))
+        ent = (stamp, prep_weights(w.detach(), cfg, ent[1] if ent is not None else None, scale), w, scale)
         _FROZEN_PREP[key] = ent
     return ent[1]
 

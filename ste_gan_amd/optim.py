@@ -176,8 +176,10 @@ class FusedAdamW:
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
-        self._hyper = torch.zeros(3, device=flat.flat.device, dtype=torch.float32)
-        self._hyper_host = torch.zeros(3, dtype=torch.float32).pin_memory()
+        # device {lr, 1-b1^t, 1-b2^t, t}: t and the bias corrections advance on the device (stegan_adamw_advance); the
+        # host only fills lr when it changes (a by-value fill kernel, stream ordered) and mirrors t in step_count
+        self._hyper = torch.zeros(4, device=flat.flat.device, dtype=torch.float32)
+        self._lr_on_device = None
         self.param_groups = [dict(lr=lr, betas=self.betas, eps=eps, weight_decay=weight_decay, initial_lr=lr)]
 
     def zero_grad(self, set_to_none: bool = False):
@@ -190,14 +192,30 @@ class FusedAdamW:
         if self.pack is not None:
             self.pack.finalize_grads()
 
+    def sync_lr(self):
+        """Push the current learning rate to the device if it changed (never inside a graph capture: the captured step
+        reads hyper[0], so a later change only needs this stream-ordered fill ahead of the next replay)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_on_device:
+            self._hyper[0:1].fill_(lr)
+            self._lr_on_device = lr
+
+    def _set_device_step(self, t: int):
+        self._hyper.view(torch.int32)[3:4].fill_(int(t))
+
+    def reset_state(self):
+        """Forget the moments and the step count (a freshly constructed optimiser over the same arenas)."""
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        self.step_count = 0
+        self._set_device_step(0)
+
     def stage_hyper(self):
-        """Advance the step counter and upload {lr, 1-b1^t, 1-b2^t} (async H2D from pinned memory)."""
+        """Advance the step counter and the bias corrections on the device (one tiny launch, graph-capturable)."""
         self.step_count += 1
-        lr = self.param_groups[0]["lr"]
-        self._hyper_host[0] = lr
-        self._hyper_host[1] = 1.0 - self.betas[0] ** self.step_count
-        self._hyper_host[2] = 1.0 - self.betas[1] ** self.step_count
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        check(_lib.lib().stegan_adamw_advance(C.c_void_p(self._hyper.data_ptr()), float(self.betas[0]), float(self.betas[1]),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_advance")
 
     def launch(self, grad_scale: float = 1.0):
         f = self.flat
@@ -249,6 +267,8 @@ class FusedAdamW:
         if len(steps) > 1:
             raise ValueError("FusedAdamW needs one common step count across parameters")
         self.step_count = steps.pop() if steps else 0
+        self._set_device_step(self.step_count)
+        self._lr_on_device = None
 
 
 class ExponentialLR:

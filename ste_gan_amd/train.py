@@ -173,9 +173,9 @@ class GANTrainStep:
 class GraphedTrainStep:
     """The whole train step captured once into a hipGraph and replayed per batch.
 
-    A step is ~2 900 small launches; captured, the host only refreshes the static input buffers and the three AdamW
-    scalars per optimiser (pinned host words that the captured H2D copies read at replay time) and calls one
-    ``hipGraphLaunch``.  Requirements: fixed batch shapes, single process (the RCCL exchange stays on the eager path).
+    A step is ~2 900 small launches; captured, the host only refreshes the static input buffers (and the learning rate
+    word when the scheduler changed it) and calls one ``hipGraphLaunch``; AdamW's step counter and bias corrections
+    advance inside the graph (``stegan_adamw_advance``), so replays can queue arbitrarily far ahead of the GPU.  Requirements: fixed batch shapes, single process (the RCCL exchange stays on the eager path).
     """
 
     def __init__(self, step: GANTrainStep, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
@@ -202,10 +202,8 @@ class GraphedTrainStep:
         self.last = self.out
 
     def _stage(self, opt: FusedAdamW):
-        opt.step_count += 1
-        opt._hyper_host[0] = opt.param_groups[0]["lr"]
-        opt._hyper_host[1] = 1.0 - opt.betas[0] ** opt.step_count
-        opt._hyper_host[2] = 1.0 - opt.betas[1] ** opt.step_count
+        opt.step_count += 1          # host mirror of the device-side counter the captured advance kernel increments
+        opt.sync_lr()
 
     def __call__(self, batch_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         for k, v in batch_dict.items():

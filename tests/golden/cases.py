@@ -48,6 +48,38 @@ ENC_CASES = {
 # B=2 T_su=4, had one generator activation at 1.6e-7 and was rejected for that reason)
 STEP_CASES = {"step_c48_b3": (48, (64, 2, 128), 3, 5, 2)}
 
+# ---- batch-assembly cases (data/collate.py): name -> (frames per utterance, extra EMG samples past 16*frames,
+#      emg_train_length, n_mfcc, torch seed).  chunk 200 is not a multiple of the hop: the reference crops 12 frames but
+#      200 samples, which only stacks when the drawn window fits, hence the 8 extra samples (a non-strict corpus).
+COLLATE_CASES = {
+    "collate_c200": ((40, 13, 97, 12, 64, 30, 21), 8, 200, 25, 1234),
+    "collate_c2048": ((130, 128, 400, 251), 0, 2048, 25, 7),             # the reference default chunk
+}
+
+
+def poscheck(t):
+    """Checksum that moves when any element changes or shifts: float64 [sum, sum(x*w), sum(x*x)], w = 1 + (i mod 8191)/8191."""
+    import numpy as np
+    x = np.asarray(t, dtype=np.float64).reshape(-1)
+    w = 1.0 + (np.arange(x.size) % 8191) / 8191.0
+    return np.array([x.sum(), (x * w).sum(), (x * x).sum()])
+
+
+def collate_samples(name):
+    """Synthetic utterances shaped like EMGDataset.__getitem__ output (data/emg_dataset.py:277-294); keys are the
+    DataType strings (constants.py:192-239)."""
+    frames, extra, _, n_mfcc, _ = COLLATE_CASES[name]
+    out = []
+    for i, f in enumerate(frames):
+        tag = f"{name}.u{i}"
+        out.append({"REAL_EMG": det_input(tag + ".emg", (16 * f + extra, 8), "tanh"),
+                    "SPEECH_UNITS": det_input(tag + ".su", (f, 256)),
+                    "PHONEMES": det_ints(tag + ".ph", (f,), 48),
+                    "SESSION_INDEX": det_ints(tag + ".sess", (1,), 17)[0],
+                    "SPEAKING_MODE_IDX": det_ints(tag + ".spk", (1,), 3)[0],
+                    "MFCCS": det_input(tag + ".mfcc", (2 * f, n_mfcc))})
+    return out
+
 
 def gen_inputs(name):
     ft, ch, B, T = GEN_CASES[name]

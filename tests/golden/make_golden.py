@@ -238,9 +238,27 @@ def step_cases():
         save(name, **rec)
 
 
+def collate_cases():
+    """ste_gan_collate (data/collate.py:22-61) on synthetic utterances: the train partition under a fixed torch seed
+    (its start frames come from the global torch RNG, collate.py:118-121), and the valid partition."""
+    from ste_gan.data.collate import ste_gan_collate
+    for name, (frames, extra, emg_len, n_mfcc, seed) in cases.COLLATE_CASES.items():
+        rec = {}
+        for part in ("train", "valid"):
+            torch.manual_seed(seed)
+            out = ste_gan_collate(cases.collate_samples(name), partition=part, emg_train_length=emg_len,
+                                  chunksize=emg_len, hopsize=ste_gan.HOPSIZE)
+            for k, v in out.items():
+                # large float outputs are kept as a position-weighted checksum (cases.poscheck) to keep fixtures small
+                big = v.is_floating_point() and v.numel() > 50_000
+                rec[f"{part}.{k}" + (".poscheck" if big else "")] = cases.poscheck(v) if big else v.numpy()
+        save(name, **rec)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen", "disc", "td", "enc", "step"]
+    which = sys.argv[1:] or ["gen", "disc", "td", "enc", "step", "collate"]
     for w in which:
-        {"gen": gen_cases, "disc": disc_cases, "td": td_cases, "enc": enc_cases, "step": step_cases}[w]()
+        {"gen": gen_cases, "disc": disc_cases, "td": td_cases, "enc": enc_cases, "step": step_cases,
+         "collate": collate_cases}[w]()
     leaked = [os.path.join(dp, d) for dp, dn, _ in os.walk("/root/reference") for d in dn if d == "__pycache__"]
     assert not leaked, f"__pycache__ written into the reference tree: {leaked}"

@@ -1,0 +1,168 @@
+"""Loaders over a device-resident corpus -- the role of ``ste_gan/data/loader.py`` without DataLoader workers.
+
+``loaders(...)`` / ``loaders_via_config(cfg)`` keep the reference's signatures (loader.py:19-29,92-109) and return three
+iterables whose batches are the reference's ``DataType``-keyed dicts (collate.py:54-61), already on the GPU:
+
+* train: a fresh random permutation per epoch (``RandomSampler``), random window per utterance (collate.py:118-121);
+* valid: sequential, windows at frame 0 (collate.py:135-145);
+* test : sequential, whole utterances at batch size 1 (collate.py:148-155), served as views of the resident arenas.
+
+An epoch's (utterance, start frame) plan is drawn on the host in one go, validated against the stored lengths and
+uploaded once; each batch is then a single ``stegan_assemble_batch`` launch reading its slice of the plan, so the
+steady state has no per-batch host->device copy and nothing to pickle.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import torch
+
+from .. import constants as K
+from ..constants import DataDir, DataType, SpeakingMode
+from .collate import UtteranceStore, check_partition, draw_start_frames
+
+
+class DeviceLoader:
+    """Iterable over one partition of a resident corpus (``len()`` = batches per epoch, like a DataLoader)."""
+
+    def __init__(self, store: UtteranceStore, partition: str, batch_size: int, emg_train_length: int,
+                 hopsize: int = K.HOPSIZE, hop_aligned_emg: bool = False):
+        check_partition(partition)
+        if batch_size < 1:
+            raise ValueError(f"batch_size should be a positive integer value, but got batch_size={batch_size}")
+        self.store, self.partition, self.hopsize = store, partition, hopsize
+        self.batch_size = 1 if partition == "test" else batch_size
+        self.n_frames = emg_train_length // hopsize                        # collate.py:44
+        # the reference crops emg_train_length samples even when that is not a multiple of the hop (chunk 200 -> 12
+        # frames but 200 samples); hop_aligned_emg crops n_frames * hopsize instead, which is what the generator emits
+        self.n_emg = self.n_frames * hopsize if hop_aligned_emg else emg_train_length
+
+    def __len__(self) -> int:
+        return (len(self.store) + self.batch_size - 1) // self.batch_size   # DataLoader default drop_last=False
+
+    def epoch_plan(self):
+        """Host lists (utterance order, start frames) for one epoch, in the RNG order of sampler then collate."""
+        n = len(self.store)
+        if self.partition == "train":
+            order = torch.randperm(n).tolist()                             # RandomSampler (loader.py:50)
+            starts: List[int] = []
+            for i in range(0, n, self.batch_size):                         # one collate call per batch
+                starts += draw_start_frames([self.store.frames[u] for u in order[i:i + self.batch_size]], self.n_frames)
+        else:
+            order, starts = list(range(n)), [0] * n
+        return order, starts
+
+    def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
+        st = self.store
+        if self.partition == "test":
+            for u in range(len(st)):
+                yield st.whole_utterance(u)
+            return
+        order, starts = self.epoch_plan()
+        st.check_windows(order, starts, self.n_frames, self.n_emg, self.hopsize)
+        plan = torch.tensor([order, starts], dtype=torch.int32).to(st.device)
+        for i in range(0, len(order), self.batch_size):
+            yield st.assemble(plan[0, i:i + self.batch_size], plan[1, i:i + self.batch_size], self.n_frames, self.n_emg,
+                              self.hopsize, validate=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# corpus directory -> per-utterance sample dicts (host I/O, once at start-up)
+# ---------------------------------------------------------------------------------------------
+def _utt_session(utt_id: str) -> str:
+    return utt_id.split("__")[0]                                           # emg_dataset.py:187-189
+
+
+def _utt_mode(utt_id: str) -> str:
+    return utt_id.split("__")[-1]                                          # emg_dataset.py:191-193
+
+
+def _file_id(stem: str, prefix: str = "emg_synth__") -> str:
+    return stem.split(prefix)[1] if stem.startswith(prefix) else stem      # emg_dataset.py:195-200
+
+
+def read_partition(root_dir: Path, partition: str, session_id_to_idx: Optional[Dict] = None,
+                   speaking_mode_id_to_idx: Optional[Dict] = None, only_include_voiced: bool = True,
+                   only_include_silent: bool = False, filter_by_length: bool = True, strict: bool = False,
+                   train_emg_length: int = K.TRAIN_EMG_LENGTH):
+    """Read ``<root>/<partition>/{emg,units,phonemes,mfccs}/*.pt`` the way ``EMGDataset`` selects and labels utterances
+    (emg_dataset.py:50-151,229-294): sorted EMG paths; short utterances dropped unless testing; speaking-mode filter;
+    session / speaking-mode ids from the ``{session}__...__{mode}`` utterance id, indexed in sorted order unless the
+    train partition's mappings are handed in.  Returns (samples, session_id_to_idx, speaking_mode_id_to_idx, utt_ids).
+    """
+    check_partition(partition)
+    assert not (only_include_silent and only_include_voiced), \
+        "Either only_include_silent or only_include_voiced can be True."
+    split = Path(root_dir) / partition
+    is_test = partition == "test"
+    samples, utt_ids = [], []
+    n_filtered = 0
+    for emg_path in sorted((split / DataDir.EMG).glob("*.pt")):
+        emg = torch.load(emg_path)
+        utt_id = emg_path.stem
+        silent = _utt_mode(utt_id) != SpeakingMode.NORMAL
+        if (filter_by_length and len(emg) < train_emg_length and not is_test) or (only_include_voiced and silent) \
+                or (only_include_silent and not silent):
+            n_filtered += 1
+            continue
+        fid = _file_id(utt_id)
+        units = torch.load(split / DataDir.SPEECH_UNITS / f"{fid}.pt")
+        phonemes = torch.load(split / DataDir.PHONEMES / f"{fid}.pt")
+        mfcc_path = split / DataDir.MFCCS / f"{utt_id}.pt"
+        mfccs = torch.load(mfcc_path) if mfcc_path.exists() else None
+        if strict:                                                         # emg_dataset.py:254-261
+            assert len(units) == len(phonemes)
+            assert len(emg) == K.HOPSIZE * len(units)
+        samples.append({DataType.UTT_ID: utt_id, DataType.REAL_EMG: emg, DataType.SPEECH_UNITS: units,
+                        DataType.PHONEMES: phonemes, DataType.MFCCS: mfccs,
+                        DataType.SESSION_ID: _utt_session(utt_id), DataType.SPEAKING_MODE_ID: _utt_mode(utt_id)})
+        utt_ids.append(utt_id)
+    logging.info(f"Filtered {n_filtered} EMG paths for partition {partition}; kept {len(samples)}.")
+    if not session_id_to_idx:
+        session_id_to_idx = {s: i for i, s in enumerate(sorted({x[DataType.SESSION_ID] for x in samples}))}
+    if not speaking_mode_id_to_idx:
+        speaking_mode_id_to_idx = {m: i for i, m in enumerate(sorted({x[DataType.SPEAKING_MODE_ID] for x in samples}))}
+    for x in samples:
+        x[DataType.SESSION_INDEX] = torch.tensor(session_id_to_idx[x[DataType.SESSION_ID]])
+        x[DataType.SPEAKING_MODE_INDEX] = torch.tensor(speaking_mode_id_to_idx[x[DataType.SPEAKING_MODE_ID]])
+    return samples, session_id_to_idx, speaking_mode_id_to_idx, utt_ids
+
+
+def check_no_data_overlap(utt_id_lists: Sequence[Sequence[str]]) -> None:
+    """emg_dataset.py:220-226."""
+    seen = set()
+    for ids in utt_id_lists:
+        inter = seen & set(ids)
+        if inter:
+            raise ValueError(f"Intersecting utterance ids: {','.join(sorted(inter))}")
+        seen |= set(ids)
+
+
+def loaders_from_samples(train_samples, valid_samples, test_samples, batch_size: int = K.BATCH_SIZE,
+                         train_emg_length: int = K.TRAIN_EMG_LENGTH, hopsize: int = K.HOPSIZE, device="cuda",
+                         hop_aligned_emg: bool = False):
+    """(train, valid, test) DeviceLoaders over three lists of sample dicts (each uploaded once)."""
+    mk = lambda samples, part: DeviceLoader(UtteranceStore(samples, device), part, batch_size, train_emg_length, hopsize,
+                                            hop_aligned_emg)
+    return mk(train_samples, "train"), mk(valid_samples, "valid"), mk(test_samples, "test")
+
+
+def loaders(data_root: Path, strict=False, chunksize: int = K.CHUNK_SIZE, hopsize: int = K.HOPSIZE,
+            train_emg_length: int = K.TRAIN_EMG_LENGTH, batch_size: int = K.BATCH_SIZE, device="cuda",
+            hop_aligned_emg: bool = False):
+    """loader.py:19-90 over resident stores."""
+    tr, s2i, m2i, tr_ids = read_partition(data_root, "train", strict=strict, train_emg_length=train_emg_length)
+    va, _, _, va_ids = read_partition(data_root, "valid", s2i, m2i, strict=strict, train_emg_length=train_emg_length)
+    te, _, _, te_ids = read_partition(data_root, "test", s2i, m2i, filter_by_length=False, strict=strict,
+                                      train_emg_length=train_emg_length)
+    check_no_data_overlap([tr_ids, va_ids, te_ids])
+    return loaders_from_samples(tr, va, te, batch_size, train_emg_length, hopsize, device, hop_aligned_emg)
+
+
+def loaders_via_config(cfg, device="cuda"):
+    """loader.py:92-109 (``train_emg_length = chunk_size``: no autoregressive extra input)."""
+    chunksize = cfg.train.chunk_size
+    return loaders(data_root=Path(cfg.data.dataset_root), strict=cfg.data.strict, chunksize=chunksize, hopsize=K.HOPSIZE,
+                   train_emg_length=chunksize, batch_size=cfg.train.batch_size, device=device)

@@ -85,6 +85,7 @@ class DiscriminatorSmallerS(_ScaleDisc):
     def __init__(self, num_emg_channels, norm="weight_norm", name="DiscriminatorS"):
         super().__init__()
         self.name = name
+        self.norm = norm
         self.num_emg_channels = num_emg_channels
         self.layers = nn.ModuleList([
             NormedConv1d(num_emg_channels, 128, 15, 1, padding=7, norm=norm, out_act=ACT_LRELU),
@@ -100,6 +101,7 @@ class DiscriminatorS(_ScaleDisc):
     def __init__(self, num_emg_channels, norm="weight_norm", name="DiscriminatorS"):
         super().__init__()
         self.name = name
+        self.norm = norm
         self.num_emg_channels = num_emg_channels
         self.layers = nn.ModuleList([
             NormedConv1d(num_emg_channels, 128, 15, 1, padding=7, norm=norm, out_act=ACT_LRELU),
@@ -138,6 +140,29 @@ class _MultiDisc(nn.Module):
             results.append(disc(xs))
             xs = ops.avgpool421(xs)            # the reference also pools once more after the last scale
         return results
+
+    def forward_pair(self, x_a, x_b):
+        """``(self(x_a), self(x_b))`` -- the discriminator step's fake and real passes (train.py:190-191) -- with every
+        stateless sub-discriminator run ONCE on the concatenated batch (same per-sample arithmetic, half the launches,
+        fuller grids on the short late layers).  The spectral-norm scale discriminator stays two calls in the
+        reference's order: in training mode each of its forwards advances the power iteration, so its two halves see
+        different sigma estimates."""
+        n = x_a.shape[0]
+        both = torch.cat([x_a, x_b], 0)
+        res_a, res_b = [], []
+        for disc in self.multi_pooled_disc:
+            fm = disc(both)
+            res_a.append([f[:n] for f in fm]); res_b.append([f[n:] for f in fm])
+        xs = ops.btc_to_bct(both)
+        for i, disc in enumerate(self.multi_scale_disc):
+            if disc.norm == "spectral_norm":
+                res_a.append(disc(xs[:n])); res_b.append(disc(xs[n:]))      # batch-major: the halves are contiguous views
+            else:
+                fm = disc(xs)
+                res_a.append([f[:n] for f in fm]); res_b.append([f[n:] for f in fm])
+            if i + 1 < len(self.multi_scale_disc):
+                xs = ops.avgpool421(xs)
+        return res_a, res_b
 
 
 class DiscriminatorSmall(_MultiDisc):

@@ -93,8 +93,7 @@ class GANTrainStep:
         # ---- discriminator step (train.py:189-199)
         d_handle = None
         if t.loss_adversarial:
-            D_fake_det = netD(x_pred_t.detach())
-            D_real = netD(x_t)
+            D_fake_det, D_real = netD.forward_pair(x_pred_t.detach(), x_t)          # train.py:190-191, batched
             loss_D = lsgan_loss(D_fake_det, 0.0) + lsgan_loss(D_real, 1.0)
             loss_D.backward()
             self.optD.finalize_grads()

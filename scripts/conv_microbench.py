@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ste_gan_amd import ops
-B = 64
+B = int(os.environ.get("MB_B", "64"))
 # (name, Cin, Cout, K, stride, dil, pad, groups, up, relu, Tin, Beff)
 LAYERS = [
     ("G 768->768 k3 d1 T12", 768, 768, 3, 1, 1, 1, 1, 1, True, 12, B),

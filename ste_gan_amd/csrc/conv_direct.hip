@@ -82,6 +82,12 @@ __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, in
     }
 }
 
+// max(x, floor) as ONE VALU op (fmaxf also canonicalises both inputs): median(x, floor, +inf); floor = 0 (ReLU) or
+// -inf (identity)
+__device__ __forceinline__ float relu_max(float x, float floor_) {
+    return __builtin_amdgcn_fmed3f(x, floor_, INFINITY);
+}
+
 // sums the split-K partials and applies the fused epilogue; one thread per output element (t fastest)
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const DirP p) {
     const long total = (long)p.B * p.Cdst * p.Tdst;
@@ -302,7 +308,11 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(4) }
 #endif
+#ifdef STEGAN_EXP_NODMA
+        if (false) {
+#else
         if (c + 1 < c_end) {
+#endif
             // the short DMA-issue phase runs at raised priority so it is not starved by the co-resident waves' MFMA
             // streams (they keep the matrix pipe busy meanwhile)
             __builtin_amdgcn_s_setprio(2);
@@ -322,36 +332,51 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
             int colb2[TN];
 #pragma unroll
             for (int j = 0; j < TN; ++j) colb2[j] = colbase[j] + half * p.XROW;
+            // Operands are kept RAW in registers and the ReLU floor is applied at the point of use, one body (4 MFMAs,
+            // >= 256 matrix-pipe cycles) after the ds_reads were issued: the wait for them is then free.  (Applying it
+            // right behind the loads made hipcc drain lgkmcnt(0) in front of every MFMA -- the LDS latency of each
+            // step was exposed.)  The loop is peeled so its steady state carries no branches.
             float a0[4][TM], b0[4][TN], a1[4][TM], b1[4][TN];
 #define STEGAN_FAST_LOAD(a_, b_, r2_, k_)                                                                      \
             {                                                                                                  \
                 const int xb_ = ((r2_) & (CC - 1)) * p.XROW + ((r2_) >> p.logCC) * tp.step + 2 * (k_) * p.XROW; \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[k_][i] = abase[((r2_) + 2 * (k_)) * BM + i * 32]; \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = fmaxf(Xcur[xb_ + colb2[j]], relu_floor); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k_][j] = Xcur[xb_ + colb2[j]];               \
             }
 #define STEGAN_FAST_MFMA(a_, b_, k_)                                                                           \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k_][i], b_[k_][j], acc[i][j], 0, 0, 0);
+            {                                                                                                  \
+                float bb_[TN];                                                                                 \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) bb_[j] = relu_max(b_[k_][j], relu_floor);       \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                 \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                             \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k_][i], bb_[j], acc[i][j], 0, 0, 0); \
+            }
+#define STEGAN_FAST_STEP(an_, bn_, rn_, ac_, bc_)                                                              \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                    \
+                STEGAN_FAST_LOAD(an_, bn_, rn_, k)                                                             \
+                STEGAN_FAST_MFMA(ac_, bc_, k)                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
+            }
+#define STEGAN_FAST_LAST(ac_, bc_)                                                                             \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                    \
+                STEGAN_FAST_MFMA(ac_, bc_, k)                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                             \
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) STEGAN_FAST_LOAD(a0, b0, 0, k)
-            for (int r2 = 0; r2 < RC; r2 += 16) {
-                const bool has1 = r2 + 8 < RC, has2 = r2 + 16 < RC;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (has1) STEGAN_FAST_LOAD(a1, b1, r2 + 8, k)
-                    STEGAN_FAST_MFMA(a0, b0, k)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (has1) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (has2) STEGAN_FAST_LOAD(a0, b0, r2 + 16, k)
-                        STEGAN_FAST_MFMA(a1, b1, k)
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+            int r2 = 0;
+            for (; r2 + 16 < RC; r2 += 16) {
+                STEGAN_FAST_STEP(a1, b1, r2 + 8, a0, b0)
+                STEGAN_FAST_STEP(a0, b0, r2 + 16, a1, b1)
             }
+            if (r2 + 8 < RC) {
+                STEGAN_FAST_STEP(a1, b1, r2 + 8, a0, b0)
+                STEGAN_FAST_LAST(a1, b1)
+            } else {
+                STEGAN_FAST_LAST(a0, b0)
+            }
+#undef STEGAN_FAST_STEP
+#undef STEGAN_FAST_LAST
 #undef STEGAN_FAST_LOAD
 #undef STEGAN_FAST_MFMA
         } else {

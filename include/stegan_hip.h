@@ -90,6 +90,15 @@ int stegan_conv1d_bwd_data(const stegan_conv_desc* d, const float* dy, const flo
  */
 int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
                              float* db, void* stream);
+/*
+ * Same contract with a caller-owned workspace: the reduction over (batch, time) is cut into batch slices that write
+ * their partial dw to slabs of `workspace` with plain stores, and a second kernel adds the slabs into dw in a fixed
+ * order (deterministic, and far cheaper than float atomics, which cost one memory transaction per element).
+ * Cout * Cin/groups * K floats per slice; any size works (a short workspace means fewer, longer slices; NULL / too
+ * small for one slab falls back to the atomic path above).
+ */
+int stegan_conv1d_bwd_weight_ws(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                float* workspace, int64_t workspace_floats, void* stream);
 
 /*
  * Fast path of stegan_conv1d_fwd / stegan_conv1d_bwd_data (same semantics, same descriptors): the direct

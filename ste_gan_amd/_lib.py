@@ -40,6 +40,7 @@ SIGNATURES = {
     "stegan_conv1d_fwd": [_D, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data": [_D, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_weight": [_D, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_weight_ws": [_D, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv_prep": [_D, _P, _P, _P, _P, _P],
     "stegan_conv_prep_multi": [_I32, _P, _I32, _P],
     "stegan_conv1d_fwd_t": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],

@@ -57,3 +57,7 @@ __device__ static inline float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// conv_wgrad.hip: direct weight-gradient kernel; returns 1 when the caller should use the generic implicit GEMM
+int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                        float* workspace, int64_t workspace_floats, hipStream_t stream);

@@ -382,17 +382,29 @@ extern "C" int stegan_conv1d_bwd_data(const stegan_conv_desc* d, const float* dy
     return launch<MODE_BWD_DATA>(p, d->groups, 1, (hipStream_t)stream);
 }
 
-extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
-                                        float* db, void* stream) {
+static int bwd_weight_impl(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                           float* workspace, int64_t workspace_floats, void* stream) {
     ConvK p;
     int rc = fill_common(d, p);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
+    rc = stegan_wgrad_direct(d, x, dy, dw, db, workspace, workspace_floats, (hipStream_t)stream);
+    if (rc != 1) return rc;
     p.x = x; p.dy = dy; p.out = dw; p.db = db;
     p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout;
     p.fdT = make_fastdiv((uint32_t)d->Tout);
     const int splits = bwd_weight_splits(p, d->groups);
     return launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                        float* db, void* stream) {
+    return bwd_weight_impl(d, x, dy, dw, db, nullptr, 0, stream);
+}
+
+extern "C" int stegan_conv1d_bwd_weight_ws(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                           float* db, float* workspace, int64_t workspace_floats, void* stream) {
+    return bwd_weight_impl(d, x, dy, dw, db, workspace, workspace_floats, stream);
 }
 
 extern "C" int stegan_conv1d_plan(const stegan_conv_desc* d, int32_t mode, int32_t* tile, int32_t* splits,

@@ -101,6 +101,8 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     name, nominal, live = PROFILER.plan(d, mode)
     if kind == "direct":
         name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
+    elif mode == 2:
+        name = "bwd_weight (conv_wgrad_kernel | conv_igemm_kernel<2>)"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = fn()
@@ -218,8 +220,10 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     """Accumulates into dw (and db)."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
-    check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _stream())),
-          "stegan_conv1d_bwd_weight")
+    ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
+    check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                                                      ws.numel(), _stream())),
+          "stegan_conv1d_bwd_weight_ws")
 
 
 def wn_scale(v: Tensor, g: Tensor) -> Tensor:

@@ -28,7 +28,7 @@
 namespace {
 
 constexpr int MAX_TAPS = 48;
-constexpr int XE = 8;            // X-tile elements staged per thread and chunk: CC * XROW <= 256 * XE
+constexpr int XE = 16;           // X-tile elements staged per thread and chunk: CC * XROW <= 256 * XE
 constexpr int WE = 4;            // W-tile float4 per thread and chunk: RC * 16 <= 256 * WE
 constexpr int BM2 = 64;
 
@@ -51,6 +51,7 @@ struct DirP {
     int in_relu, out_act, out_btc;
     int m_tiles, CC, logCC;
     int SEG, NSEG, XROW;
+    int WR;                             // W-tile rows held in LDS per buffer (>= taps * CC of any phase, multiple of 8)
     int U0;                             // columns per batch element for phase 0 (max over phases)
     int splits, chunks_per_split;       // split-K over channel chunks: grid.z = phase*splits + split
     float* partial;                     // splits > 1: raw accumulators [split][B*Cdst*Tdst], epilogue runs separately
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BM = 64 * TM;                 // 2x2 waves, wave tile (32*TM) x (32*TN)
     constexpr int WEt = WE * TM;                // W-tile float4 per thread and chunk
     constexpr int WROW4 = 16 * TM;              // float4 per W row
-    extern __shared__ __align__(16) float smem[];      // Ws[66*64] | Xs[CC*XROW]
+    extern __shared__ __align__(16) float smem[];      // 2 x { Ws[WR*BM] | Xs[CC*XROW] }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef STEGAN_STAMPS
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         const int c0_ = (c_) * CC;                                                                             \
         const int lim_ = p.C2_g - c0_;                                                                         \
         float* Wd_ = smem + (buf_) * buf_floats;                                                               \
-        float* Xd_ = Wd_ + 66 * BM;                                                                            \
+        float* Xd_ = Wd_ + p.WR * BM;                                                                          \
         const float* wc_ = wt_g + (size_t)c0_ * p.LD;                                                          \
         _Pragma("unroll") for (int i = 0; i < WEt; ++i) {                                                      \
             const int idx = tid + 256 * i;                                                                     \
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 
     // Two LDS buffers, ONE barrier per chunk: the DMA of chunk c+1 is issued right behind the barrier and stays in
     // flight while the matrix cores run over chunk c (LDS reads of the next 4-MFMA body interleaved with the MFMAs).
-    const int buf_floats = 66 * BM + CC * p.XROW;
+    const int buf_floats = p.WR * BM + CC * p.XROW;
     STAMP(1)
     if (c_begin < c_end) STEGAN_DMA_CHUNK(c_begin, 0)
     STAMP(2)
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         if (c == c_begin + 3) { STAMP(6) }
 #endif
         const float* Wcur = smem + cur * buf_floats;
-        const float* Xcur = Wcur + 66 * BM;
+        const float* Xcur = Wcur + p.WR * BM;
         if constexpr (FAST) {
             // Fast path (host guarantees CC >= 8) (K_eff*CC is a multiple of 8, a body of 8 rows never straddles a tap): the B address is
             // colb2 + scalar, the A address abase + immediate.  Loads of the NEXT body are interleaved one row pair at
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepEntry* _
 
 inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-struct Geo { int CC, logCC, SEG, NSEG, XROW, BN; size_t lds; bool ok; };
+struct Geo { int CC, logCC, SEG, NSEG, XROW, BN, WR; size_t lds; bool ok; };
 
 // geometry for one launch; ntaps_max bounds the taps of any phase
 Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks, bool xvec) {
@@ -571,7 +572,8 @@ Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long
         int CC = 32;
         while (CC > 1 && (ntaps_max * CC > 64 || CC * XROW > 256 * XE)) CC >>= 1;
         if (CC * XROW > 256 * XE) continue;
-        const size_t lds = 2 * ((size_t)66 * 64 * 4 + (size_t)CC * XROW * 4);
+        const int WR = round_up(ntaps_max * CC, 8);
+        const size_t lds = 2 * ((size_t)WR * 64 * 4 + (size_t)CC * XROW * 4);
         const long blocks = (N + BN - 1) / BN;
         static const char* env128 = getenv("STEGAN_BN128_MIN_BLOCKS");
         const long min128 = env128 ? atol(env128) : 768;
@@ -579,7 +581,7 @@ Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long
             gm.CC = CC;
             gm.logCC = 0;
             while ((1 << gm.logCC) < CC) ++gm.logCC;
-            gm.SEG = SEG; gm.NSEG = NSEG; gm.XROW = XROW; gm.BN = BN; gm.lds = lds; gm.ok = true;
+            gm.SEG = SEG; gm.NSEG = NSEG; gm.XROW = XROW; gm.BN = BN; gm.WR = WR; gm.lds = lds; gm.ok = true;
             return gm;
         }
     }
@@ -700,7 +702,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
                       !getenv("STEGAN_NO_XVEC");
     Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
     if (!gm.ok) return 1;
-    p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.U0 = U;
+    p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.WR = gm.WR; p.U0 = U;
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
     const long nb = (N + gm.BN - 1) / gm.BN;
@@ -719,7 +721,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         const int s2 = choose_splits(nb * (p.M_g / 128) * d->groups * phases, nchunks, 1.7, &cost2);
         tm = 2; splits = s2;
     }
-    if (tm == 2) gm.lds = 2 * ((size_t)66 * 128 * 4 + (size_t)gm.CC * gm.XROW * 4);
+    if (tm == 2) gm.lds = 2 * ((size_t)gm.WR * 128 * 4 + (size_t)gm.CC * gm.XROW * 4);
     p.m_tiles = ceil_div(p.M_g, 64 * tm);
     const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
     if (splits > 1 && (!workspace || workspace_floats < out_elems * splits)) {

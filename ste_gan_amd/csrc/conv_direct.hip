@@ -89,15 +89,43 @@ __device__ __forceinline__ float relu_max(float x, float floor_) {
     return __builtin_amdgcn_fmed3f(x, floor_, INFINITY);
 }
 
-// sums the split-K partials and applies the fused epilogue; one thread per output element (t fastest)
+// sums the split-K partials and applies the fused epilogue; HBM-bound: a thread takes 4 consecutive outputs (t fastest)
+// with 16-byte loads from every slab, all slabs' loads issued before the first add
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const DirP p) {
-    const long total = (long)p.B * p.Cdst * p.Tdst;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const uint32_t total = (uint32_t)p.B * p.Cdst * p.Tdst;           // < 2^31, checked on the host
+    if ((p.Tdst & 3) == 0) {
+        const uint32_t total4 = total >> 2;
+        for (uint32_t i4 = blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += gridDim.x * 256) {
+            const float4* src = reinterpret_cast<const float4*>(p.partial) + i4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = 0;
+            for (; s + 4 <= p.splits; s += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = src[(size_t)(s + u) * total4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+            }
+            for (; s < p.splits; ++s) {
+                const float4 t = src[(size_t)s * total4];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const uint32_t i = i4 << 2;
+            const uint32_t r = i / (uint32_t)p.Tdst, to = i - r * p.Tdst;
+            const uint32_t b = r / (uint32_t)p.Cdst, ch = r - b * p.Cdst;
+            epilogue_store(p, v.x, (int)b, (int)ch, (int)to);
+            epilogue_store(p, v.y, (int)b, (int)ch, (int)to + 1);
+            epilogue_store(p, v.z, (int)b, (int)ch, (int)to + 2);
+            epilogue_store(p, v.w, (int)b, (int)ch, (int)to + 3);
+        }
+        return;
+    }
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < p.splits; ++s) v += p.partial[(size_t)s * total + i];
-        const int to = (int)(i % p.Tdst);
-        const long r = i / p.Tdst;
-        epilogue_store(p, v, (int)(r / p.Cdst), (int)(r % p.Cdst), to);
+        const uint32_t r = i / (uint32_t)p.Tdst, to = i - r * p.Tdst;
+        const uint32_t b = r / (uint32_t)p.Cdst, ch = r - b * p.Cdst;
+        epilogue_store(p, v, (int)b, (int)ch, (int)to);
     }
 }
 
@@ -757,7 +785,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
 #undef STEGAN_LAUNCH
     if (p.splits > 1) {
-        long eb = (out_elems + 255) / 256;
+        long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;
         if (eb > 4096) eb = 4096;
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)eb), dim3(256), 0, s, p);
     }

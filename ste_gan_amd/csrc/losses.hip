@@ -16,10 +16,25 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 // mode 0: L1 |a-b|, mode 1: MSE (a-b)^2;  b == nullptr -> constant target
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         float target, long n, int mode, float w_over_n,
-                                                        float* __restrict__ loss_slot, float* __restrict__ da) {
+                                                        float* __restrict__ loss_slot, float* __restrict__ da, int vec) {
     __shared__ float red[4];
     float s = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    // HBM-bound (read a, b; write da): 16 bytes per lane when the three arrays are 16-byte aligned
+    const long n4 = vec ? (n >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 av = reinterpret_cast<const float4*>(a)[i];
+        float4 bv = make_float4(target, target, target, target);
+        if (b) bv = reinterpret_cast<const float4*>(b)[i];
+        const float d[4] = {av.x - bv.x, av.y - bv.y, av.z - bv.z, av.w - bv.w};
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (mode == 0) { s += fabsf(d[k]); g[k] = d[k] > 0.f ? w_over_n : (d[k] < 0.f ? -w_over_n : 0.f); }
+            else { s += d[k] * d[k]; g[k] = 2.f * d[k] * w_over_n; }
+        }
+        if (da) reinterpret_cast<float4*>(da)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float d = a[i] - (b ? b[i] : target);
         if (mode == 0) {
             s += fabsf(d);
@@ -274,8 +289,9 @@ inline int nblk(long n) {
 extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64_t n, int32_t mode,
                                         float weight, float* loss_slot, float* da, void* stream) {
     STEGAN_CHECK_ARG(a && n > 0 && (mode == 0 || mode == 1));
-    hipLaunchKernelGGL(pair_loss_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, target, (long)n, mode,
-                       weight / (float)n, loss_slot, da);
+    const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) % 16) == 0;
+    hipLaunchKernelGGL(pair_loss_kernel, dim3(nblk(vec ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, target,
+                       (long)n, mode, weight / (float)n, loss_slot, da, vec);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

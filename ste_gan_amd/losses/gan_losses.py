@@ -9,18 +9,14 @@ from __future__ import annotations
 from .. import ops
 
 
-def lsgan_loss(d_out, target: float):
-    """sum over the 8 sub-discriminators of mse(logits, target) -- train.py:192-196 (0 / 1), :209-211 (1)."""
-    loss = 0
-    for scale in d_out:
-        loss = loss + ops.mse_to_const(scale[-1], target)
-    return loss
+def lsgan_loss(d_out, target: float, weight: float = 1.0, unit_grad: bool = False):
+    """weight * sum over the 8 sub-discriminators of mse(logits, target) -- train.py:192-196 (0 / 1), :209-211 (1).
+    One autograd node for the whole sum (``ops.multi_pair_loss``); see there for ``unit_grad``."""
+    return ops.multi_pair_loss([scale[-1] for scale in d_out], None, 1, weight, target=float(target), unit_grad=unit_grad)
 
 
-def feature_matching_loss(d_fake, d_real):
-    """sum_i sum_{j<last} l1(D_fake[i][j], D_real[i][j].detach()) -- train.py:257-262."""
-    loss = 0
-    for i in range(len(d_fake)):
-        for j in range(len(d_fake[i]) - 1):
-            loss = loss + ops.l1_loss(d_fake[i][j], d_real[i][j])
-    return loss
+def feature_matching_loss(d_fake, d_real, weight: float = 1.0, unit_grad: bool = False):
+    """weight * sum_i sum_{j<last} l1(D_fake[i][j], D_real[i][j].detach()) -- train.py:257-262."""
+    fake = [d_fake[i][j] for i in range(len(d_fake)) for j in range(len(d_fake[i]) - 1)]
+    real = [d_real[i][j] for i in range(len(d_fake)) for j in range(len(d_fake[i]) - 1)]
+    return ops.multi_pair_loss(fake, real, 0, weight, unit_grad=unit_grad)

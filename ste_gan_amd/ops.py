@@ -496,6 +496,56 @@ class _PairLossFn(torch.autograd.Function):
         return ctx.restore(_chain(da, g)), None, None, None
 
 
+class _MultiPairLossFn(torch.autograd.Function):
+    """weight * sum_i mean(|a_i - b_i|)  (mode 0)  or  weight * sum_i mean((a_i - b_i)^2)  (mode 1) in one autograd node:
+    every pair's kernel adds into ONE loss word and writes its own gradient, so a 40-term feature-matching sum costs 40
+    launches instead of 40 x (zero-fill + loss kernel + scalar add + gradient scale).
+
+    ``unit_grad``: the caller promises that the returned (already weighted) value enters the scalar handed to
+    ``backward()`` as a plain summand, i.e. its upstream gradient is exactly 1 -- the stored gradients are then returned
+    as they are instead of being multiplied by a device scalar that is known to be one."""
+
+    @staticmethod
+    def forward(ctx, mode: int, weight: float, target, unit_grad: bool, n: int, *ts):
+        a_list, b_list = ts[:n], (ts[n:] if target is None else (None,) * n)
+        loss = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
+        grads, restores = [], []
+        L = _lib.lib()
+        for i, (a, b) in enumerate(zip(a_list, b_list)):
+            af, bf, restore = _memory_order_pair(a, b)
+            af = _gpu_f32(af, "input")
+            if bf is not None:
+                bf = _gpu_f32(bf, "target")
+                if bf.numel() != af.numel():
+                    raise RuntimeError(f"The size of tensor a ({list(a.shape)}) must match the size of tensor b ({list(b.shape)})")
+            da = torch.empty_like(af) if ctx.needs_input_grad[5 + i] else None
+            check(L.stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target or 0.0), af.numel(), mode, float(weight), _p(loss),
+                                             _p(da), _stream()), "stegan_pair_loss_fwd_bwd")
+            grads.append(da); restores.append(restore)
+        ctx.restores, ctx.unit_grad, ctx.n_extra = restores, unit_grad, len(ts) - n
+        ctx.save_for_backward(*[g for g in grads if g is not None])
+        ctx.has = [g is not None for g in grads]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = list(ctx.saved_tensors)
+        out = []
+        for has, restore in zip(ctx.has, ctx.restores):
+            if not has:
+                out.append(None)
+                continue
+            da = saved.pop(0)
+            out.append(restore(da if ctx.unit_grad else _chain(da, g)))
+        return (None, None, None, None, None, *out, *([None] * ctx.n_extra))
+
+
+def multi_pair_loss(a_list, b_list, mode: int, weight: float = 1.0, target=None, unit_grad: bool = False):
+    a_list = list(a_list)
+    extra = [] if target is not None else [b.detach() for b in b_list]
+    return _MultiPairLossFn.apply(mode, float(weight), target, bool(unit_grad), len(a_list), *a_list, *extra)
+
+
 def l1_loss(a, b):
     return _PairLossFn.apply(a, b.detach(), 0.0, 0)
 

@@ -94,7 +94,8 @@ class GANTrainStep:
         d_handle = None
         if t.loss_adversarial:
             D_fake_det, D_real = netD.forward_pair(x_pred_t.detach(), x_t)          # train.py:190-191, batched
-            loss_D = lsgan_loss(D_fake_det, 0.0) + lsgan_loss(D_real, 1.0)
+            # both terms are plain summands of the scalar handed to backward(): unit upstream gradient (ops.multi_pair_loss)
+            loss_D = lsgan_loss(D_fake_det, 0.0, unit_grad=True) + lsgan_loss(D_real, 1.0, unit_grad=True)
             loss_D.backward()
             self.optD.finalize_grads()
             out["discriminator"] = loss_D.detach()
@@ -137,11 +138,12 @@ class GANTrainStep:
             with torch.no_grad():
                 D_real = netD(x_t)
             if t.loss_adversarial:
-                loss_G = loss_G + lsgan_loss(D_fake, 1.0)
+                loss_G = loss_G + lsgan_loss(D_fake, 1.0, unit_grad=True)
             if t.loss_feat_match_error:
-                loss_feat = feature_matching_loss(D_fake, D_real)
-                loss_G = loss_G + t.loss_feat_match_weight * loss_feat
-                out["feature_matching"] = loss_feat.detach()
+                w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
+                loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True)
+                loss_G = loss_G + loss_feat_w
+                out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
             loss_G.backward()
         finally:
             self._set_d_grad(True)

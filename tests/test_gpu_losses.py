@@ -96,3 +96,29 @@ def test_lsgan_and_feature_matching_vs_oracle():
     ref = O.lsgan_loss(rf, 1.0) + 0.5 * O.lsgan_loss(rr, 0.0) + 7.0 * O.feature_matching_loss(rf, rr)
     close(float(loss), float(ref), 2e-5, "loss")
     close(xf_d.grad.cpu().numpy(), torch.autograd.grad(ref, xf_c)[0].numpy(), 2e-4, "dx_fake")
+
+
+def test_folded_weights_unit_grad_path_vs_oracle():
+    """The train step's form: weights folded into the loss kernels, terms added as plain summands (unit upstream
+    gradient, so the stored gradients are used unscaled) -- same value and input gradient as the generic form."""
+    from ste_gan_amd.losses.gan_losses import feature_matching_loss, lsgan_loss
+    from ste_gan_amd.models.discriminator import DiscriminatorSmall
+    sd = fill_state_dict(oshapes.discriminator_shapes(True))
+    d = DiscriminatorSmall(8)
+    d.load_state_dict(sd)
+    d = d.cuda().eval()
+    xf = det_input("gl2.fake", (3, 96, 8), "tanh")
+    xr = det_input("gl2.real", (3, 96, 8), "tanh")
+    xf_d = xf.cuda().requires_grad_(True)
+    of, orl = d(xf_d), d(xr.cuda())
+    fm_w = feature_matching_loss(of, orl, weight=7.0, unit_grad=True)
+    loss = lsgan_loss(of, 1.0, unit_grad=True) + fm_w
+    loss.backward()
+    xf_c = xf.clone().requires_grad_(True)
+    rf = O.discriminator_forward(sd, xf_c, True, training=False)
+    rr = O.discriminator_forward(sd, xr, True, training=False)
+    ref_fm = O.feature_matching_loss(rf, rr)
+    ref = O.lsgan_loss(rf, 1.0) + 7.0 * ref_fm
+    close(float(loss), float(ref), 2e-5, "loss")
+    close(float(fm_w) / 7.0, float(ref_fm), 2e-5, "fm")
+    close(xf_d.grad.cpu().numpy(), torch.autograd.grad(ref, xf_c)[0].numpy(), 2e-4, "dx_fake")

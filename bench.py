@@ -189,7 +189,7 @@ def main():
 
     # ---- roofline of the dominant kernel: instrumented pass, HIP events around every conv launch
     roof = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         ops.PROFILER = ops.ConvProfiler()
         for _ in range(args.profile_steps):
             eager_step(batch)                              # instrumented pass: eager launches, HIP events per conv

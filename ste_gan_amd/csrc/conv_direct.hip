@@ -21,6 +21,7 @@
 //   * v_mfma_f32_32x32x2_f32 operands: A = Ws[row][m] (32 consecutive dwords per half-wave), B = Xs[xoff[row] +
 //     colbase(lane)] where xoff[row] = channel*XROW + tap offset comes from a small LDS table -- the tap shift is
 //     just an address offset into the halo'd row.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -54,6 +55,10 @@ struct DirP {
     int WR;                             // W-tile rows held in LDS per buffer (>= taps * CC of any phase, multiple of 8)
     int U0;                             // columns per batch element for phase 0 (max over phases)
     int splits, chunks_per_split;       // split-K over channel chunks: grid.z = phase*splits + split
+    // Tail split (mix_S > 0, 1-D grid): the first mix_full tiles run whole; the remaining tiles -- the ones that would
+    // make a quarter of the CUs carry one block more than the rest -- are cut into mix_S reduction slices each, so every
+    // CU gets the same number of whole tiles plus one short block.  Tile id = (phase * ny + y) * nbx + x.
+    int mix_S, mix_full, mix_cps, nbx, ny;
     float* partial;                     // splits > 1: raw accumulators [split][B*Cdst*Tdst], epilogue runs separately
     unsigned long long* stamps;         // diagnostic builds only (STEGAN_STAMPS): 8 s_memtime stamps per block
     FastDiv fdS;
@@ -129,6 +134,34 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const DirP p)
     }
 }
 
+// tail-split launches: grid (tail tiles, 16); a block sums 4 rows x 64 columns of one split tile (one output per thread,
+// all mix_S partial loads in flight at once, fixed summation order) and applies the fused epilogue
+__global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(const DirP p) {
+    const int tile = p.mix_full + blockIdx.x;
+    const int bx = tile % p.nbx, rest = tile / p.nbx;
+    const int by = rest % p.ny, phase = rest / p.ny;
+    const int g = by / p.m_tiles, m0 = (by % p.m_tiles) * 64;
+    int U, os;
+    if (p.mode == 0) { U = p.U0; os = 1; }
+    else { U = (p.Tdst - phase + p.stride - 1) / p.stride; os = p.stride; }
+    const int N = p.B * U;
+    const int n = bx * 64 + (threadIdx.x & 63);
+    const int m = m0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (n >= N || m >= p.M_g) return;
+    const int b = n / U, u = n - b * U;
+    const int to = p.mode == 0 ? u : phase + u * os;
+    const size_t total = (size_t)p.B * p.Cdst * p.Tdst;
+    const int ch = g * p.M_g + m;
+    const float* src = p.partial + ((size_t)b * p.Cdst + ch) * p.Tdst + to;
+    float t[8];
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) t[s2] = s2 < p.mix_S ? src[(size_t)s2 * total] : 0.f;
+    float v = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) v += t[s2];
+    epilogue_store(p, v, b, ch, to);
+}
+
 // Per-phase tap progression.  The live taps of a launch (FWD) or of one output phase (BWD) form an arithmetic
 // progression: tap j uses weight index k = kbase + j*kstep and reads the source at offset off_min + j*step, so no
 // lookup tables are needed in the inner loop.
@@ -174,17 +207,33 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #endif
     STAMP(0)
     const int wm = wave >> 1, wn = wave & 1;
-    const int g = blockIdx.y / p.m_tiles;
-    const int m0 = (blockIdx.y % p.m_tiles) * BM;
-    const int phase = blockIdx.z / p.splits;
-    const int split = blockIdx.z - phase * p.splits;
+    int bx = blockIdx.x, by = blockIdx.y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
+    if (p.mix_S) {
+        int tile = bx;
+        split = 0; nsplits = 1;
+        if (bx >= p.mix_full) {
+            const int r = bx - p.mix_full;
+            tile = p.mix_full + r / p.mix_S;
+            split = r - (r / p.mix_S) * p.mix_S;
+            nsplits = p.mix_S; cps = p.mix_cps;
+        }
+        bx = tile % p.nbx;
+        const int rest = tile / p.nbx;
+        by = rest % p.ny;
+        phase = rest / p.ny;
+    } else {
+        phase = blockIdx.z / p.splits;
+        split = blockIdx.z - phase * p.splits;
+    }
+    const int g = by / p.m_tiles;
+    const int m0 = (by % p.m_tiles) * BM;
 
     // ---- per-phase geometry (wave-uniform scalar work)
     int U, cs, os;
     if (p.mode == 0) { U = p.U0; cs = p.stride; os = 1; }
     else { U = (p.Tdst - phase + p.stride - 1) / p.stride; cs = 1; os = p.stride; }
     const int N = p.B * U;
-    const int n0 = blockIdx.x * BN;
+    const int n0 = bx * BN;
     if (n0 >= N) return;
     const FastDiv fdU = (U == p.U0) ? p.fdU0 : p.fdU1;
     const Taps tp = phase_taps(p, phase);
@@ -270,8 +319,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #endif
     const int half = lane >> 5, l31 = lane & 31;
     const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) / CC : 0;
-    const int c_begin = split * p.chunks_per_split;
-    const int c_end = min(nchunks, c_begin + p.chunks_per_split);
+    const int c_begin = split * cps;
+    const int c_end = min(nchunks, c_begin + cps);
     const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
 
     // Staging is LDS-DMA (global_load_lds): every lane hands the DMA engine its own global address and the data lands
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #pragma unroll
      for (int im = 0; im < TM; ++im) {
         const int mrow0 = m0 + (wm * TM + im) * 32 + 4 * half;
-        if (p.splits > 1) {
+        if (nsplits > 1) {
             float* dst = p.partial + (size_t)split * out_elems;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -760,11 +809,48 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     p.chunks_per_split = ceil_div(nchunks, splits);
     p.splits = ceil_div(nchunks, p.chunks_per_split);
     p.partial = workspace;
+    // Tail split: with T tiles on 256 CUs, T mod 256 CUs carry one whole block more than the rest and set the launch
+    // time (every generator layer has 576 tiles: 3 blocks on 64 CUs, 2 on 192).  Cutting just those tail tiles into S
+    // reduction slices gives every CU the same number of whole tiles plus one short block.
+    p.mix_S = 0; p.mix_full = 0; p.mix_cps = 0; p.nbx = (int)nb; p.ny = p.m_tiles * d->groups;
+    {
+        static const char* no_tail = getenv("STEGAN_NO_TAILSPLIT");
+        const long tiles = nb * p.ny * phases;
+        const long q = tiles / 256, r = tiles % 256;
+        if (!no_tail && tm == 1 && gm.BN == 64 && q >= 2 && q <= 8 && r > 0 && nchunks >= 4 && workspace &&
+            workspace_floats >= 2 * out_elems && tiles < (1L << 30)) {
+            long S = 256 / r;
+            if (S < 2) S = 2;
+            if (S > nchunks / 2) S = nchunks / 2;
+            if (S > 8) S = 8;
+            if (S > workspace_floats / out_elems) S = workspace_floats / out_elems;
+            if (S >= 2) {
+                // same cost units as choose_splits: whole tiles on every CU, then the short blocks of the tail tiles
+                const int cps = ceil_div(nchunks, (int)S);
+                const long tail_rounds = (r * ceil_div(nchunks, cps) + 255) / 256;
+                const double cost_tail = (double)q * (nchunks + 2.5) + (double)tail_rounds * (cps + 2.5) + 1.0;
+                if (cost_tail < cost1 - 1e-9) {
+                    p.splits = 1; p.chunks_per_split = nchunks;
+                    p.mix_cps = cps;
+                    p.mix_S = ceil_div(nchunks, cps);
+                    p.mix_full = (int)(tiles - r);
+                }
+            }
+        }
+    }
     {
         static const char* se = getenv("STEGAN_STAMP_PTR");     // diagnostic builds: device buffer address (decimal)
         p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr;
     }
+    {
+        static const char* dbg = getenv("STEGAN_PLAN_DEBUG");
+        if (dbg) fprintf(stderr, "plan mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BN=%d tm=%d CC=%d nchunks=%d tiles=%ld splits=%d mix_S=%d full=%d lds=%zu\n",
+                         mode, d->B, p.C2_g, p.M_g, d->K, d->stride, d->dilation, p.Tdst, gm.BN, tm, gm.CC, nchunks,
+                         nb * p.ny * phases, p.splits, p.mix_S, p.mix_full, gm.lds);
+    }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
+    const long tail_tiles = p.mix_S ? nb * p.ny * phases - p.mix_full : 0;
+    if (p.mix_S) grid = dim3((unsigned)(p.mix_full + tail_tiles * p.mix_S), 1, 1);
     if (gm.lds > 64 * 1024) {
         static bool attr_done = false;
         if (!attr_done) {
@@ -784,6 +870,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         else      { if (xvec) STEGAN_LAUNCH(1, 1, false, true); else STEGAN_LAUNCH(1, 1, false, false); }
     }
 #undef STEGAN_LAUNCH
+    if (p.mix_S) hipLaunchKernelGGL(conv_tail_epilogue_kernel, dim3((unsigned)tail_tiles, 16), dim3(256), 0, s, p);
     if (p.splits > 1) {
         long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;
         if (eb > 4096) eb = 4096;

@@ -161,8 +161,15 @@ def loaders(data_root: Path, strict=False, chunksize: int = K.CHUNK_SIZE, hopsiz
     return loaders_from_samples(tr, va, te, batch_size, train_emg_length, hopsize, device, hop_aligned_emg)
 
 
-def loaders_via_config(cfg, device="cuda"):
-    """loader.py:92-109 (``train_emg_length = chunk_size``: no autoregressive extra input)."""
+def loaders_via_config(cfg, device="cuda", hop_aligned_emg: bool = True):
+    """loader.py:92-109 (``train_emg_length = chunk_size``: no autoregressive extra input).
+
+    ``hop_aligned_emg`` (default on for the trainer's loaders): a chunk size that is not a multiple of the hop (the
+    shipped 200) makes the reference crop 12 feature frames but 200 EMG samples -- its ``torch.stack`` then fails
+    whenever the last possible window of an exact-length utterance is drawn, and its losses fail on the 200-vs-192
+    mismatch anyway (SURVEY.md section 8d).  The trainer crops real EMG to ``(chunk // 16) * 16`` samples, so its loaders
+    cut exactly that; pass ``False`` for the reference's literal crop."""
     chunksize = cfg.train.chunk_size
     return loaders(data_root=Path(cfg.data.dataset_root), strict=cfg.data.strict, chunksize=chunksize, hopsize=K.HOPSIZE,
-                   train_emg_length=chunksize, batch_size=cfg.train.batch_size, device=device)
+                   train_emg_length=chunksize, batch_size=cfg.train.batch_size, device=device,
+                   hop_aligned_emg=hop_aligned_emg)

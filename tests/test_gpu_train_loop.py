@@ -1,0 +1,80 @@
+"""GPU, end to end: corpus directory -> resident stores -> device loaders -> train() (steps, validation, best-model and
+numbered checkpoints) -> resume from the checkpoint directory.  Small widths, a synthetic corpus on disk in the
+reference's layout (data/emg_dataset.py:50-151)."""
+import os
+
+import pytest
+import torch
+import yaml
+
+from oracle import shapes as oshapes
+from oracle.detfill import det_input, det_ints, fill_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _corpus(root):
+    parts = {"train": [("s1__u%02d__normal" % i, 30 + 7 * i) for i in range(6)] + [("s2__v%02d__normal" % i, 25 + i) for i in range(3)]
+             + [("s1__short__normal", 8), ("s2__sil__silent", 40)],
+             "valid": [("s1__w%02d__normal" % i, 28 + i) for i in range(3)],
+             "test": [("s2__x00__normal", 20), ("s1__x01__normal", 5)]}
+    for part, utts in parts.items():
+        for sub in ("emg", "units", "phonemes", "mfccs"):
+            (root / part / sub).mkdir(parents=True)
+        for uid, f in utts:
+            torch.save(det_input(uid + ".emg", (16 * f, 8), "tanh"), root / part / "emg" / f"{uid}.pt")
+            torch.save(det_input(uid + ".su", (f, 256)), root / part / "units" / f"{uid}.pt")
+            torch.save(det_ints(uid + ".ph", (f,), 48), root / part / "phonemes" / f"{uid}.pt")
+            torch.save(det_input(uid + ".mf", (2 * f, 25)), root / part / "mfccs" / f"{uid}.pt")
+
+
+def _cfg(tmp_path, max_steps):
+    from ste_gan_amd.train_utils import DictConfig
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs/ste_gan_base_gantts.yaml")))
+    cfg["data"] = yaml.safe_load(open(os.path.join(ROOT, "configs/data/gaddy_and_klein_corpus.yaml")))
+    cfg["data"]["dataset_root"] = str(tmp_path / "corpus")
+    cfg["data"]["strict"] = True
+    cfg["model"]["params"] = {"channels": 32}
+    cfg["emg_encoder"] = {"type": "EMGEncoderTransformer",
+                          "params": {"model_size": 64, "num_transformer_layers": 2, "dim_feedforward": 128}}
+    cfg["train"].update(batch_size=4, chunk_size=200, max_steps=max_steps, interval_log=1, interval_valid=2, interval_save=2)
+    return DictConfig(cfg)
+
+
+def test_train_loop_end_to_end_and_resume(tmp_path):
+    from ste_gan_amd.data import loaders_via_config
+    from ste_gan_amd.train import train
+    _corpus(tmp_path / "corpus")
+    enc_ckpt = tmp_path / "enc.pt"
+    torch.save(fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128)), enc_ckpt)
+    cfg = _cfg(tmp_path, max_steps=3)
+
+    tr, va, te = loaders_via_config(cfg)
+    assert len(tr.store) == 9 and len(va.store) == 3 and len(te.store) == 2       # short + silent utterances filtered
+    assert (len(tr), len(va), len(te)) == (3, 1, 2)
+    b = next(iter(tr))
+    assert b["REAL_EMG"].shape == (4, 192, 8) and b["SPEECH_UNITS"].shape == (4, 12, 256) and b["REAL_EMG"].is_cuda
+
+    out = tmp_path / "run"
+    out.mkdir()
+    train(cfg, out, None, "cuda", debug=False, emg_enc_ckpt=enc_ckpt)
+    names = {p.name for p in out.iterdir()}
+    assert {".done", "netG-final.pt", "netD-final.pt", "checkpoint-final.pt", "netG-00000002.pt", "checkpoint-00000002.pt",
+            "best_netG.pt", "best_netD.pt"} <= names
+    ck = torch.load(out / "checkpoint-00000002.pt")
+    assert ck["steps"] == 2 and set(ck) == {"epoch", "steps", "optG", "optD"}
+    sdG = torch.load(out / "netG-00000002.pt")
+    assert list(sdG) == list(oshapes.generator_shapes("SPEECH_UNITS", 32))          # reference key layout
+    assert all(torch.isfinite(v).all() for v in sdG.values())
+
+    # resume: picks the highest NUMBERED checkpoint (step 2), continues to the new max_steps
+    (out / ".done").unlink()
+    cfg2 = _cfg(tmp_path, max_steps=5)
+    train(cfg2, out, out, "cuda", debug=False, emg_enc_ckpt=enc_ckpt)
+    ck4 = torch.load(out / "checkpoint-00000004.pt")
+    assert ck4["steps"] == 4
+    st = next(iter(ck4["optG"]["state"].values()))
+    # checkpoint 2 holds 3 optimiser steps (loop counter 0, 1, 2); the resumed loop starts again AT counter 2
+    # (train.py:84-91,165: `steps` is restored, then the next batch runs) and runs counters 2, 3, 4
+    assert float(st["step"]) == 6.0

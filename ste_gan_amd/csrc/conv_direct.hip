@@ -191,9 +191,11 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
     return t;
 }
 
-template <int TM, int TN, bool FAST, bool XVEC>
+// W14: the four waves sit side by side along N (block tile 32 x 128) instead of 2 x 2 (64 x 64) -- for groups / phases
+// with at most 32 output rows, where the lower wave row of the 2 x 2 layout would multiply padding.
+template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
-    constexpr int BN = 64 * TN;
+    constexpr int BN = W14 ? 128 : 64 * TN;
     constexpr int BM = 64 * TM;                 // 2x2 waves, wave tile (32*TM) x (32*TN)
     constexpr int WEt = WE * TM;                // W-tile float4 per thread and chunk
     constexpr int WROW4 = 16 * TM;              // float4 per W row
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #define STAMP(i_)
 #endif
     STAMP(0)
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = W14 ? 0 : wave >> 1, wn = W14 ? wave : wave & 1;
     int bx = blockIdx.x, by = blockIdx.y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
     if (p.mix_S) {
         int tile = bx;
@@ -362,13 +364,14 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[k][i] = Wcur[r * BM + (wm * TM + i) * 32 + l31];     \
         const int tap = r >> p.logCC, ci = r & (CC - 1);                                                       \
         const int xo = r < RCV ? ci * p.XROW + tap * tp.step : 0;                                              \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = fmaxf(Xcur[xo + colbase[j]], relu_floor);    \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[k][j] = Xcur[xo + colbase[j]];                       \
     }
 #define STEGAN_MFMA_BODY(a_, b_)                                                                               \
     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                              \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                         \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k][i], b_[k][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[k][i], relu_max(b_[k][j], relu_floor),     \
+                                                                 acc[i][j], 0, 0, 0);
 
     // Two LDS buffers, ONE barrier per chunk: the DMA of chunk c+1 is issued right behind the barrier and stays in
     // flight while the matrix cores run over chunk c (LDS reads of the next 4-MFMA body interleaved with the MFMAs).
@@ -630,12 +633,14 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 struct Geo { int CC, logCC, SEG, NSEG, XROW, BN, WR; size_t lds; bool ok; };
 
 // geometry for one launch; ntaps_max bounds the taps of any phase
-Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks, bool xvec) {
+Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long other_blocks, bool xvec,
+             int force_bn = 0) {
     Geo gm;
     gm.ok = false;
     if (ntaps_max > MAX_TAPS) return gm;
     // BN: 128 when the grid still fills the chip, else 64
     for (int BN : {128, 64}) {
+        if (force_bn && BN != force_bn) continue;
         const int UT = U < BN ? U : BN;
         int SEG = (UT - 1) * cs + span_off + 1;
         if (xvec) SEG = (SEG + 3 + 3) & ~3;          // + up to 3 slots of down-rounding, padded to whole float4s
@@ -654,7 +659,7 @@ Geo plan_geo(int ntaps_max, int span_off, int cs, int U, int U_min, long N, long
         const long blocks = (N + BN - 1) / BN;
         static const char* env128 = getenv("STEGAN_BN128_MIN_BLOCKS");
         const long min128 = env128 ? atol(env128) : 768;
-        if (BN == 64 || blocks * other_blocks >= min128) {
+        if (BN == 64 || force_bn || blocks * other_blocks >= min128) {
             gm.CC = CC;
             gm.logCC = 0;
             while ((1 << gm.logCC) < CC) ++gm.logCC;
@@ -779,6 +784,13 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
                       !getenv("STEGAN_NO_XVEC");
     Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
     if (!gm.ok) return 1;
+    // narrow groups (<= 32 output rows per group / phase): four waves along N, see W14
+    static const char* no_w14 = getenv("STEGAN_NO_W14");
+    bool w14 = false;
+    if (!no_w14 && p.M_g <= 32) {
+        Geo g2 = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)d->groups * phases, xvec, 128);
+        if (g2.ok && g2.CC >= gm.CC) { gm = g2; w14 = true; }
+    }
     p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.WR = gm.WR; p.U0 = U;
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
@@ -794,7 +806,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     // measured (scripts/conv_microbench.py): 128-row tiles win only on the small-N layers (few output tiles, deep
     // reductions); with plenty of tiles the smaller LDS footprint of 64-row tiles (3 resident blocks per CU) wins
     const long base1 = nb * ceil_div(p.M_g, 64) * d->groups * phases;
-    if (fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
+    if (!w14 && fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
         const int s2 = choose_splits(nb * (p.M_g / 128) * d->groups * phases, nchunks, 1.7, &cost2);
         tm = 2; splits = s2;
     }
@@ -860,7 +872,11 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         }
     }
 #define STEGAN_LAUNCH(TM_, TN_, F_, V_) hipLaunchKernelGGL((conv_direct_kernel<TM_, TN_, F_, V_>), grid, dim3(256), gm.lds, s, p)
-    if (tm == 2) {
+#define STEGAN_LAUNCH_W14(F_, V_) hipLaunchKernelGGL((conv_direct_kernel<1, 1, F_, V_, true>), grid, dim3(256), gm.lds, s, p)
+    if (w14) {
+        if (fast) { if (xvec) STEGAN_LAUNCH_W14(true, true); else STEGAN_LAUNCH_W14(true, false); }
+        else      { if (xvec) STEGAN_LAUNCH_W14(false, true); else STEGAN_LAUNCH_W14(false, false); }
+    } else if (tm == 2) {
         if (xvec) STEGAN_LAUNCH(2, 1, true, true); else STEGAN_LAUNCH(2, 1, true, false);
     } else if (gm.BN == 128) {
         if (fast) { if (xvec) STEGAN_LAUNCH(1, 2, true, true); else STEGAN_LAUNCH(1, 2, true, false); }
@@ -870,6 +886,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         else      { if (xvec) STEGAN_LAUNCH(1, 1, false, true); else STEGAN_LAUNCH(1, 1, false, false); }
     }
 #undef STEGAN_LAUNCH
+#undef STEGAN_LAUNCH_W14
     if (p.mix_S) hipLaunchKernelGGL(conv_tail_epilogue_kernel, dim3((unsigned)tail_tiles, 16), dim3(256), 0, s, p);
     if (p.splits > 1) {
         long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;

@@ -53,3 +53,21 @@ def test_generate_b64_matches_oracle():
     # batch independence: sample 37 alone equals sample 37 in the batch
     solo = g.generate(feats[37:38].cuda(), sess[37:38].cuda(), torch.zeros(1, dtype=torch.long).cuda())
     torch.testing.assert_close(solo[0], out[37], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("T_su,ch", [(1, 768), (7, 768), (333, 96)])
+def test_whole_utterance_generation_at_batch_one(T_su, ch):
+    """Validation / sampling path (train.py:380-414, generator.py:48-75): one whole utterance of arbitrary length at
+    batch 1 -- a single frame, an odd length, and a long one (5 328 samples) -- through ``generate`` and
+    ``generate_from_data_dict`` (per-utterance dict with un-batched tensors, result (T_emg, C) on the CPU)."""
+    g, sd = build("SPEECH_UNITS", ch)
+    feats = det_input(f"utt{T_su}.feats", (1, T_su, 256))
+    sess = torch.tensor([5])
+    out = g.generate(feats.cuda(), sess.cuda(), torch.zeros(1, dtype=torch.long).cuda())
+    assert out.shape == (1, 16 * T_su, 8) and not out.requires_grad
+    ref = O.generator_forward(sd, feats, sess, None)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+    item = {"SPEECH_UNITS": feats[0], "SESSION_INDEX": torch.tensor(5), "SPEAKING_MODE_IDX": torch.tensor(0)}
+    solo = g.generate_from_data_dict(item, torch.device("cuda"))
+    assert solo.device.type == "cpu" and solo.shape == (16 * T_su, 8)
+    torch.testing.assert_close(solo, out[0].cpu(), rtol=0, atol=0)

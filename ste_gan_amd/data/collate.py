@@ -13,6 +13,7 @@ per-utterance sample dicts.
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -37,8 +38,95 @@ def draw_start_frames(frame_counts: Sequence[int], length: int) -> List[int]:
     return [int(torch.randint(0, 1 + max(0, int(f) - length), (1,)).item()) for f in frame_counts]
 
 
-def _cat(ts: List[torch.Tensor], dtype, device) -> torch.Tensor:
-    return torch.cat([t.reshape(t.shape[0], -1) if t.dim() > 1 else t for t in ts], 0).to(dtype).contiguous().to(device)
+def _cat(ts: List[torch.Tensor], dtype) -> torch.Tensor:
+    return torch.cat([t.reshape(t.shape[0], -1) if t.dim() > 1 else t for t in ts], 0).to(dtype).contiguous()
+
+
+def pack_samples(samples: Sequence[Dict]) -> Dict:
+    """Per-utterance sample dicts -> the packed host form of a partition: every field concatenated along time plus the
+    row counts (``emg_len`` / ``frames`` / ``mfcc_len``).  This is what a shard file holds (``save_packed``)."""
+    if len(samples) == 0:
+        raise ValueError("UtteranceStore needs at least one utterance")
+    emg = [s[DataType.REAL_EMG] for s in samples]
+    su = [s[DataType.SPEECH_UNITS] for s in samples]
+    ph = [s[DataType.PHONEMES] for s in samples]
+    mf = [s.get(DataType.MFCCS) for s in samples]
+    if any(m is None for m in mf) and not all(m is None for m in mf):
+        raise ValueError("either every utterance carries MFCCs or none does")
+    for i, (e, u, p) in enumerate(zip(emg, su, ph)):
+        if e.dim() != 2 or u.dim() != 2 or p.dim() != 1:
+            raise ValueError(f"utterance {i}: expected EMG (T,C), units (F,D), phonemes (F,); got "
+                             f"{tuple(e.shape)}, {tuple(u.shape)}, {tuple(p.shape)}")
+        if len(u) != len(p):
+            raise ValueError(f"utterance {i}: {len(u)} unit frames but {len(p)} phoneme labels")
+    if any(e.shape[1] != emg[0].shape[1] for e in emg) or any(u.shape[1] != su[0].shape[1] for u in su):
+        raise ValueError("utterances disagree on the EMG channel count or the unit dimension")
+    has_mfcc = mf[0] is not None
+    scalar = lambda key: torch.stack([torch.as_tensor(s[key]).reshape(()) for s in samples]).to(torch.int64)
+    return {"emg": _cat(emg, torch.float32), "units": _cat(su, torch.float32), "phonemes": _cat(ph, torch.int64),
+            "mfcc": _cat(mf, torch.float32) if has_mfcc else None,
+            "session_idx": scalar(DataType.SESSION_INDEX), "mode_idx": scalar(DataType.SPEAKING_MODE_INDEX),
+            "emg_len": [len(e) for e in emg], "frames": [len(u) for u in su],
+            "mfcc_len": [len(m) for m in mf] if has_mfcc else [0] * len(samples),
+            "utt_ids": [s.get(DataType.UTT_ID, "") for s in samples]}
+
+
+_SHARD_MAGIC = b"STEGANSHARD1\n"
+_SHARD_FIELDS = (("emg", "<f4"), ("units", "<f4"), ("phonemes", "<i8"), ("mfcc", "<f4"), ("session_idx", "<i8"), ("mode_idx", "<i8"))
+
+
+def save_packed(packed: Dict, path) -> None:
+    """One shard file per partition: magic, a JSON header (shapes, row counts, utterance ids, byte offsets), then the raw
+    little-endian arrays, each 64-byte aligned -- so a later run maps it instead of unpickling one ``.pt`` per utterance
+    and field (the reference's layout: 4 files x thousands of utterances, data/emg_dataset.py:229-251)."""
+    import json
+    import numpy as np
+    head = {"emg_len": packed["emg_len"], "frames": packed["frames"], "mfcc_len": packed["mfcc_len"],
+            "utt_ids": packed["utt_ids"], "arrays": {}}
+    blobs, off = [], 0
+    for name, dt in _SHARD_FIELDS:
+        t = packed[name]
+        if t is None:
+            continue
+        a = np.ascontiguousarray(t.numpy()).astype(dt, copy=False)
+        head["arrays"][name] = {"dtype": dt, "shape": list(a.shape), "offset": off}
+        blobs.append((off, a))
+        off += (a.nbytes + 63) // 64 * 64
+    hj = json.dumps(head).encode()
+    pre = len(_SHARD_MAGIC) + 8 + len(hj)
+    pad = (-pre) % 64
+    with open(path, "wb") as f:
+        f.write(_SHARD_MAGIC)
+        f.write((len(hj) + pad).to_bytes(8, "little"))
+        f.write(hj + b" " * pad)
+        base = f.tell()
+        for o, a in blobs:
+            f.seek(base + o)
+            f.write(a.tobytes())
+        f.truncate(base + off)
+
+
+def load_packed(path) -> Dict:
+    """Inverse of ``save_packed``; the arrays are memory-mapped (read-only), so the upload streams from the page cache."""
+    import json
+    import numpy as np
+    with open(path, "rb") as f:
+        if f.read(len(_SHARD_MAGIC)) != _SHARD_MAGIC:
+            raise ValueError(f"{path}: not a ste-gan shard file")
+        hlen = int.from_bytes(f.read(8), "little")
+        head = json.loads(f.read(hlen).decode())
+        base = f.tell()
+    out = {k: head[k] for k in ("emg_len", "frames", "mfcc_len", "utt_ids")}
+    for name, _ in _SHARD_FIELDS:
+        meta = head["arrays"].get(name)
+        if meta is None:
+            out[name] = None
+            continue
+        a = np.memmap(path, dtype=meta["dtype"], mode="r", offset=base + meta["offset"], shape=tuple(meta["shape"]))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")                  # read-only mapping: the tensor is only ever a copy source
+            out[name] = torch.from_numpy(np.asarray(a))
+    return out
 
 
 class UtteranceStore:
@@ -46,50 +134,36 @@ class UtteranceStore:
 
     ``samples`` are dicts shaped like ``EMGDataset.__getitem__`` output (data/emg_dataset.py:277-294): ``REAL_EMG``
     (T, C) float, ``SPEECH_UNITS`` (F, D) float, ``PHONEMES`` (F,) int, ``SESSION_INDEX`` / ``SPEAKING_MODE_INDEX``
-    0-d int, optionally ``MFCCS`` (M, n_mfcc) float (``None`` for all utterances = no MFCC arena).  Row counts stay on
-    the host too: window validation never touches the device.
+    0-d int, optionally ``MFCCS`` (M, n_mfcc) float (``None`` for all utterances = no MFCC arena) -- or the packed form
+    of ``pack_samples`` / ``load_packed``.  Row counts stay on the host too: window validation never touches the device.
     """
 
-    def __init__(self, samples: Sequence[Dict], device="cuda"):
-        if len(samples) == 0:
-            raise ValueError("UtteranceStore needs at least one utterance")
+    def __init__(self, samples, device="cuda"):
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(f"UtteranceStore lives in HBM; got device '{device}' (there is no CPU fallback)")
         self.device = device
-        emg = [s[DataType.REAL_EMG] for s in samples]
-        su = [s[DataType.SPEECH_UNITS] for s in samples]
-        ph = [s[DataType.PHONEMES] for s in samples]
-        mf = [s.get(DataType.MFCCS) for s in samples]
-        if any(m is None for m in mf) and not all(m is None for m in mf):
-            raise ValueError("either every utterance carries MFCCs or none does")
-        for i, (e, u, p) in enumerate(zip(emg, su, ph)):
-            if e.dim() != 2 or u.dim() != 2 or p.dim() != 1:
-                raise ValueError(f"utterance {i}: expected EMG (T,C), units (F,D), phonemes (F,); got "
-                                 f"{tuple(e.shape)}, {tuple(u.shape)}, {tuple(p.shape)}")
-            if len(u) != len(p):
-                raise ValueError(f"utterance {i}: {len(u)} unit frames but {len(p)} phoneme labels")
-        self.emg_channels, self.unit_dim = emg[0].shape[1], su[0].shape[1]
-        if any(e.shape[1] != self.emg_channels for e in emg) or any(u.shape[1] != self.unit_dim for u in su):
-            raise ValueError("utterances disagree on the EMG channel count or the unit dimension")
-        self.has_mfcc = mf[0] is not None
-        self.mfcc_dim = mf[0].shape[1] if self.has_mfcc else 0
-        self.emg_len = [len(e) for e in emg]
-        self.frames = [len(u) for u in su]
-        self.mfcc_len = [len(m) for m in mf] if self.has_mfcc else [0] * len(samples)
-        self.n = len(samples)
+        pk = samples if isinstance(samples, dict) else pack_samples(samples)
+        self.emg_len, self.frames, self.mfcc_len = list(pk["emg_len"]), list(pk["frames"]), list(pk["mfcc_len"])
+        self.utt_ids = list(pk.get("utt_ids", []))
+        self.n = len(self.frames)
+        if self.n == 0:
+            raise ValueError("UtteranceStore needs at least one utterance")
+        self.has_mfcc = pk["mfcc"] is not None
+        self.emg_channels, self.unit_dim = pk["emg"].shape[1], pk["units"].shape[1]
+        self.mfcc_dim = pk["mfcc"].shape[1] if self.has_mfcc else 0
 
         def offsets(lens):
             return torch.tensor([0] + list(torch.tensor(lens, dtype=torch.int64).cumsum(0)), dtype=torch.int64, device=device)
 
-        self.emg = _cat(emg, torch.float32, device)
-        self.units = _cat(su, torch.float32, device)
-        self.phonemes = _cat(ph, torch.int64, device)
-        self.mfcc = _cat(mf, torch.float32, device) if self.has_mfcc else None
+        self.emg = pk["emg"].to(device)
+        self.units = pk["units"].to(device)
+        self.phonemes = pk["phonemes"].to(device)
+        self.mfcc = pk["mfcc"].to(device) if self.has_mfcc else None
         self.emg_off, self.frame_off = offsets(self.emg_len), offsets(self.frames)
         self.mfcc_off = offsets(self.mfcc_len) if self.has_mfcc else None
-        self.session_idx = torch.stack([torch.as_tensor(s[DataType.SESSION_INDEX]).reshape(()) for s in samples]).to(torch.int64).to(device)
-        self.mode_idx = torch.stack([torch.as_tensor(s[DataType.SPEAKING_MODE_INDEX]).reshape(()) for s in samples]).to(torch.int64).to(device)
+        self.session_idx = pk["session_idx"].to(device)
+        self.mode_idx = pk["mode_idx"].to(device)
         P = lambda t: t.data_ptr() if t is not None else None
         self._desc = Corpus(P(self.emg), P(self.emg_off), P(self.units), P(self.phonemes), P(self.frame_off), P(self.mfcc),
                             P(self.mfcc_off), P(self.session_idx), P(self.mode_idx), self.n, self.emg_channels,

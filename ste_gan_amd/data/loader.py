@@ -149,14 +149,38 @@ def loaders_from_samples(train_samples, valid_samples, test_samples, batch_size:
     return mk(train_samples, "train"), mk(valid_samples, "valid"), mk(test_samples, "test")
 
 
+def _packed_partition(data_root, partition, shard_dir, s2i, m2i, **kw):
+    """(packed partition, utterance ids, session map, mode map): from ``<shard_dir>/<partition>.shard`` when it exists,
+    else from the per-utterance ``.pt`` files (and the shard is written for next time)."""
+    from .collate import load_packed, pack_samples, save_packed
+    shard = Path(shard_dir) / f"{partition}.shard" if shard_dir else None
+    if shard is not None and shard.exists():
+        pk = load_packed(shard)
+        ids = pk["utt_ids"]
+        if not s2i:                                       # same rule as read_partition: sorted ids of THIS partition
+            s2i = {s: i for i, s in enumerate(sorted({_utt_session(u) for u in ids}))}
+            m2i = {m: i for i, m in enumerate(sorted({_utt_mode(u) for u in ids}))}
+        return pk, ids, s2i, m2i
+    samples, s2i, m2i, ids = read_partition(data_root, partition, s2i, m2i, **kw)
+    pk = pack_samples(samples)
+    if shard is not None:
+        shard.parent.mkdir(parents=True, exist_ok=True)
+        save_packed(pk, shard)
+    return pk, ids, s2i, m2i
+
+
 def loaders(data_root: Path, strict=False, chunksize: int = K.CHUNK_SIZE, hopsize: int = K.HOPSIZE,
             train_emg_length: int = K.TRAIN_EMG_LENGTH, batch_size: int = K.BATCH_SIZE, device="cuda",
-            hop_aligned_emg: bool = False):
-    """loader.py:19-90 over resident stores."""
-    tr, s2i, m2i, tr_ids = read_partition(data_root, "train", strict=strict, train_emg_length=train_emg_length)
-    va, _, _, va_ids = read_partition(data_root, "valid", s2i, m2i, strict=strict, train_emg_length=train_emg_length)
-    te, _, _, te_ids = read_partition(data_root, "test", s2i, m2i, filter_by_length=False, strict=strict,
-                                      train_emg_length=train_emg_length)
+            hop_aligned_emg: bool = False, shard_dir=None):
+    """loader.py:19-90 over resident stores.  ``shard_dir``: cache each partition as one packed, memory-mappable shard
+    file (``collate.save_packed``) and start from it when present (the selection parameters are baked into a shard:
+    use a fresh directory per ``train_emg_length`` / filter setting)."""
+    tr, tr_ids, s2i, m2i = _packed_partition(data_root, "train", shard_dir, None, None, strict=strict,
+                                             train_emg_length=train_emg_length)
+    va, va_ids, _, _ = _packed_partition(data_root, "valid", shard_dir, s2i, m2i, strict=strict,
+                                         train_emg_length=train_emg_length)
+    te, te_ids, _, _ = _packed_partition(data_root, "test", shard_dir, s2i, m2i, filter_by_length=False, strict=strict,
+                                         train_emg_length=train_emg_length)
     check_no_data_overlap([tr_ids, va_ids, te_ids])
     return loaders_from_samples(tr, va, te, batch_size, train_emg_length, hopsize, device, hop_aligned_emg)
 

@@ -87,3 +87,25 @@ def test_read_partition_layout(tmp_path):
     check_no_data_overlap([ids2, va_ids])
     with pytest.raises(ValueError, match="Intersecting"):
         check_no_data_overlap([ids2, ids])
+
+
+def test_shard_roundtrip(tmp_path):
+    """pack -> shard file -> memory-mapped load gives the same arrays, row counts and ids; bad files are refused."""
+    from ste_gan_amd.data import load_packed, pack_samples, save_packed
+    samples = cases.collate_samples("collate_c200")
+    for i, s in enumerate(samples):
+        s["UTT_ID"] = f"s{i % 2}__u{i}__normal"
+    pk = pack_samples(samples)
+    assert pk["emg"].shape == (sum(16 * f + 8 for f in cases.COLLATE_CASES["collate_c200"][0]), 8)
+    save_packed(pk, tmp_path / "train.shard")
+    q = load_packed(tmp_path / "train.shard")
+    for k, v in pk.items():
+        assert (torch.equal(v, q[k]) if torch.is_tensor(v) else v == q[k]), k
+    for s in samples:
+        s["MFCCS"] = None
+    pk2 = pack_samples(samples)
+    save_packed(pk2, tmp_path / "nomfcc.shard")
+    assert load_packed(tmp_path / "nomfcc.shard")["mfcc"] is None
+    (tmp_path / "junk.shard").write_bytes(b"not a shard")
+    with pytest.raises(ValueError, match="not a ste-gan shard"):
+        load_packed(tmp_path / "junk.shard")

@@ -78,3 +78,26 @@ def test_train_loop_end_to_end_and_resume(tmp_path):
     # checkpoint 2 holds 3 optimiser steps (loop counter 0, 1, 2); the resumed loop starts again AT counter 2
     # (train.py:84-91,165: `steps` is restored, then the next batch runs) and runs counters 2, 3, 4
     assert float(st["step"]) == 6.0
+
+
+def test_loaders_from_shard_cache_match_loaders_from_pt_files(tmp_path):
+    """First call reads the per-utterance .pt files and writes one shard per partition; the second call starts from the
+    memory-mapped shards: same stores, same batches under the same seed."""
+    from ste_gan_amd.data import loaders
+    _corpus(tmp_path / "corpus")
+    kw = dict(strict=True, train_emg_length=192, batch_size=4)
+    a = loaders(tmp_path / "corpus", shard_dir=tmp_path / "shards", **kw)
+    assert sorted(p.name for p in (tmp_path / "shards").iterdir()) == ["test.shard", "train.shard", "valid.shard"]
+    b = loaders(tmp_path / "corpus", shard_dir=tmp_path / "shards", **kw)
+    c = loaders(tmp_path / "corpus", **kw)
+    for la, lb, lc in zip(a, b, c):
+        assert la.store.frames == lb.store.frames == lc.store.frames and lb.store.utt_ids == lc.store.utt_ids
+        assert torch.equal(la.store.session_idx, lb.store.session_idx) and torch.equal(lb.store.session_idx, lc.store.session_idx)
+        outs = []
+        for ld in (la, lb, lc):
+            torch.manual_seed(99)
+            outs.append(list(ld))
+        for x, y, z in zip(*outs):
+            for k in x:
+                if x[k] is not None:
+                    assert torch.equal(x[k], y[k]) and torch.equal(y[k], z[k]), k

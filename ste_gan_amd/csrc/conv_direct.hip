@@ -29,6 +29,7 @@
 namespace {
 
 constexpr int MAX_TAPS = 48;
+constexpr int MAX_PHASES = 8;    // BWD_DATA output phases = stride (larger strides take the generic kernel)
 constexpr int XE = 16;           // X-tile elements staged per thread and chunk: CC * XROW <= 256 * XE
 constexpr int WE = 4;            // W-tile float4 per thread and chunk: RC * 16 <= 256 * WE
 constexpr int BM2 = 64;
@@ -63,6 +64,10 @@ struct DirP {
     unsigned long long* stamps;         // diagnostic builds only (STEGAN_STAMPS): 8 s_memtime stamps per block
     FastDiv fdS;
     FastDiv fdXROW, fdSEG, fdU0, fdU1;  // magic division by XROW, SEG, U0 and U0-1 (the two per-phase column counts)
+    FastDiv fdMT, fdSP, fdNBX, fdNY, fdMS;   // ... by m_tiles, splits, nbx, ny, mix_S (block-id decode: no software division
+                                             // chains, ~35 scalar instructions each, in front of the first DMA)
+    int ph_ntaps[MAX_PHASES], ph_kbase[MAX_PHASES], ph_kstep[MAX_PHASES], ph_offmin[MAX_PHASES], ph_step[MAX_PHASES];
+    int ph_U[MAX_PHASES];               // per output phase: tap progression and column count, precomputed on the host
 };
 
 __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, int ch, int to) {
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_tail_epilogue_kernel(const DirP p) {
 // lookup tables are needed in the inner loop.
 struct Taps { int ntaps, kbase, kstep, off_min, step; };
 
-__device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
+inline Taps phase_taps_host(const DirP& p, int phase) {
     Taps t;
     if (p.mode == 0) {
         t.ntaps = p.k_hi - p.k_lo + 1; t.kbase = p.k_lo; t.kstep = 1;
@@ -191,8 +196,13 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
     return t;
 }
 
-// W14: the four waves sit side by side along N (block tile 32 x 128) instead of 2 x 2 (64 x 64) -- for groups / phases
-// with at most 32 output rows, where the lower wave row of the 2 x 2 layout would multiply padding.
+__device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
+    Taps t;
+    t.ntaps = p.ph_ntaps[phase]; t.kbase = p.ph_kbase[phase]; t.kstep = p.ph_kstep[phase];
+    t.off_min = p.ph_offmin[phase]; t.step = p.ph_step[phase];
+    return t;
+}
+
 template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BN = W14 ? 128 : 64 * TN;
@@ -208,6 +218,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #define STAMP(i_)
 #endif
     STAMP(0)
+    // Pull the descriptor words the prologue needs into scalar registers in ONE clustered batch of kernarg loads: left
+    // alone, hipcc sinks each s_load next to its first use -- ~20 dependent load + wait round trips (100-200 cycles each)
+    // strung through the index setup in front of the first DMA.
+    asm volatile("" ::"s"(p.B), "s"(p.Csrc), "s"(p.Cdst), "s"(p.Tsrc), "s"(p.Tq), "s"(p.Tdst), "s"(p.C2_g), "s"(p.M_g),
+                 "s"(p.LD), "s"(p.K), "s"(p.stride), "s"(p.mode), "s"(p.m_tiles), "s"(p.CC), "s"(p.logCC), "s"(p.SEG),
+                 "s"(p.NSEG), "s"(p.XROW), "s"(p.WR), "s"(p.U0), "s"(p.splits), "s"(p.chunks_per_split), "s"(p.mix_S),
+                 "s"(p.mix_full), "s"(p.nbx), "s"(p.ny), "s"(p.ups), "s"(p.in_relu));
     const int wm = W14 ? 0 : wave >> 1, wn = W14 ? wave : wave & 1;
     int bx = blockIdx.x, by = blockIdx.y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
     if (p.mix_S) {
@@ -215,25 +232,26 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         split = 0; nsplits = 1;
         if (bx >= p.mix_full) {
             const int r = bx - p.mix_full;
-            tile = p.mix_full + r / p.mix_S;
-            split = r - (r / p.mix_S) * p.mix_S;
+            const int rq = (int)fd_div((uint32_t)r, p.fdMS);
+            tile = p.mix_full + rq;
+            split = r - rq * p.mix_S;
             nsplits = p.mix_S; cps = p.mix_cps;
         }
-        bx = tile % p.nbx;
-        const int rest = tile / p.nbx;
-        by = rest % p.ny;
-        phase = rest / p.ny;
+        const int rest = (int)fd_div((uint32_t)tile, p.fdNBX);
+        bx = tile - rest * p.nbx;
+        phase = (int)fd_div((uint32_t)rest, p.fdNY);
+        by = rest - phase * p.ny;
     } else {
-        phase = blockIdx.z / p.splits;
+        phase = (int)fd_div(blockIdx.z, p.fdSP);
         split = blockIdx.z - phase * p.splits;
     }
-    const int g = by / p.m_tiles;
-    const int m0 = (by % p.m_tiles) * BM;
+    const int g = (int)fd_div((uint32_t)by, p.fdMT);
+    const int m0 = (by - g * p.m_tiles) * BM;
 
-    // ---- per-phase geometry (wave-uniform scalar work)
+    // ---- per-phase geometry (wave-uniform scalar work; the per-phase values come precomputed from the host)
     int U, cs, os;
     if (p.mode == 0) { U = p.U0; cs = p.stride; os = 1; }
-    else { U = (p.Tdst - phase + p.stride - 1) / p.stride; cs = 1; os = p.stride; }
+    else { U = p.ph_U[phase]; cs = 1; os = p.stride; }
     const int N = p.B * U;
     const int n0 = bx * BN;
     if (n0 >= N) return;
@@ -320,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     STAMP(6)
 #endif
     const int half = lane >> 5, l31 = lane & 31;
-    const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) / CC : 0;
+    const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) >> p.logCC : 0;
     const int c_begin = split * cps;
     const int c_end = min(nchunks, c_begin + cps);
     const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
@@ -859,6 +877,16 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         if (dbg) fprintf(stderr, "plan mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BN=%d tm=%d CC=%d nchunks=%d tiles=%ld splits=%d mix_S=%d full=%d lds=%zu\n",
                          mode, d->B, p.C2_g, p.M_g, d->K, d->stride, d->dilation, p.Tdst, gm.BN, tm, gm.CC, nchunks,
                          nb * p.ny * phases, p.splits, p.mix_S, p.mix_full, gm.lds);
+    }
+    if (phases > MAX_PHASES) return 1;
+    p.fdMT = make_fastdiv((uint32_t)p.m_tiles); p.fdSP = make_fastdiv((uint32_t)p.splits);
+    p.fdNBX = make_fastdiv((uint32_t)p.nbx); p.fdNY = make_fastdiv((uint32_t)p.ny);
+    p.fdMS = make_fastdiv((uint32_t)(p.mix_S > 0 ? p.mix_S : 1));
+    for (int ph = 0; ph < MAX_PHASES; ++ph) {
+        const Taps t = phase_taps_host(p, ph < phases ? ph : 0);
+        p.ph_ntaps[ph] = t.ntaps; p.ph_kbase[ph] = t.kbase; p.ph_kstep[ph] = t.kstep; p.ph_offmin[ph] = t.off_min;
+        p.ph_step[ph] = t.step;
+        p.ph_U[ph] = mode == 0 ? U : (p.Tdst - ph + d->stride - 1) / d->stride;
     }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
     const long tail_tiles = p.mix_S ? nb * p.ny * phases - p.mix_full : 0;

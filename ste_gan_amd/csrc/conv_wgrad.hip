@@ -35,7 +35,7 @@ struct WgP {
     int XSEG, XP;                // halo'd row segment per item, padded (odd) row pitch
     int total_chunks, chunks_per_block;
     int m_tiles, ci_tiles;
-    FastDiv fdXSEG, fdT, fdNCT;
+    FastDiv fdXSEG, fdT, fdNCT, fdCIT, fdMT;
 };
 
 __device__ __forceinline__ float floor_max(float x, float floor_) {      // one VALU op, no canonicalisation
@@ -50,10 +50,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
     const int wm = wave & 1, wn = wave >> 1;
     const int half = lane >> 5, l31 = lane & 31;
 
-    int tile = blockIdx.x;
-    const int cit = tile % p.ci_tiles; tile /= p.ci_tiles;
-    const int mt = tile % p.m_tiles;
-    const int g = tile / p.m_tiles;
+    // descriptor words in one clustered batch of kernarg loads; block-id decode by magic division (see conv_direct.hip)
+    asm volatile("" ::"s"(p.B), "s"(p.Cin), "s"(p.Cout), "s"(p.Cin_g), "s"(p.Cout_g), "s"(p.K), "s"(p.stride), "s"(p.dil),
+                 "s"(p.pad), "s"(p.Tin), "s"(p.Te), "s"(p.Tout), "s"(p.ups), "s"(p.relu), "s"(p.k_lo), "s"(p.K_eff),
+                 "s"(p.RCH), "s"(p.RV), "s"(p.nct), "s"(p.nbc), "s"(p.XSEG), "s"(p.XP), "s"(p.total_chunks),
+                 "s"(p.chunks_per_block), "s"(p.m_tiles), "s"(p.ci_tiles));
+    const int tile = blockIdx.x;
+    const int t1 = (int)fd_div((uint32_t)tile, p.fdCIT);
+    const int cit = tile - t1 * p.ci_tiles;
+    const int g = (int)fd_div((uint32_t)t1, p.fdMT);
+    const int mt = t1 - g * p.m_tiles;
     const int m0 = mt * 64, ci0 = cit * 32;
     const int tg = blockIdx.y;
     const int ktaps = min(KT, p.K_eff - tg * KT);
@@ -322,6 +328,7 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
     p.fdXSEG = make_fastdiv((uint32_t)p.XSEG); p.fdT = make_fastdiv((uint32_t)T);
     p.fdNCT = make_fastdiv((uint32_t)(p.nct ? p.nct : 1));
     p.m_tiles = ceil_div(p.Cout_g, 64); p.ci_tiles = ceil_div(p.Cin_g, 32);
+    p.fdCIT = make_fastdiv((uint32_t)p.ci_tiles); p.fdMT = make_fastdiv((uint32_t)p.m_tiles);
     const int tapgroups = ceil_div(p.K_eff, KT);
     const long tiles = (long)d->groups * p.m_tiles * p.ci_tiles * tapgroups;
     // Slices of the reduction (whole chunks, not whole items, so any slice count works): aim at two co-resident blocks

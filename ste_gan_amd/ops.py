@@ -332,8 +332,11 @@ class _SNConvFn(torch.autograd.Function):
         y = conv1d_fwd(x, w_orig, scale, bias, None, cfg, wf)
         ctx.cfg = cfg
         ctx.wb = wb
-        # u / v are cloned because the next forward power-iterates them in place (torch clones them too)
-        ctx.save_for_backward(x, w_orig, u.clone(), v.clone(), scale, sigma, y if cfg.out_act != ACT_NONE else None)
+        # u / v are cloned because the next forward power-iterates them in place (torch clones them too) -- but only the
+        # weight gradient reads them, so frozen-weight passes (generator step, no_grad) skip the two copies
+        need_w = ctx.needs_input_grad[1]
+        ctx.save_for_backward(x, w_orig, u.clone() if need_w else u, v.clone() if need_w else v, scale, sigma,
+                              y if cfg.out_act != ACT_NONE else None)
         return y
 
     @staticmethod

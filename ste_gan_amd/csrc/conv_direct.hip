@@ -54,6 +54,9 @@ struct DirP {
     int m_tiles, CC, logCC;
     int SEG, NSEG, XROW;
     int WR;                             // W-tile rows held in LDS per buffer (>= taps * CC of any phase, multiple of 8)
+    int TG, NTG;                        // tap groups: a W chunk holds TG taps x CC channels, NTG chunks per channel chunk
+                                        // (NTG = 1: every live tap in one chunk); the X tile is staged once per channel chunk
+    FastDiv fdNTG;
     int U0;                             // columns per batch element for phase 0 (max over phases)
     int splits, chunks_per_split;       // split-K over channel chunks: grid.z = phase*splits + split
     // Tail split (mix_S > 0, 1-D grid): the first mix_full tiles run whole; the remaining tiles -- the ones that would
@@ -203,7 +206,9 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
     return t;
 }
 
-template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false>
+// TAPG: tap groups (p.NTG > 1) -- compiled separately so the common all-taps-in-one-chunk kernels keep their straight-line
+// DMA issue (a data-dependent branch around the X-tile DMA costs every chunk of every layer otherwise).
+template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false, bool TAPG = false>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     constexpr int BN = W14 ? 128 : 64 * TN;
     constexpr int BM = 64 * TM;                 // 2x2 waves, wave tile (32*TM) x (32*TN)
@@ -262,7 +267,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #endif
     const int ntaps = tp.ntaps, off_min = tp.off_min;
     const int CC = p.CC;
-    const int RCV = ntaps * CC;                     // valid rows per chunk
+    // rows per W chunk: (taps of the chunk) x CC.  With tap groups every chunk has TG * CC rows; the rows of taps past the
+    // phase's last live tap are zero weight rows (their B operands read real halo data, so the products are exact zeros)
+    const int RCV = (TAPG ? p.TG : ntaps) * CC;
     const int RC = (RCV + 7) & ~7;                  // padded to the MFMA loop's unroll (zero weight rows)
 
     // ---- chunk-invariant part of the X staging.  Scalar form: thread element e <-> tile index tid + 256 e =
@@ -296,16 +303,16 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #endif
     // ---- W staging: thread element i <-> float4 index tid + 256 i = row * 16 + c4
     int w_off[WEt];     // offset of the float4 inside the group's transposed weights, without the chunk term
-    int w_ci[WEt];
+    int w_ci[WEt];      // channel within the chunk + 2^16 * tap within the chunk (1 << 30 = never valid)
 #pragma unroll
     for (int i = 0; i < WEt; ++i) {
         const int idx = tid + 256 * i;
         const int r = idx / WROW4, c4 = idx % WROW4;
         const int tap = r >> p.logCC, ci = r & (CC - 1);
-        w_ci[i] = 1 << 20;
+        w_ci[i] = 1 << 30;
         w_off[i] = 0;
         if (r < RCV) {
-            w_ci[i] = ci;
+            w_ci[i] = TAPG ? (ci | (tap << 16)) : ci;
             w_off[i] = ((tp.kbase + tap * tp.kstep) * p.C2_g + ci) * p.LD + m0 + c4 * 4;
         }
     }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     STAMP(6)
 #endif
     const int half = lane >> 5, l31 = lane & 31;
-    const int nchunks = ntaps > 0 ? (p.C2_g + CC - 1) >> p.logCC : 0;
+    const int nchunks = ntaps > 0 ? ((p.C2_g + CC - 1) >> p.logCC) * (TAPG ? p.NTG : 1) : 0;   // c = (channel chunk, tap group)
     const int c_begin = split * cps;
     const int c_end = min(nchunks, c_begin + cps);
     const float* wt_g = p.wt + (size_t)g * p.K * p.C2_g * p.LD;
@@ -350,27 +357,36 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     const float* zero_row = p.wt + p.zero_off;
+    // LDS: two W buffers (one per chunk, alternating) followed by two X buffers (one per CHANNEL chunk, alternating)
+    const int wbuf_floats = p.WR * BM, xbuf_floats = CC * p.XROW;
+    float* const Xbufs = smem + 2 * wbuf_floats;
+    const int cc_begin = TAPG ? (int)fd_div((uint32_t)c_begin, p.fdNTG) : c_begin;
 #define STEGAN_DMA_CHUNK(c_, buf_)                                                                             \
     {                                                                                                          \
-        const int c0_ = (c_) * CC;                                                                             \
-        const int lim_ = p.C2_g - c0_;                                                                         \
-        float* Wd_ = smem + (buf_) * buf_floats;                                                               \
-        float* Xd_ = Wd_ + p.WR * BM;                                                                          \
-        const float* wc_ = wt_g + (size_t)c0_ * p.LD;                                                          \
+        const int cc_ = TAPG ? (int)fd_div((uint32_t)(c_), p.fdNTG) : (c_), tg_ = TAPG ? (c_) - cc_ * p.NTG : 0; \
+        const int c0_ = cc_ * CC;                                                                              \
+        const int lim_ = p.C2_g - c0_;                          /* live channels of this chunk        */        \
+        const int tlim_ = (ntaps - tg_ * p.TG) << 16;           /* live taps of this chunk, << 16     */        \
+        float* Wd_ = smem + (buf_) * wbuf_floats;                                                              \
+        const float* wc_ = wt_g + ((long)c0_ + (long)tg_ * p.TG * tp.kstep * p.C2_g) * p.LD;                   \
         _Pragma("unroll") for (int i = 0; i < WEt; ++i) {                                                      \
             const int idx = tid + 256 * i;                                                                     \
             if ((idx / WROW4) < RC) {                                                                          \
-                const float* src_ = (w_ci[i] < lim_) ? wc_ + w_off[i] : zero_row + (idx % WROW4) * 4;          \
+                const bool ok_ = TAPG ? ((w_ci[i] & 0xffff) < lim_ && (w_ci[i] & ~0xffff) < tlim_) : (w_ci[i] < lim_); \
+                const float* src_ = ok_ ? wc_ + w_off[i] : zero_row + (idx % WROW4) * 4;                        \
                 __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (wave * 64 + 256 * i) * 4), 16, 0, 0); \
             }                                                                                                  \
         }                                                                                                      \
-        const float* xc_ = p.src + (size_t)(g * p.C2_g + c0_) * p.Tsrc;                                        \
-        _Pragma("unroll") for (int e = 0; e < XN; ++e) {                                                       \
-            const int idx = (tid + 256 * e) * (XVEC ? 4 : 1);                                                  \
-            if (idx < CC * p.XROW) {                                                                           \
-                const float* src_ = (x_ci[e] < lim_) ? xc_ + x_src[e] : zero_row;                              \
-                if (XVEC) __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + (wave * 64 + 256 * e) * 4), 16, 0, 0); \
-                else __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + wave * 64 + 256 * e), 4, 0, 0); \
+        if (!TAPG || tg_ == 0 || (c_) == c_begin) {             /* first chunk of a channel chunk: its X tile */ \
+            float* Xd_ = Xbufs + ((cc_ - cc_begin) & 1) * xbuf_floats;                                         \
+            const float* xc_ = p.src + (size_t)(g * p.C2_g + c0_) * p.Tsrc;                                    \
+            _Pragma("unroll") for (int e = 0; e < XN; ++e) {                                                   \
+                const int idx = (tid + 256 * e) * (XVEC ? 4 : 1);                                              \
+                if (idx < CC * p.XROW) {                                                                       \
+                    const float* src_ = (x_ci[e] < lim_) ? xc_ + x_src[e] : zero_row;                          \
+                    if (XVEC) __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + (wave * 64 + 256 * e) * 4), 16, 0, 0); \
+                    else __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Xd_ + wave * 64 + 256 * e), 4, 0, 0); \
+                }                                                                                              \
             }                                                                                                  \
         }                                                                                                      \
     }
@@ -393,7 +409,6 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 
     // Two LDS buffers, ONE barrier per chunk: the DMA of chunk c+1 is issued right behind the barrier and stays in
     // flight while the matrix cores run over chunk c (LDS reads of the next 4-MFMA body interleaved with the MFMAs).
-    const int buf_floats = p.WR * BM + CC * p.XROW;
     STAMP(1)
     if (c_begin < c_end) STEGAN_DMA_CHUNK(c_begin, 0)
     STAMP(2)
@@ -421,8 +436,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(6) }
 #endif
-        const float* Wcur = smem + cur * buf_floats;
-        const float* Xcur = Wcur + p.WR * BM;
+        const int cc_cur = TAPG ? (int)fd_div((uint32_t)c, p.fdNTG) : c, tg_cur = TAPG ? c - cc_cur * p.NTG : 0;
+        const float* Wcur = smem + cur * wbuf_floats;
+        // the chunk's taps start tg * TG taps into the halo'd rows
+        const float* Xcur = Xbufs + ((cc_cur - cc_begin) & 1) * xbuf_floats + tg_cur * p.TG * tp.step;
         if constexpr (FAST) {
             // Fast path (host guarantees CC >= 8) (K_eff*CC is a multiple of 8, a body of 8 rows never straddles a tap): the B address is
             // colb2 + scalar, the A address abase + immediate.  Loads of the NEXT body are interleaved one row pair at
@@ -797,23 +814,54 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         cs = 1; U = (Te + d->stride - 1) / d->stride; U_min = Te / d->stride; phases = d->stride;
     }
     const long N = (long)d->B * U;
+    // Tap groups: with more than 8 live taps a chunk of ALL taps leaves room for only 1-4 channels (rows <= 64) and the
+    // slow generic MFMA loop; instead a W chunk takes TG = 4 or 8 taps x (64 / TG) channels -- the fast loop's shape --
+    // and the halo'd X tile of a channel chunk is staged once and reused by its NTG tap groups.
+    int TG = ntaps_max, NTG = 1;
+    const int span_all = span_off;
+    if (ntaps_max > 8 && !getenv("STEGAN_NO_TAPGROUPS")) {
+        const int pad8 = ceil_div(ntaps_max, 8) * 8, pad4 = ceil_div(ntaps_max, 4) * 4;
+        TG = pad4 < pad8 ? 4 : 8;
+        NTG = ceil_div(ntaps_max, TG);
+        int step = d->dilation;
+        if (mode == 1) {
+            int gg = d->dilation % d->stride, hh = d->stride;
+            while (gg) { const int tt = hh % gg; hh = gg; gg = tt; }
+            step = d->dilation / hh;
+        }
+        span_off = (NTG * TG - 1) * step;              // the dead taps of the last group read real halo data
+    }
     // 16-byte X DMA needs float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
     const bool xvec = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
                       !getenv("STEGAN_NO_XVEC");
-    Geo gm = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
+    if (ntaps_max > MAX_TAPS) return 1;
+    Geo gm = plan_geo(TG, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
     if (!gm.ok) return 1;
-    // narrow groups (<= 32 output rows per group / phase): four waves along N, see W14
+    if (NTG > 1 && gm.CC < 8) {                        // X tile too wide for 8 channels: back to all taps in one chunk
+        TG = ntaps_max; NTG = 1;
+        span_off = span_all;
+        gm = plan_geo(TG, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
+        if (!gm.ok) return 1;
+    }
+    // narrow groups (<= 32 output rows per group / phase): four waves along N, see W14.  Measured on the K = 37 grouped
+    // layers: not multiplying padding rows matters more than the fast loop, so when the 128-column X tile leaves no room
+    // for 8-channel tap groups the layer keeps W14 with all taps in one chunk (generic loop).
     static const char* no_w14 = getenv("STEGAN_NO_W14");
     bool w14 = false;
     if (!no_w14 && p.M_g <= 32) {
-        Geo g2 = plan_geo(ntaps_max, span_off, cs, U, U_min, N, (long)d->groups * phases, xvec, 128);
-        if (g2.ok && g2.CC >= gm.CC) { gm = g2; w14 = true; }
+        Geo g2 = plan_geo(TG, span_off, cs, U, U_min, N, (long)d->groups * phases, xvec, 128);
+        if (g2.ok && (NTG == 1 ? g2.CC >= gm.CC : g2.CC >= 8)) { gm = g2; w14 = true; }
+        else if (NTG > 1) {
+            Geo g3 = plan_geo(ntaps_max, span_all, cs, U, U_min, N, (long)d->groups * phases, xvec, 128);
+            if (g3.ok) { gm = g3; w14 = true; TG = ntaps_max; NTG = 1; span_off = span_all; }
+        }
     }
     p.CC = gm.CC; p.logCC = gm.logCC; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.WR = gm.WR; p.U0 = U;
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
     const long nb = (N + gm.BN - 1) / gm.BN;
-    const int nchunks = ceil_div(p.C2_g, gm.CC);
+    p.TG = TG; p.NTG = NTG; p.fdNTG = make_fastdiv((uint32_t)NTG);
+    const int nchunks = ceil_div(p.C2_g, gm.CC) * NTG;
     const bool fast = gm.CC >= 8;
     // M tile: 128 rows (two MFMA row tiles per wave: twice the matrix work per staged X element, per barrier and per
     // block prologue / epilogue) when the channel count allows it and the cost model does not lose to 64-row tiles
@@ -824,7 +872,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     // measured (scripts/conv_microbench.py): 128-row tiles win only on the small-N layers (few output tiles, deep
     // reductions); with plenty of tiles the smaller LDS footprint of 64-row tiles (3 resident blocks per CU) wins
     const long base1 = nb * ceil_div(p.M_g, 64) * d->groups * phases;
-    if (!w14 && fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
+    if (!w14 && NTG == 1 && fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
         const int s2 = choose_splits(nb * (p.M_g / 128) * d->groups * phases, nchunks, 1.7, &cost2);
         tm = 2; splits = s2;
     }
@@ -874,9 +922,9 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
     {
         static const char* dbg = getenv("STEGAN_PLAN_DEBUG");
-        if (dbg) fprintf(stderr, "plan mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BN=%d tm=%d CC=%d nchunks=%d tiles=%ld splits=%d mix_S=%d full=%d lds=%zu\n",
+        if (dbg) fprintf(stderr, "plan mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BN=%d tm=%d CC=%d nchunks=%d tiles=%ld splits=%d mix_S=%d full=%d lds=%zu TG=%d NTG=%d w14=%d XROW=%d\n",
                          mode, d->B, p.C2_g, p.M_g, d->K, d->stride, d->dilation, p.Tdst, gm.BN, tm, gm.CC, nchunks,
-                         nb * p.ny * phases, p.splits, p.mix_S, p.mix_full, gm.lds);
+                         nb * p.ny * phases, p.splits, p.mix_S, p.mix_full, gm.lds, TG, NTG, (int)w14, gm.XROW);
     }
     if (phases > MAX_PHASES) return 1;
     p.fdMT = make_fastdiv((uint32_t)p.m_tiles); p.fdSP = make_fastdiv((uint32_t)p.splits);
@@ -901,7 +949,15 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
 #define STEGAN_LAUNCH(TM_, TN_, F_, V_) hipLaunchKernelGGL((conv_direct_kernel<TM_, TN_, F_, V_>), grid, dim3(256), gm.lds, s, p)
 #define STEGAN_LAUNCH_W14(F_, V_) hipLaunchKernelGGL((conv_direct_kernel<1, 1, F_, V_, true>), grid, dim3(256), gm.lds, s, p)
-    if (w14) {
+    if (NTG > 1) {                                           // tap groups: fast loop by construction (CC >= 8), 64-row tiles
+        if (w14) {
+            if (xvec) hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, true, true, true>), grid, dim3(256), gm.lds, s, p);
+            else hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, false, true, true>), grid, dim3(256), gm.lds, s, p);
+        } else {
+            if (xvec) hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, true, false, true>), grid, dim3(256), gm.lds, s, p);
+            else hipLaunchKernelGGL((conv_direct_kernel<1, 1, true, false, false, true>), grid, dim3(256), gm.lds, s, p);
+        }
+    } else if (w14) {
         if (fast) { if (xvec) STEGAN_LAUNCH_W14(true, true); else STEGAN_LAUNCH_W14(true, false); }
         else      { if (xvec) STEGAN_LAUNCH_W14(false, true); else STEGAN_LAUNCH_W14(false, false); }
     } else if (tm == 2) {

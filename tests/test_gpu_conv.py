@@ -36,6 +36,12 @@ CASES = [
     (22, 256, 512, 3, 3, 1, 2, 1, 1, False, 11),     # MPD p=11 tail: bwd phases with 4,4,3 columns per row
     (22, 512, 1, 3, 1, 1, 1, 1, 1, False, 4),        # MPD output conv at H=4
     (4, 32, 32, 5, 4, 1, 2, 1, 1, False, 10),        # stride 4: phases with 3,3,2,2 columns
+    (3, 128, 256, 37, 2, 1, 18, 4, 1, False, 48),    # tap groups, short rows: most of the 37 taps reach into the padding
+    (3, 128, 256, 37, 2, 1, 18, 4, 1, False, 24),    # ... T = 24: live taps are a sub-range (k_lo > 0)
+    (3, 256, 512, 37, 2, 1, 18, 16, 1, False, 12),   # ... T = 12 -> 6, narrow groups
+    (3, 256, 512, 37, 2, 1, 18, 16, 1, False, 24),
+    (3, 8, 128, 15, 1, 1, 7, 1, 1, False, 24),       # k15 tap groups at T = 24 and 96
+    (3, 8, 128, 15, 1, 1, 7, 1, 1, False, 96),
 ]
 
 

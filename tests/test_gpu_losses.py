@@ -121,4 +121,19 @@ def test_folded_weights_unit_grad_path_vs_oracle():
     ref = O.lsgan_loss(rf, 1.0) + 7.0 * ref_fm
     close(float(loss), float(ref), 2e-5, "loss")
     close(float(fm_w) / 7.0, float(ref_fm), 2e-5, "fm")
-    close(xf_d.grad.cpu().numpy(), torch.autograd.grad(ref, xf_c)[0].numpy(), 2e-4, "dx_fake")
+    # The gradient is discontinuous at the leaky-ReLU kinks, and with ~7e5 activations some pre-activation always lies
+    # within fp32 rounding of zero (min |y| / max |y| ~ 5e-9 for this input): an equally valid summation order can flip
+    # that unit's slope 0.1 <-> 1 and move every dx entry downstream of it.  The test therefore
+    # looks for such flips itself -- activations whose SIGN differs between the two forwards, all of them within 1e-6 of
+    # their map's scale -- and asserts the tight bound when there is none, a norm bound otherwise.
+    flips = 0
+    for a, b in zip(of, rf):
+        for fa, fb in zip(a[:-1], b[:-1]):
+            bad = (fa.detach().cpu() * fb) < 0
+            flips += int(bad.sum())
+            assert float(fb[bad].abs().max() if bad.any() else 0.0) <= 1e-6 * float(fb.abs().max()), "sign differs away from 0"
+    got, want = xf_d.grad.cpu().numpy().astype(np.float64), torch.autograd.grad(ref, xf_c)[0].numpy().astype(np.float64)
+    if flips == 0:
+        close(got, want, 2e-4, "dx_fake")
+    else:
+        assert flips <= 3 and np.linalg.norm(got - want) <= 1e-2 * np.linalg.norm(want), f"dx_fake (l2) with {flips} kink flips"

@@ -134,6 +134,19 @@ int64_t stegan_conv_workspace_floats(const stegan_conv_desc* d, int32_t mode);
 int stegan_conv1d_fwd_t(const stegan_conv_desc* d, const float* x, const float* wf, const float* scale,
                         const float* bias, const float* residual, float* y, float* workspace,
                         int64_t workspace_floats, void* stream);
+/*
+ * Up to 5 independent forward convolutions in ONE launch (the same layer of the period discriminators: one channel
+ * structure, different weights, batch and length).  Arrays of n host pointers to descriptors / device buffers
+ * (scale, bias, residual arrays or entries may be NULL).  Returns 1 when the problems cannot share a launch (different
+ * kernel variants, many-tap or narrow-group layers): the caller then issues stegan_conv1d_fwd_t per problem.
+ */
+int stegan_conv1d_fwd_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                            const float* const* wf, const float* const* scale, const float* const* bias,
+                            const float* const* residual, float* const* y, void* stream);
+/* Input-gradient counterpart of stegan_conv1d_fwd_multi (per-channel scales folded into wb; no uniform scale). */
+int stegan_conv1d_bwd_data_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                 const float* const* wb, const float* const* mask_src, const float* const* add_src,
+                                 float* const* dx, void* stream);
 int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* dy, const float* wb, const float* scale,
                              const float* mask_src, const float* add_src, float* dx, float* workspace,
                              int64_t workspace_floats, void* stream);

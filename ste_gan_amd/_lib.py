@@ -69,6 +69,8 @@ SIGNATURES = {
     "stegan_add_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, C.c_float, _P],
     "stegan_add_layernorm_bwd": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stegan_adamw_step": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P],
+    "stegan_conv1d_fwd_multi": [_I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_data_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],

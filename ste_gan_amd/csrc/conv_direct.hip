@@ -209,7 +209,7 @@ __device__ __forceinline__ Taps phase_taps(const DirP& p, int phase) {
 // TAPG: tap groups (p.NTG > 1) -- compiled separately so the common all-taps-in-one-chunk kernels keep their straight-line
 // DMA issue (a data-dependent branch around the X-tile DMA costs every chunk of every layer otherwise).
 template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false, bool TAPG = false>
-__global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
+__device__ __forceinline__ void conv_direct_body(const DirP& p, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
     constexpr int BN = W14 ? 128 : 64 * TN;
     constexpr int BM = 64 * TM;                 // 2x2 waves, wave tile (32*TM) x (32*TN)
     constexpr int WEt = WE * TM;                // W-tile float4 per thread and chunk
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef STEGAN_STAMPS
-#define STAMP(i_) if (p.stamps && tid == 0) p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#define STAMP(i_) if (p.stamps && tid == 0) p.stamps[((size_t)(bid_z * gridDim.y + bid_y) * gridDim.x + bid_x) * 8 + (i_)] = __builtin_amdgcn_s_memtime();
 #else
 #define STAMP(i_)
 #endif
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
                  "s"(p.NSEG), "s"(p.XROW), "s"(p.WR), "s"(p.U0), "s"(p.splits), "s"(p.chunks_per_split), "s"(p.mix_S),
                  "s"(p.mix_full), "s"(p.nbx), "s"(p.ny), "s"(p.ups), "s"(p.in_relu));
     const int wm = W14 ? 0 : wave >> 1, wn = W14 ? wave : wave & 1;
-    int bx = blockIdx.x, by = blockIdx.y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
+    int bx = (int)bid_x, by = (int)bid_y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
     if (p.mix_S) {
         int tile = bx;
         split = 0; nsplits = 1;
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
         phase = (int)fd_div((uint32_t)rest, p.fdNY);
         by = rest - phase * p.ny;
     } else {
-        phase = (int)fd_div(blockIdx.z, p.fdSP);
-        split = blockIdx.z - phase * p.splits;
+        phase = (int)fd_div(bid_z, p.fdSP);
+        split = (int)bid_z - phase * p.splits;
     }
     const int g = (int)fd_div((uint32_t)by, p.fdMT);
     const int m0 = (by - g * p.m_tiles) * BM;
@@ -595,6 +595,33 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
 #undef STAMP
 }
 
+template <int TM, int TN, bool FAST, bool XVEC, bool W14 = false, bool TAPG = false>
+__global__ __launch_bounds__(256) void conv_direct_kernel(const DirP p) {
+    conv_direct_body<TM, TN, FAST, XVEC, W14, TAPG>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Multi-problem launch: up to MAX_MULTI independent convolutions that share a kernel variant (the same layer of the
+// period discriminators: one channel structure, different weights, batch and length) in ONE grid -- their ~6 us of
+// per-launch fixed cost is paid once and the blocks of all problems fill the CUs together.  Every problem runs in the
+// 1-D "tail split" decode with no split tiles (mix_full = all its tiles).
+constexpr int MAX_MULTI = 5;
+struct MultiP {
+    int n;
+    int first[MAX_MULTI + 1];       // first linear block of each problem
+    DirP p[MAX_MULTI];
+};
+
+static_assert(sizeof(MultiP) <= 4096, "kernel argument segment limit");
+
+template <bool FAST, bool XVEC>
+__global__ __launch_bounds__(256) void conv_direct_multi_kernel(const MultiP a) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_MULTI; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.first[i]) pi = i;
+    conv_direct_body<1, 1, FAST, XVEC, false, false>(a.p[pi], blockIdx.x - a.first[pi], 0, 0);
+}
+
 // ---- weight transposition: v (Cout, Cin_g, K) -> Wf[g][k][ci][co_pad], Wb[g][k][co][ci_pad]
 __global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict__ v, const float* __restrict__ scale,
                                                         float* __restrict__ wf, float* __restrict__ wb, int Cout_g,
@@ -783,8 +810,16 @@ static int choose_splits(long base_blocks, int nchunks, double chunk_cost = 1.0,
 }
 
 // returns 1 when the v2 kernel cannot take this shape (caller falls back to the generic implicit-GEMM kernel)
+struct MultiCollect {             // host side of a multi-problem launch being assembled
+    MultiP mp;
+    bool fast, xvec;
+    bool allow_xvec;              // false when some problem's rows are not float4 aligned: all use the 4-byte X DMA
+    size_t lds;
+    long blocks;
+};
+
 static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* workspace, int64_t workspace_floats,
-                         hipStream_t s) {
+                         hipStream_t s, MultiCollect* mc = nullptr) {
     int k_lo, k_hi;
     const int K_eff = live_taps(d, k_lo, k_hi);
     if (K_eff <= 0) return STEGAN_E_ARG;
@@ -819,6 +854,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     // and the halo'd X tile of a channel chunk is staged once and reused by its NTG tap groups.
     int TG = ntaps_max, NTG = 1;
     const int span_all = span_off;
+    if (mc && ntaps_max > 8) return 1;                  // multi-problem launches: plain variants only
     if (ntaps_max > 8 && !getenv("STEGAN_NO_TAPGROUPS")) {
         const int pad8 = ceil_div(ntaps_max, 8) * 8, pad4 = ceil_div(ntaps_max, 4) * 4;
         TG = pad4 < pad8 ? 4 : 8;
@@ -833,10 +869,11 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
     // 16-byte X DMA needs float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
     const bool xvec = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
-                      !getenv("STEGAN_NO_XVEC");
+                      !getenv("STEGAN_NO_XVEC") && (!mc || mc->allow_xvec);
     if (ntaps_max > MAX_TAPS) return 1;
-    Geo gm = plan_geo(TG, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec);
+    Geo gm = plan_geo(TG, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec, mc ? 64 : 0);
     if (!gm.ok) return 1;
+    // (narrow problems join a multi launch in the plain 2 x 2 layout: tiny layers, the shared fixed cost matters more)
     if (NTG > 1 && gm.CC < 8) {                        // X tile too wide for 8 channels: back to all taps in one chunk
         TG = ntaps_max; NTG = 1;
         span_off = span_all;
@@ -848,7 +885,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     // for 8-channel tap groups the layer keeps W14 with all taps in one chunk (generic loop).
     static const char* no_w14 = getenv("STEGAN_NO_W14");
     bool w14 = false;
-    if (!no_w14 && p.M_g <= 32) {
+    if (!mc && !no_w14 && p.M_g <= 32) {
         Geo g2 = plan_geo(TG, span_off, cs, U, U_min, N, (long)d->groups * phases, xvec, 128);
         if (g2.ok && (NTG == 1 ? g2.CC >= gm.CC : g2.CC >= 8)) { gm = g2; w14 = true; }
         else if (NTG > 1) {
@@ -872,7 +909,8 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     // measured (scripts/conv_microbench.py): 128-row tiles win only on the small-N layers (few output tiles, deep
     // reductions); with plenty of tiles the smaller LDS footprint of 64-row tiles (3 resident blocks per CU) wins
     const long base1 = nb * ceil_div(p.M_g, 64) * d->groups * phases;
-    if (!w14 && NTG == 1 && fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
+    if (mc) splits = 1;
+    if (!mc && !w14 && NTG == 1 && fast && gm.BN == 64 && p.M_g % 128 == 0 && ((!env_tm && base1 <= 288) || (env_tm && atoi(env_tm) == 2))) {
         const int s2 = choose_splits(nb * (p.M_g / 128) * d->groups * phases, nchunks, 1.7, &cost2);
         tm = 2; splits = s2;
     }
@@ -895,7 +933,9 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         static const char* no_tail = getenv("STEGAN_NO_TAILSPLIT");
         const long tiles = nb * p.ny * phases;
         const long q = tiles / 256, r = tiles % 256;
-        if (!no_tail && tm == 1 && gm.BN == 64 && q >= 2 && q <= 8 && r > 0 && nchunks >= 4 && workspace &&
+        if (mc) {                                              // 1-D decode, every tile whole
+            p.mix_S = 1; p.mix_full = (int)tiles; p.mix_cps = nchunks;
+        } else if (!no_tail && tm == 1 && gm.BN == 64 && q >= 2 && q <= 8 && r > 0 && nchunks >= 4 && workspace &&
             workspace_floats >= 2 * out_elems && tiles < (1L << 30)) {
             long S = 256 / r;
             if (S < 2) S = 2;
@@ -935,6 +975,17 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
         p.ph_ntaps[ph] = t.ntaps; p.ph_kbase[ph] = t.kbase; p.ph_kstep[ph] = t.kstep; p.ph_offmin[ph] = t.off_min;
         p.ph_step[ph] = t.step;
         p.ph_U[ph] = mode == 0 ? U : (p.Tdst - ph + d->stride - 1) / d->stride;
+    }
+    if (mc) {
+        MultiP& mp = mc->mp;
+        if (mp.n >= MAX_MULTI) return 1;
+        if (mp.n == 0) { mc->fast = fast; mc->xvec = xvec; mc->lds = gm.lds; mc->blocks = 0; mp.first[0] = 0; }
+        else if (mc->fast != fast || mc->xvec != xvec) return 1;
+        if (gm.lds > mc->lds) mc->lds = gm.lds;
+        mp.p[mp.n] = p;
+        mc->blocks += nb * p.ny * phases;
+        mp.first[++mp.n] = (int)mc->blocks;
+        return STEGAN_OK;
     }
     dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
     const long tail_tiles = p.mix_S ? nb * p.ny * phases - p.mix_full : 0;
@@ -1004,6 +1055,81 @@ extern "C" int stegan_conv1d_fwd_t(const stegan_conv_desc* d, const float* x, co
     p.zero_off = (long)d->groups * d->K * p.C2_g * p.LD;
     p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
     return launch_direct(d, 0, p, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+static int launch_multi(MultiCollect& mc, hipStream_t s) {
+    dim3 grid((unsigned)mc.blocks);
+    if (mc.fast) {
+        if (mc.xvec) hipLaunchKernelGGL((conv_direct_multi_kernel<true, true>), grid, dim3(256), mc.lds, s, mc.mp);
+        else hipLaunchKernelGGL((conv_direct_multi_kernel<true, false>), grid, dim3(256), mc.lds, s, mc.mp);
+    } else {
+        if (mc.xvec) hipLaunchKernelGGL((conv_direct_multi_kernel<false, true>), grid, dim3(256), mc.lds, s, mc.mp);
+        else hipLaunchKernelGGL((conv_direct_multi_kernel<false, false>), grid, dim3(256), mc.lds, s, mc.mp);
+    }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_data_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                            const float* const* wb, const float* const* mask_src,
+                                            const float* const* add_src, float* const* dx, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= MAX_MULTI && descs && dy && wb && dx);
+    MultiCollect mc;
+    mc.mp.n = 0;
+    mc.allow_xvec = true;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i] || descs[i]->Tout % 4 != 0 || ((uintptr_t)dy[i] % 16) != 0) mc.allow_xvec = false;
+    for (int i = 0; i < n; ++i) {
+        const stegan_conv_desc* d = descs[i];
+        int rc = check_desc(d);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(dy[i] && wb[i] && dx[i]);
+        const float* mk = mask_src ? mask_src[i] : nullptr;
+        STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mk);
+        DirP p;
+        p.src = dy[i]; p.wt = wb[i]; p.scale = nullptr; p.bias = nullptr; p.res = add_src ? add_src[i] : nullptr; p.out = dx[i];
+        p.mask = d->in_act == STEGAN_ACT_RELU ? mk : nullptr;
+        p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
+        p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
+        p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = round_up(p.M_g, 64);
+        p.zero_off = (long)d->groups * d->K * p.C2_g * p.LD;
+        p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
+        rc = launch_direct(d, 1, p, nullptr, 0, (hipStream_t)stream, &mc);
+        if (rc) return rc;
+    }
+    return launch_multi(mc, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_fwd_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                       const float* const* wf, const float* const* scale, const float* const* bias,
+                                       const float* const* residual, float* const* y, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= MAX_MULTI && descs && x && wf && y);
+    MultiCollect mc;
+    mc.mp.n = 0;
+    mc.allow_xvec = true;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i] || descs[i]->Tin % 4 != 0 || descs[i]->upsample != 1 || ((uintptr_t)x[i] % 16) != 0) mc.allow_xvec = false;
+    for (int i = 0; i < n; ++i) {
+        const stegan_conv_desc* d = descs[i];
+        int rc = check_desc(d);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(x[i] && wf[i] && y[i]);
+        STEGAN_CHECK_ARG(d->in_act == STEGAN_ACT_NONE || d->in_act == STEGAN_ACT_RELU);
+        STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
+        const float* res = residual ? residual[i] : nullptr;
+        STEGAN_CHECK_ARG(!(d->out_btc && res));
+        DirP p;
+        p.src = x[i]; p.wt = wf[i]; p.scale = scale ? scale[i] : nullptr; p.bias = bias ? bias[i] : nullptr; p.res = res;
+        p.mask = nullptr; p.out = y[i];
+        p.Csrc = d->Cin; p.Cdst = d->Cout; p.Tsrc = d->Tin; p.Tq = d->Tin * d->upsample; p.Tdst = d->Tout;
+        p.Tmask = 0; p.ups = d->upsample == 2 ? 1 : 0;
+        p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = round_up(p.M_g, 64);
+        p.zero_off = (long)d->groups * d->K * p.C2_g * p.LD;
+        p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
+        rc = launch_direct(d, 0, p, nullptr, 0, (hipStream_t)stream, &mc);
+        if (rc) return rc;                               // 1: not expressible as one launch, caller launches one by one
+    }
+    return launch_multi(mc, (hipStream_t)stream);
 }
 
 extern "C" int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* dy, const float* wb, const float* scale,

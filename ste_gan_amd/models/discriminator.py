@@ -134,12 +134,27 @@ class _MultiDisc(nn.Module):
         (Running the eight sub-discriminators on separate HIP streams was measured and rejected: 31.3 vs 29.0 ms/step
         inside the captured graph -- the convs already split their reductions to fill the chip, so concurrent
         kernels only compete for LDS and matrix pipes.)"""
-        results = [disc(x) for disc in self.multi_pooled_disc]
+        results = self._pooled_forward(x)
         xs = ops.btc_to_bct(x)
         for disc in self.multi_scale_disc:
             results.append(disc(xs))
             xs = ops.avgpool421(xs)            # the reference also pools once more after the last scale
         return results
+
+    def _pooled_forward(self, x):
+        """The period discriminators layer by layer: layer L of all of them is one multi-problem launch
+        (``ops.wn_conv1d_multi``) -- same channel structure, own weights / batch (B * period) / length each."""
+        discs = list(self.multi_pooled_disc)
+        B = x.shape[0]
+        hs = [ops.mpd_fold(x, d.period) for d in discs]
+        fmaps = [[] for _ in discs]
+        depth = len(discs[0].layers) + 1
+        for L in range(depth):
+            convs = [d.layers[L] if L < depth - 1 else d.output for d in discs]
+            hs = ops.wn_conv1d_multi(hs, convs)
+            for f, h, d in zip(fmaps, hs, discs):
+                f.append(_unfold_view(h, B, d.period))
+        return fmaps
 
     def forward_pair(self, x_a, x_b):
         """``(self(x_a), self(x_b))`` -- the discriminator step's fake and real passes (train.py:190-191) -- with every
@@ -150,8 +165,7 @@ class _MultiDisc(nn.Module):
         n = x_a.shape[0]
         both = torch.cat([x_a, x_b], 0)
         res_a, res_b = [], []
-        for disc in self.multi_pooled_disc:
-            fm = disc(both)
+        for fm in self._pooled_forward(both):
             res_a.append([f[:n] for f in fm]); res_b.append([f[n:] for f in fm])
         xs = ops.btc_to_bct(both)
         for i, disc in enumerate(self.multi_scale_disc):

@@ -299,6 +299,109 @@ class _WNConvFn(torch.autograd.Function):
         return dx, dv, dg, db, dres, None, None, None
 
 
+def _ptr_array(items):
+    return (C.c_void_p * len(items))(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in items])
+
+
+def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
+    """Up to five forward convs that share a kernel variant in ONE launch (stegan_conv1d_fwd_multi); None when the
+    library says they cannot share one (the caller then launches them one by one)."""
+    n = len(xs)
+    xs = [_gpu_f32(x, "x") for x in xs]
+    ys, descs = [], []
+    for x, cfg in zip(xs, cfgs):
+        B, _, tin = x.shape
+        tout = cfg.tout(tin)
+        ys.append(torch.empty((B, cfg.cout, tout), device=x.device, dtype=torch.float32))
+        descs.append(_desc(cfg, B, tin, tout))
+    dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    rc = _lib.lib().stegan_conv1d_fwd_multi(n, dptr, _ptr_array(xs), _ptr_array(wfs), _ptr_array(scales), _ptr_array(biases),
+                                            None, _ptr_array(ys), _stream())
+    if rc == 1:
+        return None
+    check(rc, "stegan_conv1d_fwd_multi")
+    return ys
+
+
+def conv1d_bwd_data_multi(dys, cfgs, wbs, tins):
+    n = len(dys)
+    dys = [_gpu_f32(t, "dy") for t in dys]
+    dxs, descs = [], []
+    for dy, cfg, tin in zip(dys, cfgs, tins):
+        B, _, tout = dy.shape
+        dxs.append(torch.empty((B, cfg.cin, tin), device=dy.device, dtype=torch.float32))
+        descs.append(_desc(cfg, B, tin, tout))
+    dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    rc = _lib.lib().stegan_conv1d_bwd_data_multi(n, dptr, _ptr_array(dys), _ptr_array(wbs), None, None, _ptr_array(dxs),
+                                                 _stream())
+    if rc == 1:
+        return None
+    check(rc, "stegan_conv1d_bwd_data_multi")
+    return dxs
+
+
+class _WNConvMultiFn(torch.autograd.Function):
+    """The same layer of several sub-discriminators (one channel structure; own weights, batch and length each) as ONE
+    autograd node: forward and input gradient are single multi-problem launches when the library can share a kernel
+    variant across them, per-problem launches otherwise.  ``layers`` = [(v, g, bias, cfg, (scale, wf, wb), sink)]."""
+
+    @staticmethod
+    def forward(ctx, layers, n, *ts):
+        xs = ts[:n]
+        cfgs = [l[3] for l in layers]
+        ys = None
+        if PROFILER is None and all(c.upsample == 1 and not c.out_btc for c in cfgs):
+            ys = conv1d_fwd_multi(xs, cfgs, [l[4][1] for l in layers], [l[4][0] for l in layers], [l[2] for l in layers])
+        if ys is None:
+            ys = [conv1d_fwd(x, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], l[2], None, l[3], l[4][1])
+                  for x, l in zip(xs, layers)]
+        ctx.layers, ctx.n = layers, n
+        ctx.wgrad = any(ctx.needs_input_grad[2 + n:])
+        ctx.save_for_backward(*xs, *ys)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, layers = ctx.n, ctx.layers
+        saved = ctx.saved_tensors
+        xs, ys = saved[:n], saved[n:]
+        gs = []
+        for dy, y, l in zip(dys, ys, layers):
+            g = _gpu_f32(dy, "grad_output")
+            gs.append(act_bwd(g, y, l[3].out_act) if l[3].out_act != ACT_NONE else g)
+        if ctx.wgrad:
+            for x, g, l in zip(xs, gs, layers):
+                if l[5] is not None:
+                    conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None)
+        dxs = [None] * n
+        need = [ctx.needs_input_grad[2 + i] for i in range(n)]
+        if any(need):
+            cfgs = [l[3] for l in layers]
+            out = None
+            if PROFILER is None and all(need):
+                out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs])
+            if out is None:
+                out = [conv1d_bwd_data(g, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], None, None, l[3],
+                                       x.shape[2], l[4][2]) if nd else None for g, x, l, nd in zip(gs, xs, layers, need)]
+            dxs = out
+        return (None, None, *dxs, *([None] * (len(ctx.needs_input_grad) - 2 - n)))
+
+
+def wn_conv1d_multi(xs, convs):
+    """convs: one WNConv1d per input (same layer of several sub-discriminators).  Falls back to per-module calls when a
+    conv needs weight gradients but has no gradient sink."""
+    grad = torch.is_grad_enabled()
+    needs_w = grad and any(c.weight_v.requires_grad for c in convs)
+    if needs_w and any(c._pack is None for c in convs):
+        return [c(x) for c, x in zip(convs, xs)]
+    layers, params = [], []
+    for c in convs:
+        sink = (c._pack[4], c.bias.grad) if (needs_w and c._pack is not None) else None
+        layers.append((c.weight_v, c.weight_g, c.bias, c.cfg, c.prepared(), sink))
+        params += [c.weight_v, c.weight_g, c.bias]
+    return list(_WNConvMultiFn.apply(layers, len(xs), *xs, *params))
+
+
 def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None) -> Tensor:
     """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None;
     sink = (raw dw arena slice, bias-gradient view) switches the backward to fused accumulation (optim.ConvPack)."""

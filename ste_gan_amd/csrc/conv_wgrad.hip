@@ -192,9 +192,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             a_ = arow[4 * (j_)];                                                                               \
             _Pragma("unroll") for (int k = 0; k < KT; ++k) b_[k] = xrow[xo[j_] + k * p.dil];                   \
         }
+#ifdef WG_EXP_NORELU
+#define WG_BVAL(x_) (x_)
+#else
+#define WG_BVAL(x_) floor_max(x_, relu_floor)
+#endif
 #define WG_MFMA(a_, b_)                                                                                        \
         _Pragma("unroll") for (int k = 0; k < KT; ++k)                                                         \
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, floor_max(b_[k], relu_floor), acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_, WG_BVAL(b_[k]), acc[k], 0, 0, 0);
 #ifndef WG_EXP_NOMFMA
         WG_OPS(a0, b0, 0)
 #pragma unroll
@@ -306,7 +311,12 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
     p.Te = d->Tin * d->upsample; p.ups = d->upsample == 2 ? 1 : 0; p.relu = d->in_act == STEGAN_ACT_RELU;
     // mostly-empty MFMA tiles (narrow groups) and single-tap convs (one MFMA per operand pair read): the generic kernel,
     // which packs (ci, k) densely along N, measured faster there (scripts/conv_microbench.py)
-    if (p.Cout_g < 64 || p.Cin_g < 64) return 1;
+    {
+        static const char* e1 = getenv("STEGAN_WG_MIN_CIN");
+        static const char* e2 = getenv("STEGAN_WG_MIN_COUT");
+        const int min_cin = e1 ? atoi(e1) : 64, min_cout = e2 ? atoi(e2) : 64;
+        if (p.Cout_g < min_cout || p.Cin_g < min_cin) return 1;
+    }
     p.K_eff = wg_live_taps(d, p.k_lo);
     if (p.K_eff <= 1) return 1;
     const int KT = p.K_eff <= 1 ? 1 : p.K_eff <= 3 ? 3 : p.K_eff <= 5 ? 5 : 8;
@@ -355,6 +365,10 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
         const double eff = load >= 3 ? 1.0 : load == 2 ? 0.8 : 0.55;      // few resident waves hide little latency
         const double cost = (double)load * (cps + 3.0) / eff + (sp > 1 ? sp * (double)p.dw_numel * 1.3e-6 : 0.0);
         if (cost < best - 1e-9) { best = cost; want = sp; }
+    }
+    {
+        static const char* env = getenv("STEGAN_WG_SPLITS");        // experiment: force the slice count
+        if (env && p.partial) { want = atol(env); if (want > max_splits) want = max_splits; if (want < 1) want = 1; }
     }
     p.chunks_per_block = ceil_div(p.total_chunks, (int)want);
     const int splits = ceil_div(p.total_chunks, p.chunks_per_block);

@@ -100,6 +100,7 @@ class GANTrainStep:
             self.optD.finalize_grads()
             out["discriminator"] = loss_D.detach()
             if self.comm is not None:
+                self.optD.flat.gather_grads()      # any gradient autograd did not write through its arena view
                 d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
 
         # ---- D-independent generator losses first: they overlap the D-gradient all-reduce
@@ -149,6 +150,7 @@ class GANTrainStep:
             self._set_d_grad(True)
         self.optG.finalize_grads()
         if self.comm is not None:
+            self.optG.flat.gather_grads()
             self.comm.wait(self.comm.launch(self.optG.flat.grad))
             self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
         else:

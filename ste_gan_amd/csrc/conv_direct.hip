@@ -9,18 +9,24 @@
 //              (phi + pad - k*dil) % stride == 0 contribute, off[k] = (phi+pad-k*dil)/stride, cs = 1,
 //              to(u) = phi + u*stride  -> a strided conv's input gradient costs no wasted MACs (grid.z = phase)
 //
-// Per block (256 threads = 2x2 wave64, tile 64 (m) x BN (n = flattened (b,u)), BN = 64 or 128):
-//   * for a chunk of CC source channels, every (channel, batch-segment) input row the tile needs is copied ONCE,
-//     with its halo, into LDS (coalesced along time; zero padding, ReLU, nearest-x2 upsample and the per-channel
-//     dy scale are applied on the way in) -- each sample is read from HBM/L2 once per chunk instead of K times and
-//     the per-element index arithmetic of an im2col gather disappears (the lane -> source offsets are chunk
-//     invariant and live in registers);
+// Per block (256 threads = 2x2 wave64, tile 64 or 128 (m) x 64 or 128 (n = flattened (b,u)); narrow groups: 1x4 waves,
+// tile 32 x 128):
+//   * for a chunk of CC source channels, every (channel, batch-segment) input row the tile needs is copied ONCE, with
+//     its halo, into LDS by LDS-DMA (global_load_lds, 16 B per lane where rows are float4 aligned): zero padding, dead
+//     rows and the nearest-x2 upsample are resolved by the per-lane source address (a zero row sits behind the
+//     transposed weights), the input ReLU is one v_max at the operand read, the per-channel dy scale is folded into the
+//     transposed weights -- each sample is read from HBM/L2 once per chunk instead of K times and the per-element index
+//     arithmetic of an im2col gather disappears (the lane -> source offsets are chunk invariant and live in registers);
 //   * the weight tile comes from a K-major, output-channel-contiguous copy of the direction tensor
 //     (stegan_conv_prep: Wf[g][k][ci][co], Wb[g][k][co][ci], leading dimension padded to 64) so staging is a
 //     pure 16-byte-per-lane copy into an unpadded [row][64] LDS image;
-//   * v_mfma_f32_32x32x2_f32 operands: A = Ws[row][m] (32 consecutive dwords per half-wave), B = Xs[xoff[row] +
-//     colbase(lane)] where xoff[row] = channel*XROW + tap offset comes from a small LDS table -- the tap shift is
-//     just an address offset into the halo'd row.
+//   * v_mfma_f32_32x32x2_f32 operands: A = Ws[row][m] (32 consecutive dwords per half-wave), B = Xs[channel * XROW +
+//     tap * step + colbase(lane)] -- the live taps form an arithmetic progression, so the tap shift is a computed
+//     address offset into the halo'd row (no tables);
+//   * two LDS buffers, one barrier per chunk; many-tap layers use tap groups (TG taps x 64/TG channels per W chunk, the X
+//     tile staged once per channel chunk); small grids split the reduction (uniform split-K, or only the tail tiles
+//     beyond a multiple of the CU count) with a fixed-order epilogue kernel; up to five independent problems can share
+//     one launch (MultiP).  DESIGN.md section 4.1 has the measurements behind each of these.
 #include <stdio.h>
 #include <stdlib.h>
 

@@ -150,8 +150,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # STEGAN_BENCH_BACKEND=gloo + STEGAN_BENCH_ONE_GPU=1: the multi-rank rehearsal of tests/test_gpu_bench_ddp.py
+        # (several ranks on ONE card, host-staged all-reduce); the driver's runs use RCCL, one rank per GPU
+        if os.environ.get("STEGAN_BENCH_ONE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("STEGAN_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
@@ -185,18 +193,22 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stats = step.read_stats(step.last)
 
     # ---- roofline of the dominant kernel: instrumented pass, HIP events around every conv launch
+    # EVERY rank runs the instrumented steps: under torch.distributed each of them carries the two gradient
+    # all-reduces, and a collective that only rank 0 enters never completes.  Only rank 0 reports.
     roof = None
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
         ops.PROFILER = ops.ConvProfiler()
         for _ in range(args.profile_steps):
             eager_step(batch)                              # instrumented pass: eager launches, HIP events per conv
         agg = ops.PROFILER.summary()
+        barrier()
+    if rank == 0 and args.profile_steps > 0:
         if os.environ.get("STEGAN_BENCH_DETAIL"):
             by = ops.profiler_by_shape(ops.PROFILER)
             print("mode B Cin Cout K s d g up Tin Tout | launches/step ms/step TFLOP/s", file=sys.stderr)

@@ -28,8 +28,13 @@ class DeviceLoader:
     """Iterable over one partition of a resident corpus (``len()`` = batches per epoch, like a DataLoader)."""
 
     def __init__(self, store: UtteranceStore, partition: str, batch_size: int, emg_train_length: int,
-                 hopsize: int = K.HOPSIZE, hop_aligned_emg: bool = False):
+                 hopsize: int = K.HOPSIZE, hop_aligned_emg: bool = False, rank: int = 0, world_size: int = 1):
         check_partition(partition)
+        if not (0 <= rank < world_size):
+            raise ValueError(f"rank {rank} outside world of {world_size}")
+        self.rank, self.world_size = rank, world_size          # data-parallel shard of the TRAIN partition (see plan_epoch)
+        self.session_id_to_idx: Optional[Dict] = None           # set by loaders(): the id maps the reference dumps as JSON
+        self.speaking_mode_id_to_idx: Optional[Dict] = None
         if batch_size < 1:
             raise ValueError(f"batch_size should be a positive integer value, but got batch_size={batch_size}")
         self.store, self.partition, self.hopsize = store, partition, hopsize
@@ -40,19 +45,29 @@ class DeviceLoader:
         self.n_emg = self.n_frames * hopsize if hop_aligned_emg else emg_train_length
 
     def __len__(self) -> int:
-        return (len(self.store) + self.batch_size - 1) // self.batch_size   # DataLoader default drop_last=False
+        n, gb = len(self.store), self.batch_size * self._shards()
+        full, rem = divmod(n, gb)
+        return full + (1 if rem >= self._shards() else 0)                   # world 1: DataLoader default drop_last=False
+
+    def _shards(self) -> int:
+        return self.world_size if self.partition == "train" else 1
 
     def epoch_plan(self):
-        """Host lists (utterance order, start frames) for one epoch, in the RNG order of sampler then collate."""
-        n = len(self.store)
-        if self.partition == "train":
-            order = torch.randperm(n).tolist()                             # RandomSampler (loader.py:50)
-            starts: List[int] = []
-            for i in range(0, n, self.batch_size):                         # one collate call per batch
-                starts += draw_start_frames([self.store.frames[u] for u in order[i:i + self.batch_size]], self.n_frames)
-        else:
-            order, starts = list(range(n)), [0] * n
-        return order, starts
+        """Host lists (utterance order, start frames) of THIS rank for one epoch (see :func:`plan_epoch`)."""
+        return plan_epoch(self.store.frames, self.partition, self.batch_size, self.n_frames, self.rank, self._shards())
+
+    def save_session_and_speaking_mode_mapping_json(self, save_dir) -> None:
+        """``session_idx_to_id.json`` / ``speaking_mode_idx_to_id.json`` as the reference's train data set writes them
+        (emg_dataset.py:202-217; train.py:121-122): the reference's eval / generate scripts read them back."""
+        import json
+        if self.session_id_to_idx is None or self.speaking_mode_id_to_idx is None:
+            raise RuntimeError("this loader was not built from a corpus directory: no session / speaking-mode id maps")
+        for name, m in (("session_idx_to_id.json", self.session_id_to_idx),
+                        ("speaking_mode_idx_to_id.json", self.speaking_mode_id_to_idx)):
+            path = Path(save_dir) / name
+            logging.info(f"Saving {name[:-5]} to {path}")
+            with open(path, "w") as fp:
+                json.dump({idx: key for key, idx in m.items()}, fp)
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         st = self.store
@@ -66,6 +81,36 @@ class DeviceLoader:
         for i in range(0, len(order), self.batch_size):
             yield st.assemble(plan[0, i:i + self.batch_size], plan[1, i:i + self.batch_size], self.n_frames, self.n_emg,
                               self.hopsize, validate=False)
+
+
+def plan_epoch(frames: Sequence[int], partition: str, batch_size: int, n_frames: int, rank: int = 0, world_size: int = 1):
+    """(utterance order, start frames) one rank walks in one epoch; host-only, uses the global torch RNG.
+
+    world_size 1: the reference's RNG order -- ``RandomSampler``'s permutation (loader.py:50), then one ``torch.randint``
+    per utterance in batch order (collate.py:118-121).  world_size N (train partition only): EVERY rank draws that same
+    full plan for a global batch of N * batch_size (the ranks seed their RNG identically and consume it identically, so
+    they stay in lockstep by construction) and keeps rows [rank * batch_size, (rank + 1) * batch_size) of every global
+    batch: together the ranks see exactly the batches a single process with batch N * batch_size would.  A trailing
+    partial global batch is split evenly (rows beyond a multiple of N are dropped, and the whole remainder when it has
+    fewer than N rows) so that all ranks take the same number of steps -- each step carries a collective."""
+    n = len(frames)
+    if partition != "train":
+        return list(range(n)), [0] * n
+    order = torch.randperm(n).tolist()
+    gb = batch_size * world_size
+    starts: List[int] = []
+    for i in range(0, n, gb):                                              # one collate call per (global) batch
+        starts += draw_start_frames([frames[u] for u in order[i:i + gb]], n_frames)
+    if world_size == 1:
+        return order, starts
+    my_order, my_starts = [], []
+    for i in range(0, n, gb):
+        rows = min(gb, n - i)
+        per = batch_size if rows == gb else rows // world_size
+        lo = i + rank * per
+        my_order += order[lo:lo + per]
+        my_starts += starts[lo:lo + per]
+    return my_order, my_starts
 
 
 # ---------------------------------------------------------------------------------------------
@@ -142,10 +187,11 @@ def check_no_data_overlap(utt_id_lists: Sequence[Sequence[str]]) -> None:
 
 def loaders_from_samples(train_samples, valid_samples, test_samples, batch_size: int = K.BATCH_SIZE,
                          train_emg_length: int = K.TRAIN_EMG_LENGTH, hopsize: int = K.HOPSIZE, device="cuda",
-                         hop_aligned_emg: bool = False):
-    """(train, valid, test) DeviceLoaders over three lists of sample dicts (each uploaded once)."""
+                         hop_aligned_emg: bool = False, rank: int = 0, world_size: int = 1):
+    """(train, valid, test) DeviceLoaders over three lists of sample dicts (each uploaded once).  ``rank`` /
+    ``world_size`` shard the train partition's epoch plan (:func:`plan_epoch`); valid / test stay whole."""
     mk = lambda samples, part: DeviceLoader(UtteranceStore(samples, device), part, batch_size, train_emg_length, hopsize,
-                                            hop_aligned_emg)
+                                            hop_aligned_emg, rank, world_size)
     return mk(train_samples, "train"), mk(valid_samples, "valid"), mk(test_samples, "test")
 
 
@@ -171,7 +217,7 @@ def _packed_partition(data_root, partition, shard_dir, s2i, m2i, **kw):
 
 def loaders(data_root: Path, strict=False, chunksize: int = K.CHUNK_SIZE, hopsize: int = K.HOPSIZE,
             train_emg_length: int = K.TRAIN_EMG_LENGTH, batch_size: int = K.BATCH_SIZE, device="cuda",
-            hop_aligned_emg: bool = False, shard_dir=None):
+            hop_aligned_emg: bool = False, shard_dir=None, rank: int = 0, world_size: int = 1):
     """loader.py:19-90 over resident stores.  ``shard_dir``: cache each partition as one packed, memory-mappable shard
     file (``collate.save_packed``) and start from it when present (the selection parameters are baked into a shard:
     use a fresh directory per ``train_emg_length`` / filter setting)."""
@@ -182,10 +228,13 @@ def loaders(data_root: Path, strict=False, chunksize: int = K.CHUNK_SIZE, hopsiz
     te, te_ids, _, _ = _packed_partition(data_root, "test", shard_dir, s2i, m2i, filter_by_length=False, strict=strict,
                                          train_emg_length=train_emg_length)
     check_no_data_overlap([tr_ids, va_ids, te_ids])
-    return loaders_from_samples(tr, va, te, batch_size, train_emg_length, hopsize, device, hop_aligned_emg)
+    out = loaders_from_samples(tr, va, te, batch_size, train_emg_length, hopsize, device, hop_aligned_emg, rank, world_size)
+    for ld in out:
+        ld.session_id_to_idx, ld.speaking_mode_id_to_idx = s2i, m2i
+    return out
 
 
-def loaders_via_config(cfg, device="cuda", hop_aligned_emg: bool = True):
+def loaders_via_config(cfg, device="cuda", hop_aligned_emg: bool = True, rank: int = 0, world_size: int = 1):
     """loader.py:92-109 (``train_emg_length = chunk_size``: no autoregressive extra input).
 
     ``hop_aligned_emg`` (default on for the trainer's loaders): a chunk size that is not a multiple of the hop (the
@@ -196,4 +245,4 @@ def loaders_via_config(cfg, device="cuda", hop_aligned_emg: bool = True):
     chunksize = cfg.train.chunk_size
     return loaders(data_root=Path(cfg.data.dataset_root), strict=cfg.data.strict, chunksize=chunksize, hopsize=K.HOPSIZE,
                    train_emg_length=chunksize, batch_size=cfg.train.batch_size, device=device,
-                   hop_aligned_emg=hop_aligned_emg)
+                   hop_aligned_emg=hop_aligned_emg, rank=rank, world_size=world_size)

@@ -392,7 +392,8 @@ def wn_conv1d_multi(xs, convs):
     conv needs weight gradients but has no gradient sink."""
     grad = torch.is_grad_enabled()
     needs_w = grad and any(c.weight_v.requires_grad for c in convs)
-    if needs_w and any(c._pack is None for c in convs):
+    # the multi node's backward passes no ReLU mask and no residual: only plain convs (in_act NONE) take this path
+    if any(c.cfg.in_act != ACT_NONE for c in convs) or (needs_w and any(c._pack is None for c in convs)):
         return [c(x) for c, x in zip(convs, xs)]
     layers, params = [], []
     for c in convs:

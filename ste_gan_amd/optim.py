@@ -272,17 +272,29 @@ class FusedAdamW:
 
 
 class ExponentialLR:
-    """lr = initial_lr * gamma^epoch, stepped per epoch -- train.py:98-104,470-472."""
+    """``torch.optim.lr_scheduler.ExponentialLR`` as the reference uses it (train.py:98-104,470-472): stepped per epoch,
+    and CHAINED from the group's current lr like torch's -- ``step()`` multiplies ``param_groups[0]["lr"]`` by gamma,
+    except for the very first call of a fresh schedule (``last_epoch`` -1 -> 0), which leaves the initial lr in place.
+    On resume (``last_epoch = start_epoch``) the constructor's own step therefore yields loaded_lr * gamma, exactly what
+    the reference's pinned torch 2.0.1 computes from a loaded optimiser state (``get_lr``: ``group["lr"]`` if
+    ``last_epoch == 0`` else ``group["lr"] * gamma``), so ``checkpoint-*.pt`` files interchange lr-exactly.  (Newer
+    torch releases skip the constructor's multiplication on resume; the pinned behaviour is the one mirrored.)"""
 
     def __init__(self, optimizer: FusedAdamW, gamma: float, last_epoch: int = -1):
         self.optimizer, self.gamma = optimizer, gamma
+        g = optimizer.param_groups[0]
+        if last_epoch == -1:
+            g.setdefault("initial_lr", g["lr"])
+        elif "initial_lr" not in g:
+            raise KeyError("param 'initial_lr' is not specified in param_groups[0] when resuming an optimizer")
         self.last_epoch = last_epoch
         self.step()
 
     def step(self):
         self.last_epoch += 1
         g = self.optimizer.param_groups[0]
-        g["lr"] = g["initial_lr"] * self.gamma ** self.last_epoch
+        if self.last_epoch > 0:
+            g["lr"] = g["lr"] * self.gamma
 
     def get_last_lr(self):
         return [self.optimizer.param_groups[0]["lr"]]

@@ -26,6 +26,12 @@ class FlatGradAllReduce:
         if not flat_grad.is_cuda:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
             return None
+        if dist.get_backend(self.group) != "nccl":
+            # gloo over device memory (multi-rank rehearsals that share one card): blocking and staged through the host
+            host = flat_grad.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat_grad.copy_(host)
+            return None
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=flat_grad.device)
         ready = torch.cuda.Event()

@@ -11,9 +11,12 @@
   phoneme counters are read back once, by :meth:`GANTrainStep.read_stats`;
 * work the reference does only to throw away is skipped: D's weight gradients inside ``loss_G.backward()``
   (zeroed by the next ``zero_grad``) and the frozen encoder's weight gradients;
-* one process per GPU: with ``torch.distributed`` initialised, the two flat gradient arenas (G, D) are
-  all-reduced over RCCL on a side HIP stream; the D-gradient exchange overlaps the multi-TD and EMG-encoder
-  losses, which do not depend on D.
+* one process per GPU (``torchrun --nproc-per-node N -m ste_gan_amd.train ...``): :func:`main` initialises
+  ``torch.distributed`` from the launcher's environment, :func:`train` broadcasts rank 0's weights, shards every
+  epoch's batch plan over the ranks (``data.loader.plan_epoch``) and leaves validation, TensorBoard and checkpoint
+  files to rank 0; inside the step the two flat gradient arenas (G, D) are all-reduced over RCCL on a side HIP
+  stream, the D-gradient exchange overlapping the multi-TD and EMG-encoder losses, which do not depend on D
+  (SURVEY.md section 5.8).
 
 On the CPU the reference's autocast/GradScaler disable themselves, i.e. its parity path is plain fp32
 (SURVEY.md 3.3 (v)); this trainer computes in fp32 throughout.
@@ -254,21 +257,57 @@ def build_training_objects(cfg, device, emg_enc_ckpt):
     return netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD
 
 
+def dist_info():
+    """(rank, world_size) of this process; (0, 1) when ``torch.distributed`` is not initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def init_distributed_from_env() -> Optional[torch.device]:
+    """One process per GPU under ``torch.distributed.run``: picks ``cuda:LOCAL_RANK`` and joins the RCCL group BEFORE
+    anything else touches the GPU.  Returns the device, or None for a plain single-process start."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or (dist.is_available() and dist.is_initialized()):
+        return None
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=device)
+    return device
+
+
 def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug: bool, emg_enc_ckpt: Path = None,
           loaders=None):
     """Full training run -- ste_gan/train.py:39-499.  ``loaders`` = (train, valid, test) DataLoaders whose batches
-    are dicts keyed by ``DataType`` (data/collate.py:54-61); when omitted they come from ``loaders_via_config``."""
+    are dicts keyed by ``DataType`` (data/collate.py:54-61); when omitted they come from ``loaders_via_config``.
+
+    Data parallel (``torch.distributed`` initialised, see :func:`main`): every rank holds a replica -- rank 0's initial
+    weights are broadcast --, walks its own shard of each epoch's batch plan and joins the two gradient all-reduces of
+    the step; validation, TensorBoard scalars and every file under ``model_directory`` belong to rank 0, the other
+    ranks wait at a barrier.  Caller-supplied ``loaders`` must already be sharded per rank."""
     device = torch.device(torch_device)
     if device.type != "cuda":
         raise RuntimeError("ste_gan_amd.train runs on MI355X (cuda device) only; there is no CPU fallback")
+    rank, world = dist_info()
+    is_main = rank == 0
     logging.info("Initializing Models")
     netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD = build_training_objects(cfg, device, emg_enc_ckpt)
-    writer = _summary_writer(model_directory)
+    writer = _summary_writer(model_directory) if is_main else _NullWriter()
     if checkpoint is not None:
         logging.info(f"Loading checkpoint: {checkpoint}")
         netG, netD, optG, optD, start_epoch, steps = load_latest_checkpoint(checkpoint, device, netG, netD, optG, optD)
     else:
         start_epoch, steps = -1, 0
+    if world > 1:                            # identical replicas whatever each process drew at initialisation
+        for opt in (optG, optD):
+            dist.broadcast(opt.flat.flat, src=0)
+            if opt.pack is not None:
+                opt.pack.invalidate()
+        for buf in itertools.chain(netG.buffers(), netD.buffers()):      # spectral-norm u / v
+            dist.broadcast(buf, src=0)
     scheduler_g = ExponentialLR(optG, gamma=.999, last_epoch=start_epoch if checkpoint is not None else -1)
     scheduler_d = ExponentialLR(optD, gamma=.999, last_epoch=start_epoch if checkpoint is not None else -1)
 
@@ -282,8 +321,11 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
         except ImportError as e:
             raise NotImplementedError("dataset loading (ste_gan/data) is outside the accelerated path this round: pass "
                                       "loaders=(train, valid, test) yielding DataType-keyed batch dicts") from e
-        loaders = loaders_via_config(cfg)
+        loaders = loaders_via_config(cfg, device=device, rank=rank, world_size=world)
     train_loader, valid_loader, test_loader = loaders
+    if is_main and hasattr(train_loader, "save_session_and_speaking_mode_mapping_json") and \
+            getattr(train_loader, "session_id_to_idx", None) is not None:
+        train_loader.save_session_and_speaking_mode_mapping_json(model_directory)          # train.py:121-122
 
     step_fn = GANTrainStep(cfg, netG, netD, emg_encoder_loss, multi_td_loss, optG, optD)
     speech_feature_type = cfg.model.speech_feature_type
@@ -324,30 +366,45 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
                 log_start = time.time()
 
             if steps % cfg.train.interval_valid == 0:
-                val = validate(netG, multi_td_loss, emg_encoder_loss, valid_loader, speech_feature_type, device)
-                for k, v in val.items():
-                    writer.add_scalar(f"val_loss/{k}", v, steps)
-                logging.info(" | ".join(f"val {k}: {v:.5f}" for k, v in val.items()))
-                if val["speech_unit"] < best_su_loss:
-                    best_su_loss = val["speech_unit"]
-                    torch.save(netG.state_dict(), model_directory / "best_netG.pt")
-                    torch.save(netD.state_dict(), model_directory / "best_netD.pt")
+                if is_main:                  # replicas are identical: rank 0 validates the whole partition
+                    val = validate(netG, multi_td_loss, emg_encoder_loss, valid_loader, speech_feature_type, device)
+                    for k, v in val.items():
+                        writer.add_scalar(f"val_loss/{k}", v, steps)
+                    logging.info(" | ".join(f"val {k}: {v:.5f}" for k, v in val.items()))
+                    if val["speech_unit"] < best_su_loss:
+                        best_su_loss = val["speech_unit"]
+                        torch.save(netG.state_dict(), model_directory / "best_netG.pt")
+                        torch.save(netD.state_dict(), model_directory / "best_netD.pt")
+                _barrier(world)
 
-            if steps % cfg.train.interval_save == 0:
-                save_checkpoint(model_directory, f"{steps:08d}", netG, netD, optG, optD, epoch, steps)
+            if steps > 0 and steps % cfg.train.interval_save == 0:                      # train.py:421
+                if is_main:
+                    save_checkpoint(model_directory, f"{steps:08d}", netG, netD, optG, optD, epoch, steps)
+                _barrier(world)
             if steps >= cfg.train.max_steps:
-                save_checkpoint(model_directory, "final", netG, netD, optG, optD, epoch, steps)
-                (model_directory / ".done").touch()
+                if is_main:
+                    save_checkpoint(model_directory, "final", netG, netD, optG, optD, epoch, steps)
+                    with open(model_directory / ".done", "w") as fp:                    # train.py:463-466
+                        fp.write(f"done: {time.time()}")
+                _barrier(world)
                 return
             steps += 1
             if debug:
                 break
+        if cfg.train.loss_adversarial:                                                  # train.py:470-472
+            scheduler_d.step()
         scheduler_g.step()
-        scheduler_d.step()
         if epoch % 5 == 0:
-            save_checkpoint(model_directory, "last", netG, netD, optG, optD, epoch, steps)
+            if is_main:
+                save_checkpoint(model_directory, "last", netG, netD, optG, optD, epoch, steps)
+            _barrier(world)
         if debug:
             return
+
+
+def _barrier(world: int) -> None:
+    if world > 1:
+        dist.barrier()
 
 
 def save_checkpoint(model_directory: Path, tag: str, netG, netD, optG, optD, epoch: int, steps: int):
@@ -385,8 +442,14 @@ def main(cfg, continue_run: bool, debug: bool, emg_enc_ckpt: Path, **kwargs):
     """Entry point -- ste_gan/train.py:503-546 (same keyword arguments: ``main(**vars(args))``)."""
     print(f"Data root: {cfg.data.dataset_root}\ncontinue_run: {continue_run}\nDebug (argparse): {debug}")
     debug = debug or bool(cfg.train.debug)
+    ddp_device = init_distributed_from_env()              # torchrun: cuda:LOCAL_RANK + RCCL group, before any GPU call
+    rank, world = dist_info()
     output_directory = Path(cfg.model_base_dir) / create_ste_gan_model_name(cfg, add_timestamp=False, debug=debug)
     checkpoint = output_directory if (output_directory.exists() and continue_run) else None
+    if world > 1:                                          # every rank must agree on resume-or-not before rank 0 mkdirs
+        flag = torch.tensor([1 if checkpoint is not None else 0], device=ddp_device)
+        dist.broadcast(flag, src=0)
+        checkpoint = output_directory if int(flag.item()) else None
     output_directory.mkdir(exist_ok=True, parents=True)
     print(f"Output directory: {output_directory}")
     done_file = output_directory / ".done"
@@ -394,14 +457,19 @@ def main(cfg, continue_run: bool, debug: bool, emg_enc_ckpt: Path, **kwargs):
         logging.warning(f"Exiting training script as '.done' file exists: {done_file.absolute()}")
         sys.exit()
     config_file = output_directory / "config.yaml"
-    if not config_file.exists():
+    if rank == 0 and not config_file.exists():
         import yaml
         with open(config_file, "w") as fp:
             yaml.safe_dump(_plain(cfg), fp)
     logging.getLogger().setLevel(logging.INFO)
-    logging.getLogger().addHandler(logging.FileHandler(str((output_directory / "log.txt").absolute())))
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    train(cfg, output_directory, checkpoint, device, debug, emg_enc_ckpt)
+    if rank == 0:
+        logging.getLogger().addHandler(logging.FileHandler(str((output_directory / "log.txt").absolute())))
+    device = ddp_device if ddp_device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    try:
+        train(cfg, output_directory, checkpoint, device, debug, emg_enc_ckpt)
+    finally:
+        if ddp_device is not None:
+            dist.destroy_process_group()
 
 
 def _plain(d):

@@ -1,0 +1,28 @@
+"""bench.py under torch.distributed, 2 ranks (round-1 advisor finding: the instrumented pass ran on rank 0 only and its
+all-reduces never completed).  One GPU box has ONE card, so both ranks share cuda:0 and exchange gradients through the
+host (gloo; STEGAN_BENCH_ONE_GPU / STEGAN_BENCH_BACKEND) -- the control flow of every rank (timed steps, symmetric
+instrumented steps, barrier, MAX over ranks, rank-0 JSON line, teardown) is the one the driver's RCCL runs take."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_with_profile_pass_completes():
+    env = dict(os.environ, STEGAN_BENCH_BACKEND="gloo", STEGAN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--profile-steps", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["scaling"] == "weak"
+    assert line["roofline"] is not None and line["roofline"]["frac"] > 0
+    assert line["value"] > 0

@@ -45,6 +45,10 @@ SIGNATURES = {
     "stegan_conv_prep_multi": [_I32, _P, _I32, _P],
     "stegan_conv1d_fwd_t": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_bwd_data_t": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "stegan_conv_prep_bf16": [_D, _P, _P, _P, _P, _P],
+    "stegan_conv_prep_bf16_multi": [_I32, _P, _I32, _P],
+    "stegan_conv1d_fwd_h": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "stegan_conv1d_bwd_data_h": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_bias_grad": [_P, _P, _I32, _I32, _I32, _P],
     "stegan_conv1d_plan": [_D, _I32, _P, _P, _P],
     "stegan_wn_scales": [_I32, _P, _P, _P, _P, _P, _I32, _P],
@@ -81,6 +85,7 @@ SIGNATURES = {
 INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_multi_td_workspace_floats": [_I32, _I32],
                 "stegan_conv_prep_floats": [_D, _I32],
+                "stegan_conv_prep_bf16_elems": [_D, _I32],
                 "stegan_conv_workspace_floats": [_D, _I32]}
 
 _lib = None

@@ -95,12 +95,21 @@ class ConvProfiler:
 PROFILER: Optional[ConvProfiler] = None
 
 
+LAST_CONV_KERNEL = ""    # "bf16" | "direct" | "igemm": which kernel family took the most recent conv launch (tests)
+
+
 def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
+    global LAST_CONV_KERNEL
     if PROFILER is None:
-        return fn()
+        rc = fn()
+        if rc != 1:
+            LAST_CONV_KERNEL = kind
+        return rc
     name, nominal, live = PROFILER.plan(d, mode)
     if kind == "direct":
         name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
+    elif kind == "bf16":
+        name = "conv_bf16_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     elif mode == 2:
         name = "bwd_weight (conv_wgrad_kernel | conv_igemm_kernel<2>)"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -108,6 +117,7 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     rc = fn()
     e1.record()
     if rc != 1:
+        LAST_CONV_KERNEL = kind
         PROFILER.records.append((name, nominal, live, e0, e1,
                                  (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout)))
     return rc
@@ -143,6 +153,31 @@ def _workspace(device, floats: int) -> Tensor:
 
 WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
 
+# Arithmetic type of the convolution operands: "f32" (the parity path: exact fp32 MFMA) or "bf16" (BASELINE configs 3-5:
+# both operands rounded to bf16 while they are staged, fp32 accumulation, fp32 activations / master weights / optimiser
+# state -- csrc/conv_bf16.hip).  The reference reaches its reduced-precision path through ``cfg.train.mixed_precision``
+# (torch.autocast, train.py:151,181,204); the trainer maps that flag onto this switch.
+COMPUTE_DTYPE = "f32"
+
+
+def set_compute_dtype(name: str) -> None:
+    global COMPUTE_DTYPE
+    if name not in ("f32", "bf16"):
+        raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+    if name != COMPUTE_DTYPE:
+        COMPUTE_DTYPE = name
+        bump_weight_epoch()            # prepared weight copies carry (or lack) their bf16 companions per mode
+
+
+def bf16_enabled() -> bool:
+    return COMPUTE_DTYPE == "bf16"
+
+
+def _bf16_of(w: Optional[Tensor]) -> Optional[Tensor]:
+    """The bf16 companion of a prepared fp32 weight copy (attribute ``h``, attached by prep_weights / ConvPack), or None
+    in fp32 mode."""
+    return getattr(w, "h", None) if (w is not None and COMPUTE_DTYPE == "bf16") else None
+
 
 def bump_weight_epoch() -> None:
     global WEIGHT_EPOCH
@@ -161,6 +196,12 @@ def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = 
         bufs = (torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 0)), device=w3.device, dtype=torch.float32),
                 torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 1)), device=w3.device, dtype=torch.float32))
     check(L.stegan_conv_prep(C.byref(d), _p(w3), _p(scale), _p(bufs[0]), _p(bufs[1]), _stream()), "stegan_conv_prep")
+    if COMPUTE_DTYPE == "bf16":
+        for which, b in enumerate(bufs):
+            if getattr(b, "h", None) is None:
+                b.h = torch.empty(int(L.stegan_conv_prep_bf16_elems(C.byref(d), which)), device=w3.device, dtype=torch.bfloat16)
+        check(L.stegan_conv_prep_bf16(C.byref(d), _p(w3), _p(scale), _p(bufs[0].h), _p(bufs[1].h), _stream()),
+              "stegan_conv_prep_bf16")
     return bufs
 
 
@@ -179,6 +220,15 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
         if residual.shape != y.shape:
             raise RuntimeError(f"residual shape {list(residual.shape)} does not match conv output {list(y.shape)}")
     d = _desc(cfg, B, tin, tout)
+    wfh = _bf16_of(wf)
+    if wfh is not None:
+        ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
+        rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_h(C.byref(d), _p(x), _p(wfh), _p(scale), _p(bias),
+                                                                 _p(residual), _p(y), _p(ws), ws.numel(), _stream()),
+                    "bf16")
+        if rc != 1:
+            check(rc, "stegan_conv1d_fwd_h")
+            return y
     if wf is not None:
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
         rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_t(C.byref(d), _p(x), _p(wf), _p(scale), _p(bias),
@@ -201,6 +251,16 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     B, _, tout = dy.shape
     dx = torch.empty((B, cfg.cin, tin * cfg.upsample), device=dy.device, dtype=torch.float32)
     d = _desc(cfg, B, tin, tout)
+    wbh = _bf16_of(wb)
+    if wbh is not None:
+        ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
+        us = scale if uniform_scale else None
+        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_h(C.byref(d), _p(dy), _p(wbh), _p(us), _p(mask_src),
+                                                                      _p(add_src), _p(dx), _p(ws), ws.numel(), _stream()),
+                    "bf16")
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_data_h")
+            return dx
     if wb is not None:
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
@@ -350,7 +410,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         xs = ts[:n]
         cfgs = [l[3] for l in layers]
         ys = None
-        if PROFILER is None and all(c.upsample == 1 and not c.out_btc for c in cfgs):
+        if PROFILER is None and not bf16_enabled() and all(c.upsample == 1 and not c.out_btc for c in cfgs):
             ys = conv1d_fwd_multi(xs, cfgs, [l[4][1] for l in layers], [l[4][0] for l in layers], [l[2] for l in layers])
         if ys is None:
             ys = [conv1d_fwd(x, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], l[2], None, l[3], l[4][1])
@@ -378,7 +438,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         if any(need):
             cfgs = [l[3] for l in layers]
             out = None
-            if PROFILER is None and all(need):
+            if PROFILER is None and not bf16_enabled() and all(need):
                 out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs])
             if out is None:
                 out = [conv1d_bwd_data(g, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], None, None, l[3],
@@ -799,7 +859,7 @@ def frozen_prepared(w: Tensor, scale: Optional[Tensor], cfg: ConvCfg):
     (a freed-and-reused address with an equal version counter would otherwise serve a stale copy)."""
     key = (w.data_ptr(), tuple(w.shape), cfg.groups, scale.data_ptr() if scale is not None else 0)
     ent = _FROZEN_PREP.get(key)
-    stamp = (w._version, scale._version if scale is not None else 0)
+    stamp = (w._version, scale._version if scale is not None else 0, COMPUTE_DTYPE)
     if ent is None or ent[0] != stamp:
         ent = (stamp, prep_weights(w.detach(), cfg, ent[1] if ent is not None else None, scale), w, scale)
         _FROZEN_PREP[key] = ent

@@ -128,6 +128,7 @@ class ConvPack:
         raw = b"".join(struct.pack("<4q8i", *r) for r in prep_rows)
         self.t_prep = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._ptr_key = tuple(v_p + g_p + dv_p + dg_p)
+        self.t_prep_h = None             # bf16 prep table, built when the bf16 compute mode is first used
         self.version = 0                 # bumped whenever this network's weights change (optimizer step, load_state_dict)
         self.prepared_version = None
         module.register_load_state_dict_post_hook(lambda mod, keys: self.invalidate())
@@ -141,9 +142,35 @@ class ConvPack:
         if key != self._ptr_key:
             raise RuntimeError("parameter storage moved after ConvPack was built (rebuild FlatParams / FusedAdamW)")
 
+    def _build_bf16_table(self):
+        """bf16 companions (attribute ``h`` of the fp32 copies, ops._bf16_of) + the device table of
+        stegan_conv_prep_bf16_multi."""
+        import struct
+        from . import ops
+        L = _lib.lib()
+        dev = self.flat.flat.device
+        rows, most = [], 1
+        for c in self.convs:
+            _, sc, wf, wb, _ = c._pack
+            d = ops._desc(c.cfg, 1, 1, 1)
+            nf, nb = int(L.stegan_conv_prep_bf16_elems(C.byref(d), 0)), int(L.stegan_conv_prep_bf16_elems(C.byref(d), 1))
+            wf.h = torch.empty(nf, device=dev, dtype=torch.bfloat16)
+            wb.h = torch.empty(nb, device=dev, dtype=torch.bfloat16)
+            G = c.cfg.groups
+            cog, cig, K = c.cfg.cout // G, c.cfg.cin // G, c.cfg.k
+            up = lambda a, b: (a + b - 1) // b * b
+            rows.append((c.weight_v.data_ptr(), sc.data_ptr(), wf.h.data_ptr(), wb.h.data_ptr(), cog, cig, K, G,
+                         up(cog, 128), up(cig, 64), up(cig, 128), up(cog, 64), nf, nb))
+            most = max(most, nf + nb)
+        raw = b"".join(struct.pack("<4q8i2q", *r) for r in rows)
+        self.t_prep_h = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.prep_h_blocks = max(1, min(2048, (most + 255) // 256))
+
     def prepare(self):
-        """Scales + transposed copies for the CURRENT weights (2 launches for the whole network)."""
-        if self.prepared_version == self.version:
+        """Scales + transposed copies for the CURRENT weights (2 launches for the whole network; 3 in bf16 mode)."""
+        from . import ops
+        key = (self.version, ops.COMPUTE_DTYPE)
+        if self.prepared_version == key:
             return
         self._check()
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -152,7 +179,11 @@ class ConvPack:
         check(L.stegan_wn_scales(self.n, P(self.t_v), P(self.t_g), P(self.t_s), P(self.t_rows), P(self.t_cols),
                                  self.max_rows, s), "stegan_wn_scales")
         check(L.stegan_conv_prep_multi(self.n, P(self.t_prep), self.max_tiles, s), "stegan_conv_prep_multi")
-        self.prepared_version = self.version
+        if ops.bf16_enabled():
+            if self.t_prep_h is None:
+                self._build_bf16_table()
+            check(L.stegan_conv_prep_bf16_multi(self.n, P(self.t_prep_h), self.prep_h_blocks, s), "stegan_conv_prep_bf16_multi")
+        self.prepared_version = key
 
     def zero(self):
         self.dw.zero_()

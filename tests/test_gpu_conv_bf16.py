@@ -1,0 +1,115 @@
+"""-m gpu: the bf16-operand direct conv kernels (stegan_conv1d_fwd_h / _bwd_data_h, csrc/conv_bf16.hip) through the C ABI.
+
+Reference: the SAME contraction on the CPU in fp64 with both operands first rounded to bf16 exactly as the kernel rounds
+them (activations after ReLU / upsample; the forward weights raw, the input-gradient weights after folding the
+per-channel scale) -- so the comparison isolates the kernel's indexing / staging / accumulation from the bf16 rounding
+itself: tolerance 2e-5 relative to the result's scale (fp32 accumulation order).  A second check bounds the distance to
+the un-rounded fp32 result by the bf16 rounding model (2^-8 relative per operand, random signs: ~1e-2 of the scale)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_conv import CASES
+
+pytestmark = pytest.mark.gpu
+
+EXTRA = [
+    (64, 96, 96, 3, 1, 27, 27, 1, 1, True, 192),     # 128 x 128 tiles, d = 27 halo, N = 12288
+    (64, 192, 96, 3, 1, 1, 1, 1, 2, True, 96),       # upsample, 128-column tiles
+    (8, 384, 256, 1, 1, 1, 0, 1, 1, False, 96),      # K = 1, 64-channel chunks
+    (4, 136, 200, 5, 1, 1, 2, 1, 1, False, 40),      # ragged channels: 136 = 2 chunks of 64 + 8, 200 rows
+    (16, 64, 64, 3, 1, 1, 1, 1, 1, False, 12),       # short rows: a tile spans many batch segments
+]
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16_fwd_bwd_data(cfg):
+    from ste_gan_amd import ops
+    B, Cin, Cout, K, s, d, p, g, up, relu, Tin = cfg
+    gen = torch.Generator().manual_seed(hash(cfg) % (2 ** 31))
+    x = torch.randn(B, Cin, Tin, generator=gen)
+    w = torch.randn(Cout, Cin // g, K, generator=gen) / (Cin // g * K) ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=gen)
+    bias = torch.randn(Cout, generator=gen)
+    c = ops.ConvCfg(Cin, Cout, K, s, d, p, g, up, 1 if relu else 0)
+    Tout = c.tout(Tin)
+    res = torch.randn(B, Cout, Tout, generator=gen)
+    dy = torch.randn(B, Cout, Tout, generator=gen)
+    add = torch.randn(B, Cin, Tin * up, generator=gen)
+
+    hx = F.relu(x) if relu else x
+    if up == 2:
+        hx = F.interpolate(hx, scale_factor=2.0, mode="nearest")
+    y_ref = F.conv1d(bf16r(hx), bf16r(w), None, stride=s, dilation=d, padding=p, groups=g) * scale.double().view(1, -1, 1) \
+        + bias.double().view(1, -1, 1) + res.double()
+    y_f32 = F.conv1d(hx.double(), w.double(), None, stride=s, dilation=d, padding=p, groups=g) * scale.double().view(1, -1, 1) \
+        + bias.double().view(1, -1, 1) + res.double()
+    # input gradient of the conv w.r.t. its (effective-resolution) input, operands rounded as the kernel rounds them
+    ws_ = w * scale.view(-1, 1, 1)
+
+    def dx_of(dy_, w_):
+        xe = torch.zeros(B, Cin, Tin * up, dtype=torch.float64, requires_grad=True)
+        ye = F.conv1d(xe, w_, None, stride=s, dilation=d, padding=p, groups=g)
+        (gx,) = torch.autograd.grad(ye, xe, dy_)
+        return gx
+
+    mask = (x > 0).double()
+    if up == 2:
+        mask = F.interpolate(mask, scale_factor=2.0, mode="nearest")
+    dx_ref = dx_of(bf16r(dy), bf16r(ws_)) * (mask if relu else 1.0) + add.double()
+    dx_f32 = dx_of(dy.double(), ws_.double()) * (mask if relu else 1.0) + add.double()
+
+    dev = "cuda"
+    xg, wg, sg, bg, rg, dyg, addg = (t.to(dev) for t in (x, w, scale, bias, res, dy, add))
+    ops.set_compute_dtype("bf16")
+    try:
+        wf, wb = ops.prep_weights(wg, c, None, sg)
+        assert wf.h.dtype == torch.bfloat16 and wb.h is not None
+        y = ops.conv1d_fwd(xg, wg, sg, bg, rg, c, wf)
+        k_fwd = ops.LAST_CONV_KERNEL
+        dxe = ops.conv1d_bwd_data(dyg, wg, sg, xg if relu else None, addg, c, Tin, wb)
+        k_bwd = ops.LAST_CONV_KERNEL
+    finally:
+        ops.set_compute_dtype("f32")
+    cin_g, cout_g = Cin // g, Cout // g
+    assert k_fwd == ("bf16" if (cin_g >= 8 and cout_g >= 16) else "direct"), k_fwd
+    assert k_bwd == ("bf16" if (cout_g >= 8 and cin_g >= 16) else "direct"), k_bwd
+    for got, ref, f32, kern in ((y, y_ref, y_f32, k_fwd), (dxe, dx_ref, dx_f32, k_bwd)):
+        got = got.double().cpu()
+        scale_ = float(f32.abs().max())
+        if kern == "bf16":
+            assert float((got - ref).abs().max()) <= 2e-5 * scale_, (kern, float((got - ref).abs().max()), scale_)
+            assert float((got - f32).abs().max()) <= 3e-2 * scale_
+        else:                                             # shape left to the exact fp32 kernel
+            assert float((got - f32).abs().max()) <= 2e-5 * scale_
+
+
+def test_prep_bf16_layout():
+    """wfh[g][k][co][ci] / wbh[g][k][ci][co] x scale, zero padding and the all-zero plane k = K."""
+    from ste_gan_amd import ops
+    Cin, Cout, K, g = 24, 40, 3, 2
+    c = ops.ConvCfg(Cin, Cout, K, 1, 1, 1, g)
+    gen = torch.Generator().manual_seed(5)
+    w = torch.randn(Cout, Cin // g, K, generator=gen)
+    sc = 0.5 + torch.rand(Cout, generator=gen)
+    ops.set_compute_dtype("bf16")
+    try:
+        wf, wb = ops.prep_weights(w.cuda(), c, None, sc.cuda())
+        wfh, wbh = wf.h.cpu(), wb.h.cpu()
+    finally:
+        ops.set_compute_dtype("f32")
+    cog, cig = Cout // g, Cin // g
+    wfh = wfh.view(g, K + 1, 128, 64)
+    wbh = wbh.view(g, K + 1, 128, 64)
+    want_f = torch.zeros(g, K + 1, 128, 64)
+    want_b = torch.zeros(g, K + 1, 128, 64)
+    for gi in range(g):
+        blk = w[gi * cog:(gi + 1) * cog]                                  # (cog, cig, K)
+        want_f[gi, :K, :cog, :cig] = blk.permute(2, 0, 1)
+        want_b[gi, :K, :cig, :cog] = (blk * sc[gi * cog:(gi + 1) * cog].view(-1, 1, 1)).permute(2, 1, 0)
+    assert torch.equal(wfh, want_f.to(torch.bfloat16))
+    assert torch.equal(wbh, want_b.to(torch.bfloat16))

@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="arithmetic type of the convolution operands (accumulation, activations, weights and optimiser state "
+                         "stay fp32): f32 = parity path, bf16 = BASELINE config 3")
     ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
                     help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
@@ -165,6 +168,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
 
     from ste_gan_amd import ops
+    ops.set_compute_dtype(args.dtype)
     cfg = make_cfg("train_step")
     if args.workload == "gen_infer":
         return gen_infer(args, cfg, device)
@@ -251,7 +255,7 @@ def main():
         line = {"metric": "EMG frames/sec (gen+disc fwd+bwd) at B=64 chunk=200", "value": round(frames / dt, 1),
                 "unit": "EMG frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": "full GAN train step (G + small MPD/MSD D + multi-TD/SU/phoneme/FM losses + 2x AdamW), "
                                        "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, fp32 parity path",
                            "global_batch": world * B, "parallelism": f"dp{world}",

@@ -8,23 +8,27 @@
 // but the operands are rounded to bf16 ONCE, while they are staged, and the LDS images are channel-contiguous so that
 // one MFMA operand (8 consecutive reduction channels of one row / column) is ONE 16-byte ds_read_b128:
 //
-//   * X tile  Xs[slot][8 NCB channels] bf16 -- activations stay fp32 (B, C, T) in HBM; a thread loads the 8 channels of
-//     one (8-channel block, time slot) with 8 buffer_load_dword (lanes along time: coalesced; the channel stride is a
-//     scalar offset; halo / padding / out-of-range slots carry an out-of-range offset and read 0 from the buffer unit),
-//     applies the input ReLU on the packed halves (v_pk_max_i16 x, 0), converts with v_cvt_pk_bf16_f32 and stores ONE
-//     ds_write_b128.  Rows are padded by 16 bytes (odd pitch in 16-byte units): operand reads of 32 consecutive rows are
-//     bank-conflict free.  A tap shift is a ROW offset, so any dilation / stride is an address offset, never a gather;
-//     the nearest-x2 upsample is resolved by the per-slot source offset.  Loads for chunk c+1 are issued before the MFMA
-//     loop of chunk c and written to LDS after it (registers carry them across): global latency hides under the MFMAs.
-//   * W tile  Ws[tap][m][8 NCB channels] bf16 from a bf16 copy of the direction tensor laid out [g][k][m][c] (c
-//     contiguous, zero padded to 128 rows / 64 channels, plus one all-zero tap plane), produced once per weight
-//     version by stegan_conv_prep_bf16: staged by LDS-DMA (global_load_lds, 16 B per lane) with the XOR swizzle applied
-//     to the per-lane SOURCE address (linear LDS image), the same swizzle on the operand read: conflict free.
+//   * X tile  Xs[cb][slot][8 channels] bf16 (channel-block-major: one 8-channel block of all slots, then the next) --
+//     activations stay fp32 (B, C, T) in HBM; a thread loads the 8 channels of one (8-channel block, run of 4 time slots)
+//     with 8 buffer_load_dwordx4 (lanes along time: whole 128-byte lines; the channel stride is a scalar offset; halo /
+//     padding / out-of-range slots carry an out-of-range offset and read 0 from the buffer unit; rows that are not
+//     float4-aligned, and the nearest-x2 upsample, take 8 buffer_load_dword per slot), applies the input ReLU on the
+//     packed halves (v_pk_max_i16 x, 0), converts with v_cvt_pk_bf16_f32 and stores ds_write_b128.  A tap shift is a SLOT
+//     offset, so any dilation / stride is an address offset, never a gather; operand reads of 32 consecutive slots are 32
+//     consecutive 16-byte pieces: bank-conflict free without padding or swizzle.
+//   * W tile  Ws[tap][cb][m][8 channels] bf16 from a bf16 copy of the direction tensor laid out [g][k][cb][m][8] (zero
+//     padded to 128 rows / 64 channels, plus one all-zero tap plane), produced once per weight version by
+//     stegan_conv_prep_bf16: staged by LDS-DMA (global_load_lds, 16 B per lane), every wave-instruction a contiguous
+//     1 KiB of global memory landing as a contiguous 1 KiB of the LDS image.
+//   * pipeline: chunk c + 1 is in flight while chunk c is multiplied (X loads held in registers and converted / stored
+//     behind the MFMA loop, W by LDS-DMA), two LDS buffers per operand, one barrier per chunk; two blocks share a CU.
 //   * the reduction runs over "atoms" = (tap, 8-channel block); one MFMA consumes two atoms (lane halves): with >= 16
 //     channels per chunk the halves take neighbouring channel blocks of one tap, with 8-channel chunks (first layers,
 //     narrow groups, many-tap layers where the W tile must stay small) they take neighbouring TAPS.
-//   * block = 4 waves (2 x 2), wave tile 32 TM x 32 TN, block tile up to 128 x 128; two LDS buffers, one barrier per
-//     chunk; split-K / tail split and their fixed-order epilogue kernels are shared with the fp32 kernel.
+//   * block = 4 waves (2 x 2), wave tile 32 TM x 32 TN, block tile up to 128 x 128; the X fragment is the MFMA's A
+//     operand, so an accumulator tile holds its output channel on the lane and 4 runs of 4 consecutive time steps in
+//     its registers: the epilogue loads / stores 16 bytes per lane; split-K and its fixed-order epilogue kernel are
+//     shared with the fp32 kernel; blocks are mapped to tiles XCD-aware (M tiles fastest inside one XCD's range).
 //
 // Numerics: products of bf16-rounded operands accumulated in fp32 (k-ordered chain inside the MFMA); everything around
 // the contraction (scale, bias, residual, activations, masks) is fp32 exactly as in conv_direct.hip.
@@ -38,7 +42,8 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int HX_MAX = 6;      // X items (8 channels x 1 slot -> one 16-byte LDS store) per thread and chunk
+constexpr int HX_MAX = 6;      // X items (8 channels x 1 slot -> one 16-byte LDS store) per thread and chunk, scalar loads
+constexpr int HXV_MAX = 2;     // X items (8 channels x 4 slots -> four LDS stores) per thread and chunk, 16-byte loads
 constexpr int HW_MAX = 12;     // W 16-byte DMA pieces per thread and chunk
 constexpr unsigned OOB = 0x7ffff000u;   // buffer offset beyond any source tensor (host checks bytes < 2^31 - 2^13): reads 0
 
@@ -46,12 +51,14 @@ struct HP {
     DirP d;                       // CC = channels per chunk (8 NCB); XROW etc. as in the fp32 kernel
     const unsigned short* wh;     // bf16 [G][K + 1][Mpad][Cpad]; plane K is all zero
     int Mpad, Cpad;
-    int XROWP;                    // X rows rounded up to 64 (staging items are laid out per 64-slot wave row)
-    int XP;                       // X row pitch in bytes
+    int NG;                       // X staging items per 8-channel block: XROW (scalar loads) or XROW / 4 (16-byte loads)
+    FastDiv fdNG;
     int ntapsW;                   // taps in the W tile = max over phases (rounded up to even when NCB == 1)
     int xit, wit;                 // staging items per thread
     unsigned src_bytes;
-    FastDiv fdXROWP;
+    int vec_out;                  // 16-byte epilogue accesses: unit output stride, columns and rows multiples of 4, aligned
+    int dbg;                      // diagnostic ablations (STEGAN_BF16_DBG bits: 1 no X loads, 2 no W DMA, 4 no MFMA loop, 8 no
+                                  // X LDS stores); results are wrong when set
 };
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
@@ -61,36 +68,50 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
     return __builtin_bit_cast(unsigned, s);
 }
 
-template <int TM, int TN, int LOGNCB>
+// XV: 16-byte X loads (4 consecutive time slots per lane): rows and valid extent multiples of 4 floats, no upsample;
+// every segment then starts at the source position rounded DOWN to a multiple of 4 and the rounding (0..3 slots) is
+// added to the lanes' column bases instead (the fp32 kernel's XVEC idea).
+template <int TM, int TN, int LOGNCB, bool XV>
 __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
     const DirP& p = h.d;
     constexpr int NCB = 1 << LOGNCB;
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int KS = NCB >= 2 ? NCB / 2 : 1;        // MFMA k-steps per tap (NCB >= 2) / per tap pair (NCB == 1)
-    constexpr int WROWB = NCB * 16;                   // bytes per W row
-    extern __shared__ __align__(16) char smem[];      // W buf 0 | W buf 1 | X buf 0 | X buf 1
+    extern __shared__ __align__(16) char smem[];      // W ring (2 chunks) | X ring (2 chunks)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int bx = (int)bid_x, by = (int)bid_y, phase, split, nsplits = p.splits, cps = p.chunks_per_split;
-    if (p.mix_S) {
-        int tile = bx;
-        split = 0; nsplits = 1;
-        if (bx >= p.mix_full) {
-            const int r = bx - p.mix_full;
-            const int rq = (int)fd_div((uint32_t)r, p.fdMS);
-            tile = p.mix_full + rq;
-            split = r - rq * p.mix_S;
-            nsplits = p.mix_S; cps = p.mix_cps;
-        }
-        const int rest = (int)fd_div((uint32_t)tile, p.fdNBX);
-        bx = tile - rest * p.nbx;
-        phase = (int)fd_div((uint32_t)rest, p.fdNY);
-        by = rest - phase * p.ny;
-    } else {
-        phase = (int)fd_div(bid_z, p.fdSP);
-        split = (int)bid_z - phase * p.splits;
+#ifdef STEGAN_STAMPS          // diagnostic builds only (scripts/bf16_stamps.py): 8 s_memtime stamps per block
+#define HSTAMP(i_) if (p.stamps && tid == 0) p.stamps[(size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#else
+#define HSTAMP(i_)
+#endif
+    HSTAMP(0)
+    // one clustered batch of kernarg loads (left alone, hipcc sinks each s_load next to its first use: a string of
+    // dependent load + wait round trips through the index setup)
+    asm volatile("" ::"s"(p.B), "s"(p.Csrc), "s"(p.Cdst), "s"(p.Tsrc), "s"(p.Tq), "s"(p.Tdst), "s"(p.C2_g), "s"(p.M_g), "s"(p.K),
+                 "s"(p.stride), "s"(p.mode), "s"(p.m_tiles), "s"(p.SEG), "s"(p.NSEG), "s"(p.XROW), "s"(p.U0), "s"(p.splits),
+                 "s"(p.chunks_per_split), "s"(p.nbx), "s"(p.ny), "s"(p.ups), "s"(p.in_relu), "s"(h.Mpad), "s"(h.Cpad), "s"(h.NG),
+                 "s"(h.ntapsW), "s"(h.xit), "s"(h.wit), "s"(h.src_bytes), "s"(h.vec_out));
+    // 1-D grid.  Blocks are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so linear block L is first
+    // mapped to a logical tile id such that every XCD works on ONE contiguous range of ids, and ids run M-tile fastest:
+    // the blocks resident on an XCD at any time then cover a few N tiles x all M tiles of a layer -- each X chunk is
+    // fetched into that L2 once and reused by the M tiles, the W chunks of all M tiles stay resident across its N tiles
+    // (with the natural x-fastest order every XCD streams the whole of X and W through its L2: measured 3-4 TB/s of
+    // Infinity-Cache traffic bound the kernel).  Placement only affects speed, never results.
+    int bx, by, phase, split;
+    const int nsplits = p.splits, cps = p.chunks_per_split;
+    {
+        const unsigned total = gridDim.x, L = bid_x;
+        const unsigned q8 = total >> 3, r8 = total & 7, xcd = L & 7;
+        const unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+        const unsigned rest = fd_div(t, p.fdNY);
+        by = (int)(t - rest * p.ny);
+        const unsigned z = fd_div(rest, p.fdNBX);
+        bx = (int)(rest - z * p.nbx);
+        phase = (int)fd_div(z, p.fdSP);
+        split = (int)z - phase * p.splits;
     }
     const int g = (int)fd_div((uint32_t)by, p.fdMT);
     const int m0 = (by - g * p.m_tiles) * BM;
@@ -107,50 +128,53 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int ntapsW = NCB == 1 ? ((ntaps + 1) & ~1) : ntaps;       // NCB == 1: MFMA halves take neighbouring taps
     const int S = NCB == 1 ? (ntapsW >> 1) : ntaps * KS;            // MFMA k-steps per chunk
 
-    // ---- chunk-invariant part of the X staging: item = (8-channel block cg, slot); a wave's 64 items share cg
+    // ---- chunk-invariant part of the X staging.  Item = (8-channel block cg, slot or run of 4 slots), slots fastest:
+    // the lanes of a wave-instruction read consecutive time positions of one channel row (whole 128-byte lines) and store
+    // consecutive 16-byte pieces of the [cb][slot] LDS image.  The item's source offset (batch row, first channel of its
+    // block, time) is a per-lane constant; the chunk's channel base and the channel within the block are a SCALAR offset.
     const int b_lo = (int)fd_div((uint32_t)n0, fdU), u0 = n0 - b_lo * U;
     const int qbase0 = u0 * cs + off_min, qbaseN = off_min;
-    unsigned x_voff[HX_MAX];
-    int x_lds[HX_MAX], x_cg[HX_MAX];
+    const int qal0 = XV ? (qbase0 & ~3) : qbase0, qalN = XV ? (qbaseN & ~3) : qbaseN;
+    constexpr int XI = XV ? HXV_MAX : HX_MAX;
+    unsigned x_voff[XI];
+    int x_lds[XI], x_c8[XI];             // LDS byte offset of the item's first slot (-1: no item); 8 * cg
 #pragma unroll
-    for (int it = 0; it < HX_MAX; ++it) {
-        const int wbase = it * 256 + wave * 64;                     // wave-uniform
-        const int cg = (int)fd_div((uint32_t)wbase, h.fdXROWP);
-        const int slot = wbase - cg * h.XROWP + lane;
-        x_cg[it] = (it < h.xit && cg < NCB) ? cg : -1;
+    for (int it = 0; it < XI; ++it) {
+        const int idx = it * 256 + tid;
+        const int cg = (int)fd_div((uint32_t)idx, h.fdNG), grp = idx - cg * h.NG;
+        const int slot = XV ? grp * 4 : grp;
         x_voff[it] = OOB;
-        x_lds[it] = slot * h.XP + cg * 16;
-        if (slot < p.XROW) {
+        x_c8[it] = cg * 8;
+        x_lds[it] = (it < h.xit && cg < NCB) ? (cg * p.XROW + slot) * 16 : -1;
+        if (cg < NCB) {
             const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
             const int b = b_lo + sg;
-            const int q = (sg == 0 ? qbase0 : qbaseN) + sl;
+            const int q = (sg == 0 ? qal0 : qalN) + sl;
             if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
-                x_voff[it] = (unsigned)(((b * p.Csrc + g * p.C2_g) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q)) * 4);
+                x_voff[it] = (unsigned)(((b * p.Csrc + g * p.C2_g + cg * 8) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q)) * 4);
         }
     }
-    // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece (linear image); row = piece >> LOGNCB = tap * BM + m,
-    // physical 16-byte slot = piece & (NCB - 1) holds logical channel block slot ^ swz(m)
-    int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel term; -1: no piece
+    // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece; piece = (tap * NCB + cb) * BM + m.  The bf16 weights
+    // are stored [g][k][cb][m][8 channels], so the 64 lanes of a wave-instruction copy 1 KiB of CONTIGUOUS global memory
+    const int CB = h.Cpad >> 3;
+    int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
 #pragma unroll
     for (int it = 0; it < HW_MAX; ++it) {
         const int piece = it * 256 + tid;
-        const int row = piece >> LOGNCB, phys = piece & (NCB - 1);
-        const int tap = row / BM, m = row - tap * BM;
-        const int cb = phys ^ ((m >> (4 - LOGNCB)) & (NCB - 1));
+        const int m = piece & (BM - 1), r = piece / BM;
+        const int cb = r & (NCB - 1), tap = r >> LOGNCB;
         const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;            // dead tap of an odd pair: the zero plane
-        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * h.Mpad + m0 + m) * h.Cpad + cb * 8) * 2 : -1;
+        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : -1;
     }
 
-    // ---- per-lane operand addresses
+    // ---- per-lane operand addresses.  Reduction "atoms" (tap, cb) are BM (W) / XROW or step (X) 16-byte pieces apart; the
+    // two lane halves of an MFMA take atoms 2 s and 2 s + 1 of k-step s: W offset s * 2 BM * 16 for every chunk shape
     const int hl = lane >> 5, l31 = lane & 31;
     int a_byte[TM], b_byte[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a_byte[i] = ((wm * TM + i) * 32 + l31) * WROWB + (NCB == 1 ? hl * BM * 16 : 0);
-    const int a_swz = (l31 >> (4 - LOGNCB)) & (NCB - 1);           // the same for every 32-row sub-tile
-    int a_xo[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a_xo[kk] = NCB == 1 ? 0 : (((2 * kk + hl) ^ a_swz) * 16);
-    const int tapB = tp.step * h.XP;                               // bytes between the rows of neighbouring taps
+    for (int i = 0; i < TM; ++i) a_byte[i] = ((wm * TM + i) * 32 + l31 + hl * BM) * 16;
+    const int tapB = tp.step * 16;                                 // bytes between the X pieces of neighbouring taps
+    const int cbB = p.XROW * 16;                                   // ... of neighbouring channel blocks
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int jn = (wn * TN + j) * 32 + l31;
@@ -158,9 +182,9 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         if (n0 + jn < N) {
             const int uu = u0 + jn;
             const int sg = (int)fd_div((uint32_t)uu, fdU), u = uu - sg * U;
-            cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs;
+            cb = sg * p.SEG + (u - (sg == 0 ? u0 : 0)) * cs + (sg == 0 ? qbase0 - qal0 : qbaseN - qalN);
         }
-        b_byte[j] = cb * h.XP + (NCB == 1 ? hl * tapB : hl * 16);
+        b_byte[j] = cb * 16 + hl * (NCB == 1 ? tapB : cbB);
     }
 
     f32x16 acc[TM][TN];
@@ -176,207 +200,256 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int c_begin = split * cps;
     const int c_end = min(nchunks, c_begin + cps);
     const char* wt_g = (const char*)h.wh + (size_t)g * (p.K + 1) * h.Mpad * h.Cpad * 2;
-    const int wbuf = h.ntapsW * BM * WROWB, xbuf = h.XROWP * h.XP;
-    char* const Xbufs = smem + 2 * wbuf;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
+    const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = NCB * p.XROW * 16;
+    char* const Xbufs = smem + 2 * wbuf;                           // W ring of 2 | X ring of 2
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)h.src_bytes, 0x00020000);
     const bool relu = p.in_relu != 0;
     const int row_bytes = p.Tsrc * 4;
+    const int chunk_w = NCB * h.Mpad * 16;                         // bytes between the weights of neighbouring chunks
 
-    float xr[HX_MAX][8];
-#define HB_LOAD_X(c_)                                                                                           \
+    // staged X values of the chunk in flight: scalar form xAr[it][j] = channel j of the item's slot; vector form
+    // xAv[it][j] = 4 slots of channel j
+    float xAr[XV ? 1 : HX_MAX][8];
+    f32x4 xAv[XV ? HXV_MAX : 1][8];
+#define HB_LOAD_X(c_, xr, xv)                                                                                   \
     {                                                                                                           \
         const int c0_ = (c_) * CCH;                                                                             \
-        _Pragma("unroll") for (int it = 0; it < HX_MAX; ++it) {                                                 \
-            if (x_cg[it] >= 0) {                                                                                \
+        const int lim_ = p.C2_g - c0_;                  /* live channels of this chunk (ragged last chunk)     */ \
+        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
+            if (it < h.xit && !(h.dbg & 1)) {                                                                   \
                 _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-                    int ch_ = c0_ + x_cg[it] * 8 + j;                    /* channels past the group read a live */ \
-                    ch_ = ch_ < p.C2_g ? ch_ : p.C2_g - 1;               /* one: their weights are zero         */ \
-                    xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)x_voff[it], ch_ * row_bytes, 0)); \
+                    /* channels past the group: out-of-range offset, the buffer unit returns 0 */               \
+                    const int vo_ = (x_c8[it] + j < lim_) ? (int)x_voff[it] : (int)OOB;                         \
+                    const int so_ = (c0_ + j) * row_bytes;                                                      \
+                    if constexpr (XV) xv[it][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_, so_, 0)); \
+                    else xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_, so_, 0)); \
                 }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
     }
-#define HB_STORE_X(buf_)                                                                                        \
+#define HB_STORE_X(buf_, xr, xv)                                                                                \
     {                                                                                                           \
         char* Xd_ = Xbufs + (buf_) * xbuf;                                                                      \
-        _Pragma("unroll") for (int it = 0; it < HX_MAX; ++it) {                                                 \
-            if (x_cg[it] >= 0) {                                                                                \
-                const u32x4 v_ = {pack_bf16x2(xr[it][0], xr[it][1], relu), pack_bf16x2(xr[it][2], xr[it][3], relu), \
-                                  pack_bf16x2(xr[it][4], xr[it][5], relu), pack_bf16x2(xr[it][6], xr[it][7], relu)}; \
-                *(u32x4*)(Xd_ + x_lds[it]) = v_;                                                                \
+        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
+            if (it < h.xit && x_lds[it] >= 0 && !(h.dbg & 8)) {                                                 \
+                if constexpr (XV) {                                                                             \
+                    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                          \
+                        const u32x4 v_ = {pack_bf16x2(xv[it][0][s4], xv[it][1][s4], relu), pack_bf16x2(xv[it][2][s4], xv[it][3][s4], relu), \
+                                          pack_bf16x2(xv[it][4][s4], xv[it][5][s4], relu), pack_bf16x2(xv[it][6][s4], xv[it][7][s4], relu)}; \
+                        *(u32x4*)(Xd_ + x_lds[it] + s4 * 16) = v_;                                              \
+                    }                                                                                           \
+                } else {                                                                                        \
+                    const u32x4 v_ = {pack_bf16x2(xr[it][0], xr[it][1], relu), pack_bf16x2(xr[it][2], xr[it][3], relu), \
+                                      pack_bf16x2(xr[it][4], xr[it][5], relu), pack_bf16x2(xr[it][6], xr[it][7], relu)}; \
+                    *(u32x4*)(Xd_ + x_lds[it]) = v_;                                                            \
+                }                                                                                               \
             }                                                                                                   \
         }                                                                                                       \
     }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
 #define HB_DMA_W(c_, buf_)                                                                                      \
     {                                                                                                           \
-        const char* wc_ = wt_g + (c_) * CCH * 2;                                                                \
+        const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
         char* Wd_ = smem + (buf_) * wbuf;                                                                       \
         _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                 \
-            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB) {                                     \
+            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !(h.dbg & 2)) {                     \
                 const char* src_ = wc_ + (w_off[it] >= 0 ? w_off[it] : 0);                                      \
                 __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (it * 256 + wave * 64) * 16), 16, 0, 0); \
             }                                                                                                   \
         }                                                                                                       \
     }
-
-    // prologue: first chunk
-    if (c_begin < c_end) {
-        HB_LOAD_X(c_begin)
-        HB_DMA_W(c_begin, 0)
-        HB_STORE_X(0)
+#define HB_LDS(ptr_) (*(const bf16x8*)(ptr_))
+#define HB_LOAD(a_, b_, s_)                                                                                     \
+    {                                                                                                           \
+        const char* wa_ = Wcur + (s_) * (BM * 32);                                                              \
+        const char* xb_ = Xcur + (NCB == 1 ? (s_) * 2 * tapB : ((s_) / KS) * tapB + ((s_) % KS) * 2 * cbB);     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[i] = HB_LDS(wa_ + a_byte[i]);                         \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[j] = HB_LDS(xb_ + b_byte[j]);                         \
     }
+#define HB_MFMA(a_, b_)                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_[j], a_[i], acc[i][j], 0, 0, 0);
+    // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
+#define HB_COMPUTE(c_)                                                                                          \
+    if (!(h.dbg & 4)) {                                                                                         \
+        const char* Wcur = smem + (((c_) - c_begin) & 1) * wbuf;                                                \
+        const char* Xcur = Xbufs + (((c_) - c_begin) & 1) * xbuf;                                               \
+        bf16x8 aA[TM], bA[TN], aB[TM], bB[TN];                                                                  \
+        if (S > 0) HB_LOAD(aA, bA, 0)                                                                           \
+        int s = 0;                                                                                              \
+        for (; s + 1 < S; s += 2) {                                                                             \
+            HB_LOAD(aB, bB, s + 1)                                                                              \
+            HB_MFMA(aA, bA)                                                                                     \
+            if (s + 2 < S) HB_LOAD(aA, bA, s + 2)                                                               \
+            HB_MFMA(aB, bB)                                                                                     \
+        }                                                                                                       \
+        if (s < S) { HB_MFMA(aA, bA) }                                                                          \
+    }
+    // Pipeline, one chunk ahead, two LDS buffers per operand, ONE barrier per chunk:
+    //   iteration c: [barrier] issue W(c+1) LDS-DMA + X(c+1) loads -> MFMAs of chunk c -> convert + store X(c+1)
+    // Two blocks share a CU where the grid allows, so one block's global round trip hides under the other's MFMAs.  (A
+    // two-chunks-ahead variant -- ring of 3 W buffers, two X register sets -- was built and measured: hipcc drains
+    // vmcnt(0) at every use of an ordinary load while an LDS-DMA is in flight, and with both operands staged through
+    // registers the per-item guards around the loads make its wait counting fall back to vmcnt(0) as well; the
+    // iteration time did not move and the doubled registers cost the second block per CU.)
+    HSTAMP(1)
+    if (c_begin < c_end) {
+        HB_LOAD_X(c_begin, xAr, xAv)
+        HB_DMA_W(c_begin, 0)
+        HB_STORE_X(0, xAr, xAv)
+    }
+    HSTAMP(2)
     for (int c = c_begin; c < c_end; ++c) {
         const int cur = (c - c_begin) & 1;
         __syncthreads();                    // chunk c's X stores and W DMA (vmcnt(0) + barrier) are visible; nobody reads cur ^ 1
+        if (c == c_begin + 1) { HSTAMP(3) }
+        if (c == c_begin + 5) { HSTAMP(4) }
         const bool more = c + 1 < c_end;
         if (more) {
-            HB_LOAD_X(c + 1)                // into registers; written to LDS behind the MFMA loop
+            HB_LOAD_X(c + 1, xAr, xAv)      // into registers; written to LDS behind the MFMA loop
             HB_DMA_W(c + 1, cur ^ 1)
         }
-        const char* Wcur = smem + cur * wbuf;
-        const char* Xcur = Xbufs + cur * xbuf;
-#define HB_LDS(ptr_) (*(const bf16x8*)(ptr_))
-        if constexpr (KS >= 2) {
-            bf16x8 aA[TM], bA[TN], aB[TM], bB[TN];
-#define HB_LOAD(a_, b_, tap_, KK_)                                                                              \
-            {                                                                                                   \
-                const char* wa_ = Wcur + (tap_) * (BM * WROWB) + a_xo[KK_];                                     \
-                const char* xb_ = Xcur + (tap_) * tapB + (KK_) * 32;                                            \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[i] = HB_LDS(wa_ + a_byte[i]);                 \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[j] = HB_LDS(xb_ + b_byte[j]);                 \
-            }
-#define HB_MFMA(a_, b_)                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i], b_[j], acc[i][j], 0, 0, 0);
-            HB_LOAD(aA, bA, 0, 0)
-            for (int tap = 0; tap < ntaps; ++tap) {
-                HB_LOAD(aB, bB, tap, 1)
-                HB_MFMA(aA, bA)
-                if constexpr (KS == 4) {
-                    HB_LOAD(aA, bA, tap, 2)
-                    HB_MFMA(aB, bB)
-                    HB_LOAD(aB, bB, tap, 3)
-                    HB_MFMA(aA, bA)
-                }
-                if (tap + 1 < ntaps) HB_LOAD(aA, bA, tap + 1, 0)
-                HB_MFMA(aB, bB)
-            }
-#undef HB_LOAD
-        } else {
-            // one k-step per tap (NCB == 2) or per tap pair (NCB == 1): step s reads W rows at s * stepA, X rows at s * stepB
-            const int stepA = (NCB == 1 ? 2 : 1) * BM * WROWB, stepB = (NCB == 1 ? 2 : 1) * tapB;
-            bf16x8 aA[TM], bA[TN], aB[TM], bB[TN];
-#define HB_LOAD(a_, b_, s_)                                                                                     \
-            {                                                                                                   \
-                const char* wa_ = Wcur + (s_) * stepA + a_xo[0];                                                \
-                const char* xb_ = Xcur + (s_) * stepB;                                                          \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[i] = HB_LDS(wa_ + a_byte[i]);                 \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[j] = HB_LDS(xb_ + b_byte[j]);                 \
-            }
-            if (S > 0) HB_LOAD(aA, bA, 0)
-            int s = 0;
-            for (; s + 1 < S; s += 2) {
-                HB_LOAD(aB, bB, s + 1)
-                HB_MFMA(aA, bA)
-                if (s + 2 < S) HB_LOAD(aA, bA, s + 2)
-                HB_MFMA(aB, bB)
-            }
-            if (s < S) { HB_MFMA(aA, bA) }
-#undef HB_LOAD
-        }
-#undef HB_MFMA
-#undef HB_LDS
-        if (more) HB_STORE_X(cur ^ 1)
+        HB_COMPUTE(c)
+        if (more) HB_STORE_X(cur ^ 1, xAr, xAv)
     }
+#undef HB_COMPUTE
+#undef HB_MFMA
+#undef HB_LOAD
+#undef HB_LDS
 #undef HB_LOAD_X
 #undef HB_STORE_X
 #undef HB_DMA_W
 
-    // ---- epilogue (same as conv_direct.hip: the accumulator layout of the 32x32 MFMAs does not depend on the dtype)
+    // ---- epilogue.  The MFMAs ran with the X fragment as the A operand, so a 32 x 32 accumulator tile has its output
+    // CHANNEL on the lane and 16 output COLUMNS (time) in its registers, as four runs of 4 consecutive columns
+    // (n = 8 q + 4 half + 0..3): scale / bias are ONE value per lane and tile, and wherever 4 consecutive columns are 4
+    // consecutive, 16-byte aligned floats of one output row (unit output stride, column count a multiple of 4) a run is ONE
+    // 16-byte load per fused input (residual, mask) and ONE 16-byte store.  (The first version kept channels in the
+    // registers: 64 dword stores and 128 dependent scalar-per-lane loads per lane cost as much as the whole main loop.)
+    HSTAMP(5)
+    if (h.dbg & 16) {
+        if (acc[0][0][0] == 123.456f) p.out[0] = 1.f;        // keep the accumulators alive
+        return;
+    }
     const size_t out_elems = (size_t)p.B * p.Cdst * p.Tdst;
+    const bool vec4 = h.vec_out != 0;                          // host: os == 1, U % 4 == 0, Tdst % 4 == 0, aligned pointers
+    const bool raw = nsplits > 1;                              // split-K: raw partial sums, the epilogue kernel fuses the rest
+    float* const outp = raw ? p.partial + (size_t)split * out_elems : p.out;
+    // every launch-uniform condition is resolved ONCE here (a single wave per SIMD pays every branch and scalar load
+    // of the epilogue in full: the first version, with the conditions inside the element loops, took 20k cycles)
+    const int act = raw ? STEGAN_ACT_NONE : p.out_act;
+    const float* const resp = raw ? nullptr : p.res;
+    const float* const maskp = (raw || p.mode != 1) ? nullptr : p.mask;
+    const float* const scalep = raw ? nullptr : p.scale;
+    const float* const biasp = (raw || p.mode != 0) ? nullptr : p.bias;
+    const int mode = p.mode, ups = p.ups, Cdst = p.Cdst, Tdst = p.Tdst, Tmask = p.Tmask, M_g = p.M_g;
+#define HB_ACT16(v_)                                                                                            \
+    if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
+    else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = fmaxf(v_[e], 0.f); }      \
+    else if (act == STEGAN_ACT_TANH) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = tanhf(v_[e]); }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int jn = (wn * TN + j) * 32 + l31;
-        const bool n_ok = n0 + jn < N;
-        const int n = n_ok ? n0 + jn : N - 1;
-        const int b = (int)fd_div((uint32_t)n, fdU), u = n - b * U;
-        const int to = p.mode == 0 ? u : phase + u * os;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + l31;
+        const bool m_ok = m < M_g;
+        const int ch = g * M_g + (m_ok ? m : M_g - 1);
+        float sc = 1.f, bi = 0.f;
+        if (scalep) sc = mode == 0 ? scalep[ch] : scalep[0];
+        if (biasp) bi = biasp[ch];
 #pragma unroll
-        for (int im = 0; im < TM; ++im) {
-            const int mrow0 = m0 + (wm * TM + im) * 32 + 4 * hl;
-            if (nsplits > 1) {
-                float* dst = p.partial + (size_t)split * out_elems;
+        for (int j = 0; j < TN; ++j) {
+            const int nb0 = n0 + (wn * TN + j) * 32 + 4 * hl;
+            f32x16 v = acc[i][j];
+            if (vec4) {
+                int oidx[4], midx[4];
+                bool ok[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = nb0 + 8 * q;
+                    ok[q] = m_ok && n < N;
+                    const int nn = n < N ? n : 0;
+                    const int b = (int)fd_div((uint32_t)nn, fdU), u = nn - b * U;
+                    oidx[q] = (b * Cdst + ch) * Tdst + (mode == 0 ? u : phase + u);
+                    midx[q] = (b * Cdst + ch) * Tmask + (u >> 1);
+                }
+                if (maskp) {
+                    if (ups == 0) {
+                        f32x4 mk[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = mk[e >> 2][e & 3] > 0.f ? v[e] : 0.f;
+                    } else {
+                        f32x2 mk[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mk[q] = *(const f32x2*)(maskp + midx[q]);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = mk[e >> 2][(e & 3) >> 1] > 0.f ? v[e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = v[e] * sc + bi;
+                if (resp) {
+                    f32x4 rs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rs[q] = *(const f32x4*)(resp + oidx[q]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += rs[e >> 2][e & 3];
+                }
+                HB_ACT16(v)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ok[q]) *(f32x4*)(outp + oidx[q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            } else {
+                int oi[16];
+                bool okk[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int m = mrow0 + (e & 3) + 8 * (e >> 2);
-                    if (n_ok && m < p.M_g) dst[((size_t)b * p.Cdst + g * p.M_g + m) * p.Tdst + to] = acc[im][j][e];
-                }
-                continue;
-            }
-#pragma unroll
-            for (int e0 = 0; e0 < 16; e0 += 8) {
-                float sc[8], bi[8], rs[8];
-                int chn[8], oidx[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = mrow0 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
-                    chn[e] = g * p.M_g + (m < p.M_g ? m : p.M_g - 1);
-                    oidx[e] = (b * p.Cdst + chn[e]) * p.Tdst + to;
-                    sc[e] = 1.f; bi[e] = 0.f; rs[e] = 0.f;
-                }
-                if (p.mode == 0) {
-                    if (p.scale) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sc[e] = p.scale[chn[e]];
+                    const int n = nb0 + 8 * (e >> 2) + (e & 3);
+                    okk[e] = m_ok && n < N;
+                    const int nn = n < N ? n : 0;
+                    const int b = (int)fd_div((uint32_t)nn, fdU), u = nn - b * U;
+                    const int to = mode == 0 ? u : phase + u * os;
+                    oi[e] = (b * Cdst + ch) * Tdst + to;
+                    if (maskp) {
+                        const float xv = maskp[(b * Cdst + ch) * Tmask + (to >> ups)];
+                        v[e] = xv > 0.f ? v[e] : 0.f;
                     }
-                    if (p.bias) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) bi[e] = p.bias[chn[e]];
-                    }
-                } else {
-                    if (p.scale) {
-                        const float us = p.scale[0];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) sc[e] = us;
-                    }
-                    if (p.mask) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float xv = p.mask[(b * p.Cdst + chn[e]) * p.Tmask + (to >> p.ups)];
-                            if (!(xv > 0.f)) sc[e] = 0.f;
-                        }
-                    }
-                }
-                if (p.res) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) rs[e] = p.res[oidx[e]];
+                    if (!raw && p.out_btc) oi[e] = (b * Tdst + to) * Cdst + ch;       // (B, T, C) store; never with a residual
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = mrow0 + ((e0 + e) & 3) + 8 * ((e0 + e) >> 2);
-                    float v = acc[im][j][e0 + e] * sc[e] + bi[e] + rs[e];
-                    if (p.out_act == STEGAN_ACT_LRELU) v = v > 0.f ? v : 0.1f * v;
-                    else if (p.out_act == STEGAN_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
-                    if (n_ok && m < p.M_g) {
-                        if (p.out_btc) p.out[((size_t)b * p.Tdst + to) * p.Cdst + g * p.M_g + m] = v;
-                        else p.out[oidx[e]] = v;
-                    }
+                for (int e = 0; e < 16; ++e) v[e] = v[e] * sc + bi;
+                if (resp) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] += resp[oi[e]];
                 }
+                HB_ACT16(v)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (okk[e]) outp[oi[e]] = v[e];
             }
         }
     }
+#undef HB_ACT16
+    HSTAMP(6)
+#ifdef STEGAN_STAMPS
+    if (p.stamps && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);                         // stores drained (vmcnt 0)
+        p.stamps[(size_t)bid_x * 8 + 7] = __builtin_amdgcn_s_memtime();
+    }
+#endif
+#undef HSTAMP
 }
 
-template <int TM, int TN, int LOGNCB>
+template <int TM, int TN, int LOGNCB, bool XV>
 __global__ __launch_bounds__(256) void conv_bf16_kernel(const HP h) {
-    conv_bf16_body<TM, TN, LOGNCB>(h, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// ---- bf16 weight copies: v (Cout, Cin_g, K) fp32 -> wf[g][k][co][ci], wb[g][k][ci][co] (x scale[co]); k = K: zero plane
+// ---- bf16 weight copies: v (Cout, Cin_g, K) fp32 -> wf[g][k][ci/8][co][ci%8], wb[g][k][co/8][ci][co%8] (x scale[co]);
+// k = K: zero plane.  Channel-block-major: the rows of one 8-channel block are contiguous 16-byte pieces, the order of the
+// kernel's LDS image, so a W tile is staged by fully contiguous 1 KiB LDS-DMA wave-instructions.
 struct PrepH {
     const float* v;
     const float* scale;
@@ -391,22 +464,27 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
+// layout [g][k][cb][m][8]: element e = (((g (K+1) + k) CB + cb) M + m) 8 + j, channel c = 8 cb + j
 __device__ __forceinline__ void prep_bf16_elems(const PrepH& t, long e0, long stride) {
     const int K = t.K;
     for (long e = e0; e < t.nf + t.nb; e += stride) {
         if (e < t.nf) {
-            const int c = (int)(e % t.Cf);
-            long r = e / t.Cf;
+            const int j = (int)(e & 7);
+            long r = e >> 3;
             const int m = (int)(r % t.Mf); r /= t.Mf;
+            const int CBf = t.Cf >> 3;
+            const int c = (int)(r % CBf) * 8 + j; r /= CBf;
             const int k = (int)(r % (K + 1)), g = (int)(r / (K + 1));
             float v = 0.f;
             if (k < K && m < t.Cout_g && c < t.Cin_g) v = t.v[((size_t)(g * t.Cout_g + m) * t.Cin_g + c) * K + k];
             t.wf[e] = to_bf16(v);
         } else {
             const long eb = e - t.nf;
-            const int c = (int)(eb % t.Cb);
-            long r = eb / t.Cb;
+            const int j = (int)(eb & 7);
+            long r = eb >> 3;
             const int m = (int)(r % t.Mb); r /= t.Mb;
+            const int CBb = t.Cb >> 3;
+            const int c = (int)(r % CBb) * 8 + j; r /= CBb;
             const int k = (int)(r % (K + 1)), g = (int)(r / (K + 1));
             float v = 0.f;
             if (k < K && m < t.Cin_g && c < t.Cout_g) {
@@ -436,58 +514,62 @@ void fill_prep(PrepH& t, const stegan_conv_desc* d) {
     t.nb = (long)t.G * (t.K + 1) * t.Mb * t.Cb;
 }
 
-struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, XROWP, XP, ntW, xit, wit, span; size_t lds; bool ok; };
+struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, NG, ntW, xit, wit, span; size_t lds; bool ok; };
 
-// geometry for one (TM, TN): the largest channel chunk whose tiles fit
-GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_max, int cs, int U, int U_min) {
+// geometry for one (TM, TN): the largest channel chunk whose tiles fit (cch_max caps it: experiments)
+GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_max, int cs, int U, int U_min, bool xv,
+               int cch_max) {
     GeoH gm;
     gm.ok = false; gm.TM = TM; gm.TN = TN;
     const int BM = 64 * TM, BN = 64 * TN;
     GeoH fallback = gm;
     for (int logNCB = 3; logNCB >= 0; --logNCB) {
         const int NCB = 1 << logNCB, CCH = 8 * NCB;
+        if (CCH > cch_max && logNCB > 0) continue;
         if (logNCB > 0 && CCH > round_up(C2_g, 8) && CCH > 16) continue;       // chunk wider than the group: only padding
         if (logNCB > 0 && C2_g <= 8) continue;
         const int ntW = NCB == 1 ? round_up(ntaps_max, 2) : ntaps_max;
         const int span = NCB == 1 ? span_taps + (ntW - ntaps_max) * step_max : span_taps;   // the dead tap reads real rows
         const int UT = U < BN ? U : BN;
-        const int SEG = (UT - 1) * cs + span + 1;
+        int SEG = (UT - 1) * cs + span + 1;
+        if (xv) SEG = (SEG + 3 + 3) & ~3;                // up to 3 slots of down-rounding, whole groups of 4
         int NSEG = 1;
         for (int uu = (U_min < 1 ? 1 : U_min); uu <= U; ++uu) {
             const int ns = (uu % BN == 0) ? 1 : ((BN + uu - 2) / uu + 1);
             if (ns > NSEG) NSEG = ns;
         }
-        const int XROW = SEG * NSEG, XROWP = round_up(XROW, 64);
-        const int XP = NCB == 1 ? 16 : (NCB + 1) * 16;
-        const int xit = ceil_div(NCB * XROWP, 256), wit = ceil_div(ntW * BM * NCB, 256);
-        if (xit > HX_MAX || wit > HW_MAX) continue;
-        const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)XROWP * XP);
+        const int XROW = SEG * NSEG;
+        const int NG = xv ? XROW / 4 : XROW;
+        const int xit = ceil_div(NCB * NG, 256), wit = ceil_div(ntW * BM * NCB, 256);
+        if (xit > (xv ? HXV_MAX : HX_MAX) || wit > HW_MAX) continue;
+        const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)XROW * NCB * 16);       // W ring of 2, X ring of 2
         if (lds > 160 * 1024) continue;
         GeoH c = gm;
-        c.logNCB = logNCB; c.SEG = SEG; c.NSEG = NSEG; c.XROW = XROW; c.XROWP = XROWP; c.XP = XP; c.ntW = ntW;
+        c.logNCB = logNCB; c.SEG = SEG; c.NSEG = NSEG; c.XROW = XROW; c.NG = NG; c.ntW = ntW;
         c.xit = xit; c.wit = wit; c.span = span; c.lds = lds; c.ok = true;
-        if (lds <= 80 * 1024) return c;                  // two blocks per CU
+        static const char* env_pref = getenv("STEGAN_BF16_LDS_PREF");       // KiB; experiments
+        if (lds <= (size_t)(env_pref ? atoi(env_pref) : 80) * 1024) return c;   // default: two blocks per CU
         if (!fallback.ok) fallback = c;
     }
     return fallback;
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool XV>
 void launch_variant(int logNCB, dim3 grid, size_t lds, hipStream_t s, const HP& h) {
     switch (logNCB) {
-        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0>), grid, dim3(256), lds, s, h); break;
-        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1>), grid, dim3(256), lds, s, h); break;
-        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2>), grid, dim3(256), lds, s, h); break;
-        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3>), grid, dim3(256), lds, s, h); break;
+        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV>), grid, dim3(256), lds, s, h); break;
+        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV>), grid, dim3(256), lds, s, h); break;
+        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV>), grid, dim3(256), lds, s, h); break;
+        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV>), grid, dim3(256), lds, s, h); break;
     }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, bool XV>
 void set_lds_attr() {
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 0, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 1, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 2, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 3, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // returns 1 when this kernel does not take the shape (caller uses the fp32 kernels)
@@ -532,30 +614,42 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     }
     if (ntaps_max > MAX_TAPS || phases > MAX_PHASES) return 1;
     const long N = (long)d->B * U;
-    // tile: 128 rows when the padding it adds stays small, 128 columns when the grid still fills the chip
-    static const char* env_tile = getenv("STEGAN_BF16_TILE");          // "MN", e.g. "22", "11" (experiments)
+    // 16-byte X loads need float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
+    const bool xv = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
+                    !getenv("STEGAN_BF16_NO_XV");
+    // tile: 128 rows when the padding it adds stays small; 128 columns unless the grid gets too small to fill the chip
+    const char* env_tile = getenv("STEGAN_BF16_TILE");                 // "MN", e.g. "22", "11" (experiments)
+    const char* env_cch = getenv("STEGAN_BF16_CCH_MAX");
+    const int cch_max = env_cch ? atoi(env_cch) : 64;
     int TM = (p.M_g >= 112 && round_up(p.M_g, 128) - p.M_g <= p.M_g / 6) ? 2 : 1;
     int TN = 2;
     {
         const long tiles2 = ceil_div(p.M_g, 64 * TM) * (long)d->groups * phases * ((N + 127) / 128);
-        if (tiles2 < 512) TN = 1;
+        if (tiles2 < 256) TN = 1;
         if (TN == 1 && TM == 2) {
             const long tiles1 = ceil_div(p.M_g, 128) * (long)d->groups * phases * ((N + 63) / 64);
             if (tiles1 < 256) TM = 1;
         }
     }
     if (env_tile && env_tile[0] && env_tile[1]) { TM = env_tile[0] - '0'; TN = env_tile[1] - '0'; }
-    GeoH gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min);
-    if (!gm.ok && TN == 2) { TN = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min); }
-    if (!gm.ok && TM == 2) { TM = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min); }
+    GeoH gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max);
+    if (!gm.ok && TN == 2) { TN = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max); }
+    if (!gm.ok && TM == 2) { TM = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max); }
     if (!gm.ok) return 1;
     const int BM = 64 * TM, BN = 64 * TN, NCB = 1 << gm.logNCB, CCH = 8 * NCB;
     p.CC = CCH; p.logCC = gm.logNCB + 3; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.WR = 0; p.U0 = U;
     p.TG = ntaps_max; p.NTG = 1; p.fdNTG = make_fastdiv(1);
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
-    h.XROWP = gm.XROWP; h.XP = gm.XP; h.ntapsW = gm.ntW; h.xit = gm.xit; h.wit = gm.wit;
-    h.fdXROWP = make_fastdiv((uint32_t)gm.XROWP);
+    h.NG = gm.NG; h.fdNG = make_fastdiv((uint32_t)gm.NG); h.ntapsW = gm.ntW; h.xit = gm.xit; h.wit = gm.wit;
+    { const char* ed = getenv("STEGAN_BF16_DBG"); h.dbg = ed ? atoi(ed) : 0; }
+    {
+        const bool al = ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
+                        (!p.mask || ((uintptr_t)p.mask % 16) == 0) && (!workspace || ((uintptr_t)workspace % 16) == 0);
+        // unit output stride (forward, or the input gradient of a stride-1 conv), whole runs of 4 columns per row
+        h.vec_out = al && !p.out_btc && (mode == 0 || d->stride == 1) && U % 4 == 0 && p.Tdst % 4 == 0 &&
+                    (p.ups == 0 || p.Tmask * 2 == p.Tdst) && !getenv("STEGAN_BF16_NO_VEC_OUT");
+    }
     h.src_bytes = (unsigned)((int64_t)d->B * p.Csrc * p.Tsrc * 4);
     const long nb = (N + BN - 1) / BN;
     const int nchunks = ceil_div(p.C2_g, CCH);
@@ -565,6 +659,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     // split-K: a chunk of the bf16 kernel is short (16x the fp32 MFMA rate), so the fixed per-block cost weighs more
     double cost1 = 0;
     int splits = choose_splits(base, nchunks, 0.5, &cost1);
+    if (const char* es = getenv("STEGAN_BF16_SPLITS")) { splits = atoi(es); splits = splits < 1 ? 1 : (splits > nchunks ? nchunks : splits); }
     const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
     if (splits > 1 && (!workspace || workspace_floats < out_elems * splits)) {
         splits = workspace ? (int)(workspace_floats / out_elems) : 1;
@@ -575,7 +670,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     p.splits = ceil_div(nchunks, p.chunks_per_split);
     p.partial = workspace;
     p.mix_S = 0; p.mix_full = 0; p.mix_cps = 0; p.nbx = (int)nb; p.ny = p.m_tiles * d->groups;
-    p.stamps = nullptr;
+    { const char* se = getenv("STEGAN_STAMP_PTR"); p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }
     p.fdMT = make_fastdiv((uint32_t)p.m_tiles); p.fdSP = make_fastdiv((uint32_t)p.splits);
     p.fdNBX = make_fastdiv((uint32_t)p.nbx); p.fdNY = make_fastdiv((uint32_t)p.ny);
     p.fdMS = make_fastdiv(1);
@@ -590,17 +685,21 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         if (dbg) fprintf(stderr, "plan-bf16 mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BM=%d BN=%d CCH=%d nchunks=%d tiles=%ld splits=%d lds=%zu ntW=%d XROW=%d xit=%d wit=%d\n",
                          mode, d->B, p.C2_g, p.M_g, d->K, d->stride, d->dilation, p.Tdst, BM, BN, CCH, nchunks, base, p.splits,
                          gm.lds, gm.ntW, gm.XROW, gm.xit, gm.wit);
+        if (dbg) fprintf(stderr, "          xv=%d\n", (int)xv);
     }
     static bool attr_done = false;
     if (!attr_done) {
-        set_lds_attr<1, 1>(); set_lds_attr<1, 2>(); set_lds_attr<2, 1>(); set_lds_attr<2, 2>();
+        set_lds_attr<1, 1, false>(); set_lds_attr<1, 2, false>(); set_lds_attr<2, 1, false>(); set_lds_attr<2, 2, false>();
+        set_lds_attr<1, 1, true>(); set_lds_attr<1, 2, true>(); set_lds_attr<2, 1, true>(); set_lds_attr<2, 2, true>();
         attr_done = true;
     }
-    dim3 grid((unsigned)nb, (unsigned)(p.m_tiles * d->groups), (unsigned)(phases * p.splits));
-    if (TM == 2 && TN == 2) launch_variant<2, 2>(gm.logNCB, grid, gm.lds, s, h);
-    else if (TM == 2) launch_variant<2, 1>(gm.logNCB, grid, gm.lds, s, h);
-    else if (TN == 2) launch_variant<1, 2>(gm.logNCB, grid, gm.lds, s, h);
-    else launch_variant<1, 1>(gm.logNCB, grid, gm.lds, s, h);
+    dim3 grid((unsigned)(nb * p.m_tiles * d->groups * phases * p.splits));
+#define HB_GO(TM_, TN_) { if (xv) launch_variant<TM_, TN_, true>(gm.logNCB, grid, gm.lds, s, h); else launch_variant<TM_, TN_, false>(gm.logNCB, grid, gm.lds, s, h); }
+    if (TM == 2 && TN == 2) HB_GO(2, 2)
+    else if (TM == 2) HB_GO(2, 1)
+    else if (TN == 2) HB_GO(1, 2)
+    else HB_GO(1, 1)
+#undef HB_GO
     if (p.splits > 1) {
         long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;
         if (eb > 4096) eb = 4096;

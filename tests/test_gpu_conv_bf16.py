@@ -89,7 +89,7 @@ def test_conv_bf16_fwd_bwd_data(cfg):
 
 
 def test_prep_bf16_layout():
-    """wfh[g][k][co][ci] / wbh[g][k][ci][co] x scale, zero padding and the all-zero plane k = K."""
+    """wfh[g][k][ci/8][co][ci%8] / wbh[g][k][co/8][ci][co%8] x scale, zero padding and the all-zero plane k = K."""
     from ste_gan_amd import ops
     Cin, Cout, K, g = 24, 40, 3, 2
     c = ops.ConvCfg(Cin, Cout, K, 1, 1, 1, g)
@@ -103,8 +103,9 @@ def test_prep_bf16_layout():
     finally:
         ops.set_compute_dtype("f32")
     cog, cig = Cout // g, Cin // g
-    wfh = wfh.view(g, K + 1, 128, 64)
-    wbh = wbh.view(g, K + 1, 128, 64)
+    # device layout [g][k][cb][m][8]  ->  [g][k][m][c] for the comparison
+    wfh = wfh.view(g, K + 1, 8, 128, 8).permute(0, 1, 3, 2, 4).reshape(g, K + 1, 128, 64)
+    wbh = wbh.view(g, K + 1, 8, 128, 8).permute(0, 1, 3, 2, 4).reshape(g, K + 1, 128, 64)
     want_f = torch.zeros(g, K + 1, 128, 64)
     want_b = torch.zeros(g, K + 1, 128, 64)
     for gi in range(g):

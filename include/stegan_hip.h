@@ -177,6 +177,16 @@ int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* dy, const u
                              const float* mask_src, const float* add_src, float* dx, float* workspace,
                              int64_t workspace_floats, void* stream);
 
+/*
+ * bf16-operand variant of stegan_conv1d_bwd_weight_ws (same accumulate-into-dw contract, fp32 accumulation, fp32 bias
+ * gradient): both operands are rounded to bf16 while they are staged and read with the transposing LDS load, so any tap
+ * shift / stride is a per-lane address.  The batch is cut into slices that write slabs of `workspace`
+ * ([slice][live tap][Cout][Cin/groups] floats) and a second kernel adds them into dw in a fixed order.  Returns 1 (nothing
+ * enqueued) for shapes left to the fp32 kernels: fewer than 16 channels per group on either side, or no room for one slab.
+ */
+int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                               float* workspace, int64_t workspace_floats, void* stream);
+
 /* db[c] += sum_{b,t} dy[b,c,t] -- the bias gradient alone (also folded into stegan_conv1d_bwd_weight). */
 int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream);
 

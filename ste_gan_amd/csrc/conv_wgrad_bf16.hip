@@ -1,0 +1,430 @@
+// Weight gradient of the 1-D convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate):
+//
+//     dW[co, ci, k] = sum_{b, u}  dy[b, co, u] * xin[b, ci, u*s + k*d - p],       xin = in_act(upsample(x))
+//
+// The reduction runs over the flattened (b, u) axis -- the axis along which BOTH operands are contiguous in HBM -- but a
+// bf16 MFMA operand needs 8 CONSECUTIVE reduction indices per lane, and a tap shift k*d - p moves the x operand by an
+// arbitrary number of 2-byte elements: no aligned 16-byte LDS read can deliver that.  So both tiles are staged
+// channel-block-major, Xs[cb][slot][8 channels] bf16 (the image of conv_bf16.hip: fp32 (B, C, T) loads with lanes along
+// time, converted once, ReLU / nearest-x2 upsample / zero padding resolved while staging), and the operands are read with
+// the transposing LDS read ds_read_b64_tr_b16: every lane supplies the address of one 8-byte piece (4 channels of one
+// slot), a 16-lane group gathers 4 slots x 16 channels and each lane receives 4 consecutive SLOTS of its own channel.
+// A tap shift or a stride is then just a different slot address per lane -- any dilation, any stride, no alignment rule.
+//
+//   * block = 4 waves as 2 (co) x 2 (ci); wave tile 32 TM co x 32 TN ci x KT taps: one dy fragment (2 transposed reads)
+//     feeds TN * KT MFMAs; more than KT live taps run as tap groups (grid dimension).
+//   * a chunk of the reduction = NB batch elements x RU output positions (R = NB * RUp columns, RUp = RU rounded up to 4 so
+//     that the 4 slots of one transposed read never straddle two batch elements; padding columns carry dy = 0);
+//     chunk c + 1 is loaded into registers while chunk c is multiplied, two LDS buffers, one barrier per chunk; there is
+//     no LDS-DMA in the loop, so hipcc's counted vmcnt waits stay exact.
+//   * planes are padded to (slots = 4 mod 16) so that the 32 lanes of a half-wave, which read 4 slots x 2 halves x 2
+//     planes x 2 channel groups, cover all 64 banks once.
+//   * the batch is cut into slices (grid dimension); every slice writes its partial dW to a slab [slice][k][co][ci]
+//     with plain coalesced stores and a second kernel adds the slabs into dW in a fixed order (deterministic).
+//
+// Numerics: bf16-rounded operands, fp32 accumulation; the bias gradient stays fp32 (stegan_bias_grad).
+#include "conv_direct_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WS_MAX = 4;      // staging items (8 channels x 1 slot) per thread, tile and chunk, scalar loads
+constexpr int WSV_MAX = 2;     // ... (8 channels x 4 slots) with 16-byte loads
+constexpr int NST_MAX = 8;     // MFMA k-steps (16 columns) per chunk: R <= 128
+constexpr unsigned OOBW = 0x7ffff000u;
+
+struct WH {
+    const float* x;            // (B, Cin, Tin)
+    const float* dy;           // (B, Cout, Tout)
+    float* partial;            // slabs [slices][K_eff][Cout][Cin_g]
+    int B, Cin, Cout, Cin_g, Cout_g, K, stride, dil, pad, Tin, Te, Tout, ups, relu;
+    int k_lo, K_eff, NTG;      // live taps, tap groups of KT
+    int NB, RU, RUp, R, NST;   // chunk: batch elements, output positions (and padded), columns, k-steps
+    int SEG, RSA, RSX;         // x slots per batch element; slots per channel-block plane of the dy / x image
+    int NGA, NGX, ait, xit;    // staging groups per plane (slots or runs of 4), items per thread
+    int u_chunks;              // chunks along time = ceil(Tout / RU)
+    int co_tiles, ci_tiles, slices, bps;     // bps = batch elements per slice (multiple of NB)
+    unsigned x_bytes, dy_bytes;
+    FastDiv fdNGA, fdNGX, fdRUp, fdSEG, fdUC, fdCI, fdCO, fdTG;
+};
+
+__device__ __forceinline__ unsigned wpack(float a, float b, bool relu) {
+    const f32x2 f = {a, b};
+    s16x2 s = __builtin_bit_cast(s16x2, __builtin_convertvector(f, bf16x2));
+    if (relu) s = __builtin_elementwise_max(s, (s16x2)(0));
+    return __builtin_bit_cast(unsigned, s);
+}
+
+// one 32 x 16 MFMA operand (lane = channel, 8 consecutive reduction columns per half-wave) from a [cb][slot][8] image:
+// two transposed reads of 4 slots each; `a0` = this lane's byte address for the first read, `d1` = byte distance of the second
+__device__ __forceinline__ bf16x8 tr_operand(const char* a0, int d1) {
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(a0 + d1));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TM, int TN, int KT, bool XV>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;          // co x ci tile of the block
+    constexpr int CBA = BM / 8, CBX = BN / 8;          // channel-block planes of the two images
+    constexpr int SI = XV ? WSV_MAX : WS_MAX;
+    extern __shared__ __align__(16) char smem[];       // dy image 0 | x image 0 | dy image 1 | x image 1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // block -> (ci tile fastest, co tile, group, tap group, slice): neighbours share the dy tile
+    unsigned t = blockIdx.x;
+    unsigned q_ = fd_div(t, h.fdCI);
+    const int ci_t = (int)(t - q_ * h.ci_tiles); t = q_;
+    q_ = fd_div(t, h.fdCO);
+    const int co_t = (int)(t - q_ * h.co_tiles); t = q_;
+    const int G = h.Cin / h.Cin_g;
+    const int g = (int)(t % (unsigned)G); t /= (unsigned)G;
+    q_ = fd_div(t, h.fdTG);
+    const int tg = (int)(t - q_ * h.NTG);
+    const int slice = (int)q_;
+    const int co0 = co_t * BM, ci0 = ci_t * BN;
+    const int kk0 = h.k_lo + tg * KT;                  // first tap of this pass
+    const int b_begin = slice * h.bps, b_end = min(h.B, b_begin + h.bps);
+    const int b_chunks = (b_end - b_begin + h.NB - 1) / h.NB;
+    const int nchunks = b_chunks * h.u_chunks;
+
+    const int abuf = CBA * h.RSA * 16, xbuf = CBX * h.RSX * 16, bufsz = abuf + xbuf;
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)h.x, 0, (int)h.x_bytes, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)h.dy, 0, (int)h.dy_bytes, 0x00020000);
+    const bool relu = h.relu != 0;
+
+    // ---- staging items (chunk invariant part): item = (channel block, slot or run of 4 slots), slots fastest
+    int a_cg[SI], a_seg[SI], a_uu[SI], a_lds[SI];       // dy: plane, batch element within the chunk, position, LDS byte (-1: none)
+    int x_cg[SI], x_seg[SI], x_sl[SI], x_lds[SI];
+#pragma unroll
+    for (int it = 0; it < SI; ++it) {
+        const int idx = it * 256 + tid;
+        {
+            const int cg = (int)fd_div((uint32_t)idx, h.fdNGA), grp = idx - cg * h.NGA;
+            const int slot = XV ? grp * 4 : grp;
+            const int seg = (int)fd_div((uint32_t)slot, h.fdRUp);
+            a_cg[it] = cg; a_seg[it] = seg; a_uu[it] = slot - seg * h.RUp;
+            a_lds[it] = (it < h.ait && cg < CBA) ? (cg * h.RSA + slot) * 16 : -1;
+        }
+        {
+            const int cg = (int)fd_div((uint32_t)idx, h.fdNGX), grp = idx - cg * h.NGX;
+            const int slot = XV ? grp * 4 : grp;
+            const int seg = (int)fd_div((uint32_t)slot, h.fdSEG);
+            x_cg[it] = cg; x_seg[it] = seg; x_sl[it] = slot - seg * h.SEG;
+            x_lds[it] = (it < h.xit && cg < CBX) ? (cg * h.RSX + slot) * 16 : -1;
+        }
+    }
+    // ---- operand addresses.  Lane l: half hl, channel l & 31 of the wave's 32-channel tile; inside its 16-lane group
+    // i = l & 15 it supplies the piece (row q = i >> 2, channels 4 p .. 4 p + 3 with p = i & 3) of each transposed read
+    const int hl = lane >> 5, g16 = (lane >> 4) & 1, qrow = (lane >> 2) & 3, pp = lane & 3;
+    int a_byte[TM], b_byte[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        a_byte[i] = (((wm * TM + i) * 4 + 2 * g16 + (pp >> 1)) * h.RSA + 8 * hl + qrow) * 16 + (pp & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_byte[j] = (((wn * TN + j) * 4 + 2 * g16 + (pp >> 1)) * h.RSX + qrow * h.stride) * 16 + (pp & 1) * 8;
+    // x slot of the first column of each transposed read: columns r4 = 16 st + 8 hl + 4 rd -> (batch element, position)
+    int xoff[NST_MAX][2];
+#pragma unroll
+    for (int st = 0; st < NST_MAX; ++st)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r4 = st * 16 + 8 * hl + 4 * rd;
+            const int seg = (int)fd_div((uint32_t)r4, h.fdRUp), uu = r4 - seg * h.RUp;
+            xoff[st][rd] = (seg * h.SEG + uu * h.stride) * 16;
+        }
+    const int tapB = h.dil * 16;
+
+    f32x16 acc[TM][TN][KT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
+
+    float ar[XV ? 1 : WS_MAX][8], xr[XV ? 1 : WS_MAX][8];
+    f32x4 av[XV ? WSV_MAX : 1][8], xv[XV ? WSV_MAX : 1][8];
+    const int rowb_y = h.Tout * 4, rowb_x = h.Tin * 4;
+    const int ylim = h.Cout_g - co0, xlim = h.Cin_g - ci0;       // live channels of the tiles
+    int adj_cur = 0, adj_nxt = 0;                                 // down-rounding of the x window start (XV)
+
+#define WG_LOAD(c_, adj_out)                                                                                    \
+    {                                                                                                           \
+        const int bc_ = (int)fd_div((uint32_t)(c_), h.fdUC), uc_ = (c_) - bc_ * h.u_chunks;                     \
+        const int b0_ = b_begin + bc_ * h.NB, u0_ = uc_ * h.RU;                                                 \
+        const int q0_ = u0_ * h.stride - h.pad + kk0 * h.dil;                                                   \
+        const int qal_ = XV ? (q0_ & ~3) : q0_;                                                                 \
+        adj_out = q0_ - qal_;                                                                                   \
+        _Pragma("unroll") for (int it = 0; it < SI; ++it) {                                                     \
+            if (it < h.ait) {                                                                                   \
+                const int b_ = b0_ + a_seg[it], u_ = u0_ + a_uu[it];                                            \
+                const bool ok_ = a_lds[it] >= 0 && a_seg[it] < h.NB && b_ < b_end && a_uu[it] < h.RU && u_ < h.Tout; \
+                const int vo_ = ok_ ? ((b_ * h.Cout + g * h.Cout_g + co0 + a_cg[it] * 8) * h.Tout + u_) * 4 : (int)OOBW; \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+                    const int vj_ = (a_cg[it] * 8 + j < ylim) ? vo_ : (int)OOBW;                                \
+                    if constexpr (XV) av[it][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_y, vj_, j * rowb_y, 0)); \
+                    else ar[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_y, vj_, j * rowb_y, 0)); \
+                }                                                                                               \
+            }                                                                                                   \
+            if (it < h.xit) {                                                                                   \
+                const int b_ = b0_ + x_seg[it], q_ = qal_ + x_sl[it];                                           \
+                const bool ok_ = x_lds[it] >= 0 && b_ < b_end && q_ >= 0 && q_ < h.Te;                          \
+                const int vo_ = ok_ ? ((b_ * h.Cin + g * h.Cin_g + ci0 + x_cg[it] * 8) * h.Tin + (q_ >> h.ups)) * 4 : (int)OOBW; \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+                    const int vj_ = (x_cg[it] * 8 + j < xlim) ? vo_ : (int)OOBW;                                \
+                    if constexpr (XV) xv[it][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vj_, j * rowb_x, 0)); \
+                    else xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, vj_, j * rowb_x, 0)); \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+#define WG_STORE_ONE(dst_, lds_, r_, v_, relu_)                                                                 \
+    if constexpr (XV) {                                                                                         \
+        _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                      \
+            const u32x4 w_ = {wpack(v_[0][s4], v_[1][s4], relu_), wpack(v_[2][s4], v_[3][s4], relu_),            \
+                              wpack(v_[4][s4], v_[5][s4], relu_), wpack(v_[6][s4], v_[7][s4], relu_)};           \
+            *(u32x4*)(dst_ + lds_ + s4 * 16) = w_;                                                              \
+        }                                                                                                       \
+    } else {                                                                                                    \
+        const u32x4 w_ = {wpack(r_[0], r_[1], relu_), wpack(r_[2], r_[3], relu_), wpack(r_[4], r_[5], relu_), wpack(r_[6], r_[7], relu_)}; \
+        *(u32x4*)(dst_ + lds_) = w_;                                                                            \
+    }
+#define WG_STORE(buf_)                                                                                          \
+    {                                                                                                           \
+        char* A_ = smem + (buf_) * bufsz;                                                                       \
+        char* X_ = A_ + abuf;                                                                                   \
+        _Pragma("unroll") for (int it = 0; it < SI; ++it) {                                                     \
+            if (it < h.ait && a_lds[it] >= 0) { WG_STORE_ONE(A_, a_lds[it], ar[XV ? 0 : it], av[XV ? it : 0], false) } \
+            if (it < h.xit && x_lds[it] >= 0) { WG_STORE_ONE(X_, x_lds[it], xr[XV ? 0 : it], xv[XV ? it : 0], relu) }  \
+        }                                                                                                       \
+    }
+
+    if (nchunks > 0) {
+        WG_LOAD(0, adj_cur)
+        WG_STORE(0)
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        __syncthreads();
+        const bool more = c + 1 < nchunks;
+        if (more) WG_LOAD(c + 1, adj_nxt)
+        const char* Acur = smem + cur * bufsz;
+        const char* Xcur = Acur + abuf + adj_cur * 16;
+        for (int st = 0; st < h.NST; ++st) {
+            bf16x8 a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = tr_operand(Acur + a_byte[i] + st * 256, 64);
+            // xoff is indexed with a runtime st: select through registers (an indexed array would go to scratch)
+            int xo0 = 0, xo1 = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < NST_MAX; ++s2)
+                if (s2 == st) { xo0 = xoff[s2][0]; xo1 = xoff[s2][1]; }
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 b = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j][k], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            WG_STORE(cur ^ 1)
+            adj_cur = adj_nxt;
+        }
+    }
+#undef WG_LOAD
+#undef WG_STORE
+#undef WG_STORE_ONE
+
+    // ---- slab store: accumulator tile = 32 co (registers: 4 runs of 4 rows) x 32 ci (lanes): coalesced along ci
+    const int l31 = lane & 31;
+    float* slab = h.partial + (size_t)slice * h.K_eff * h.Cout * h.Cin_g;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const int kk = tg * KT + k;                        // index among the live taps
+        if (kk >= h.K_eff) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = ci0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int cob = co0 + (wm * TM + i) * 32 + 4 * hl;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cob + (e & 3) + 8 * (e >> 2);
+                    if (ci < h.Cin_g && co < h.Cout_g)
+                        slab[((size_t)kk * h.Cout + g * h.Cout_g + co) * h.Cin_g + ci] = acc[i][j][k][e];
+                }
+            }
+        }
+    }
+}
+
+// dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                     long per_tap, int slices, int K, int k_lo, int K_eff) {
+    const long total = per_tap * K_eff;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int kk = (int)(i / per_tap);
+        const long r = i - (long)kk * per_tap;             // co * Cin_g + ci
+        const float* src = partial + i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= slices; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * total];
+        }
+        for (; s < slices; ++s) v[0] += src[(size_t)s * total];
+        dw[r * K + k_lo + kk] += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+}
+
+int wgh_live_taps(const stegan_conv_desc* d, int& k_lo) {
+    const int Te = d->Tin * d->upsample;
+    int lo = d->K, hi = -1;
+    for (int k = 0; k < d->K; ++k) {
+        const int a = k * d->dilation - d->pad, b = (d->Tout - 1) * d->stride + a;
+        if (b >= 0 && a < Te) { if (k < lo) lo = k; hi = k; }
+    }
+    k_lo = lo;
+    return hi - lo + 1;
+}
+
+template <int TM, int TN, int KT>
+void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(256), lds, s, h);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(256), lds, s, h);
+}
+
+}  // namespace
+
+// Accumulates into dw (and db, through the fp32 bias-gradient kernel).  Returns 1 (nothing enqueued) for shapes left to
+// the fp32 kernels: fewer than 16 channels per group on either side, or a workspace too small for one slab.
+extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                          float* workspace, int64_t workspace_floats, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(x && dy && dw);
+    STEGAN_CHECK_ARG(d->in_act == STEGAN_ACT_NONE || d->in_act == STEGAN_ACT_RELU);
+    hipStream_t s = (hipStream_t)stream;
+    WH h;
+    h.x = x; h.dy = dy;
+    h.B = d->B; h.Cin = d->Cin; h.Cout = d->Cout; h.Cin_g = d->Cin / d->groups; h.Cout_g = d->Cout / d->groups;
+    h.K = d->K; h.stride = d->stride; h.dil = d->dilation; h.pad = d->pad; h.Tin = d->Tin; h.Tout = d->Tout;
+    h.Te = d->Tin * d->upsample; h.ups = d->upsample == 2 ? 1 : 0; h.relu = d->in_act == STEGAN_ACT_RELU;
+    static const char* env_min = getenv("STEGAN_BF16_WGRAD_MIN_C");
+    const int min_c = env_min ? atoi(env_min) : 16;
+    if (h.Cin_g < min_c || h.Cout_g < min_c) return 1;
+    if ((int64_t)d->B * d->Cin * d->Tin * 4 >= (int64_t)OOBW || (int64_t)d->B * d->Cout * d->Tout * 4 >= (int64_t)OOBW) return 1;
+    h.x_bytes = (unsigned)((int64_t)d->B * d->Cin * d->Tin * 4);
+    h.dy_bytes = (unsigned)((int64_t)d->B * d->Cout * d->Tout * 4);
+    h.K_eff = wgh_live_taps(d, h.k_lo);
+    if (h.K_eff <= 0) return STEGAN_OK;                  // every tap reads only padding: dW += 0
+    // tile: 128 x 64 x 3 taps for the dense k = 3 layers; single taps take 128 x 128; more taps 64 x 64 x (5 | 8)
+    int TM, TN, KT;
+    if (h.K_eff == 1) { KT = 1; TM = h.Cout_g >= 96 ? 2 : 1; TN = h.Cin_g >= 96 ? 2 : 1; }
+    else if (h.K_eff <= 3) { KT = 3; TM = h.Cout_g >= 96 ? 2 : 1; TN = 1; }
+    else if (h.K_eff <= 5) { KT = 5; TM = 1; TN = 1; }
+    else { KT = 8; TM = 1; TN = 1; }
+    h.NTG = ceil_div(h.K_eff, KT);
+    const int BM = 64 * TM, BN = 64 * TN;
+    const bool xv = h.Tin % 4 == 0 && h.Tout % 4 == 0 && h.ups == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                    !getenv("STEGAN_BF16_NO_XV");
+    // chunk of the reduction: up to RMAX columns (LDS budget / halo share), whole batch elements when the rows are short
+    static const char* env_r = getenv("STEGAN_BF16_WGRAD_R");
+    const int RMAX = env_r ? atoi(env_r) : 64;
+    h.RU = h.Tout < RMAX ? h.Tout : RMAX;
+    h.RUp = round_up(h.RU, 4);
+    h.NB = h.RUp < RMAX ? RMAX / h.RUp : 1;
+    if (h.NB > h.B) h.NB = h.B;
+    h.R = round_up(h.NB * h.RUp, 16);
+    h.NST = h.R / 16;
+    if (h.NST > NST_MAX) return 1;
+    h.u_chunks = ceil_div(h.Tout, h.RU);
+    h.SEG = (h.RUp - 1) * h.stride + (KT - 1) * h.dil + 1;
+    if (xv) h.SEG = (h.SEG + 3 + 3) & ~3;
+    // columns of the last k-step past NB * RUp belong to "batch element NB": its slots must exist (they hold zeros)
+    const int segs = ceil_div(h.R, h.RUp);
+    auto pad4 = [](int v) { int r = v % 16; return v + ((4 - r) + 16) % 16; };     // slots = 4 (mod 16): conflict-free reads
+    // staged slots: the R columns of dy; for x the segments plus up to 3 slots of down-rounding and the reach of the last
+    // transposed read; the planes are then padded (never staged, never read) to the conflict-free pitch
+    const int xslots = round_up(segs * h.SEG + 4, 4);
+    h.RSA = pad4(h.R);
+    h.RSX = pad4(xslots);
+    h.NGA = xv ? h.R / 4 : h.R;
+    h.NGX = xv ? xslots / 4 : xslots;
+    h.ait = ceil_div((BM / 8) * h.NGA, 256);
+    h.xit = ceil_div((BN / 8) * h.NGX, 256);
+    if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return 1;
+    const size_t lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
+    if (lds > 160 * 1024) return 1;
+    h.co_tiles = ceil_div(h.Cout_g, BM); h.ci_tiles = ceil_div(h.Cin_g, BN);
+    const long tiles = (long)h.co_tiles * h.ci_tiles * d->groups * h.NTG;
+    // slices of the batch: fill the chip (two blocks per CU), bounded by the workspace and by one chunk per slice
+    const int64_t slab = (int64_t)h.K_eff * h.Cout * h.Cin_g;
+    if (!workspace || workspace_floats < slab) return 1;
+    const int b_chunks = ceil_div(h.B, h.NB);
+    long want = (512 + tiles - 1) / tiles;
+    if (const char* es = getenv("STEGAN_BF16_WGRAD_SLICES")) want = atol(es);
+    if (want > b_chunks) want = b_chunks;
+    if (want > workspace_floats / slab) want = workspace_floats / slab;
+    if (want < 1) want = 1;
+    h.bps = ceil_div(b_chunks, (int)want) * h.NB;
+    h.slices = ceil_div(h.B, h.bps);
+    h.partial = workspace;
+    h.fdNGA = make_fastdiv((uint32_t)h.NGA); h.fdNGX = make_fastdiv((uint32_t)h.NGX);
+    h.fdRUp = make_fastdiv((uint32_t)h.RUp); h.fdSEG = make_fastdiv((uint32_t)h.SEG);
+    h.fdUC = make_fastdiv((uint32_t)h.u_chunks); h.fdCI = make_fastdiv((uint32_t)h.ci_tiles);
+    h.fdCO = make_fastdiv((uint32_t)h.co_tiles); h.fdTG = make_fastdiv((uint32_t)h.NTG);
+    {
+        static const char* dbg = getenv("STEGAN_PLAN_DEBUG");
+        if (dbg) fprintf(stderr, "plan-wgrad-bf16 B=%d Cin_g=%d Cout_g=%d K=%d(live %d) s=%d d=%d T=%d->%d | tile %dx%dx%d NTG=%d NB=%d RU=%d R=%d SEG=%d RSA=%d RSX=%d ait=%d xit=%d lds=%zu tiles=%ld slices=%d xv=%d\n",
+                         d->B, h.Cin_g, h.Cout_g, d->K, h.K_eff, d->stride, d->dilation, d->Tin, d->Tout, BM, BN, KT, h.NTG, h.NB,
+                         h.RU, h.R, h.SEG, h.RSA, h.RSX, h.ait, h.xit, lds, tiles, h.slices, (int)xv);
+    }
+    dim3 grid((unsigned)(tiles * h.slices));
+    if (KT == 1) {
+        if (TM == 2 && TN == 2) wgh_launch<2, 2, 1>(xv, grid, lds, s, h);
+        else if (TM == 2) wgh_launch<2, 1, 1>(xv, grid, lds, s, h);
+        else if (TN == 2) wgh_launch<1, 2, 1>(xv, grid, lds, s, h);
+        else wgh_launch<1, 1, 1>(xv, grid, lds, s, h);
+    } else if (KT == 3) {
+        if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h);
+        else wgh_launch<1, 1, 3>(xv, grid, lds, s, h);
+    } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h);
+    else wgh_launch<1, 1, 8>(xv, grid, lds, s, h);
+    {
+        const long per_tap = (long)h.Cout * h.Cin_g;
+        long rb = (per_tap * h.K_eff + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, h.partial, dw, per_tap, h.slices,
+                           d->K, h.k_lo, h.K_eff);
+    }
+    STEGAN_LAUNCH_CHECK();
+    if (db) return stegan_bias_grad(dy, db, d->B, d->Cout, d->Tout, stream);
+    return STEGAN_OK;
+}

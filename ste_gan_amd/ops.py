@@ -109,7 +109,7 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     if kind == "direct":
         name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     elif kind == "bf16":
-        name = "conv_bf16_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
+        name = "conv_wgrad_bf16_kernel" if mode == 2 else "conv_bf16_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     elif mode == 2:
         name = "bwd_weight (conv_wgrad_kernel | conv_igemm_kernel<2>)"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -281,6 +281,12 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
     ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
+    if COMPUTE_DTYPE == "bf16":
+        rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_h(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
+                                                                        ws.numel(), _stream()), "bf16")
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_weight_h")
+            return
     check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                                                       ws.numel(), _stream())),
           "stegan_conv1d_bwd_weight_ws")

@@ -88,6 +88,50 @@ def test_conv_bf16_fwd_bwd_data(cfg):
             assert float((got - f32).abs().max()) <= 2e-5 * scale_
 
 
+@pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16_bwd_weight(cfg):
+    """dW (accumulated into a non-zero buffer) and db of stegan_conv1d_bwd_weight_h against fp64 on bf16-rounded operands."""
+    from ste_gan_amd import ops
+    B, Cin, Cout, K, s, d, p, g, up, relu, Tin = cfg
+    gen = torch.Generator().manual_seed(hash(cfg) % (2 ** 31) + 1)
+    x = torch.randn(B, Cin, Tin, generator=gen)
+    c = ops.ConvCfg(Cin, Cout, K, s, d, p, g, up, 1 if relu else 0)
+    Tout = c.tout(Tin)
+    dy = torch.randn(B, Cout, Tout, generator=gen)
+    hx = F.relu(x) if relu else x
+    if up == 2:
+        hx = F.interpolate(hx, scale_factor=2.0, mode="nearest")
+
+    def dw_of(x_, dy_):
+        w0 = torch.zeros(Cout, Cin // g, K, dtype=torch.float64, requires_grad=True)
+        y0 = F.conv1d(x_, w0, None, stride=s, dilation=d, padding=p, groups=g)
+        (gw,) = torch.autograd.grad(y0, w0, dy_)
+        return gw
+
+    dw_ref, dw_f32 = dw_of(bf16r(hx), bf16r(dy)), dw_of(hx.double(), dy.double())
+    db_ref = dy.double().sum((0, 2))
+    dw = torch.full((Cout, Cin // g, K), 0.25, device="cuda")
+    db = torch.full((Cout,), -1.0, device="cuda")
+    ops.set_compute_dtype("bf16")
+    try:
+        ops.conv1d_bwd_weight(x.cuda(), dy.cuda(), c, dw, db)
+        kern = ops.LAST_CONV_KERNEL
+    finally:
+        ops.set_compute_dtype("f32")
+    if Cin // g < 16 or Cout // g < 16:
+        assert kern == "igemm", kern                       # narrow groups stay on the exact fp32 kernels
+    elif s == 1:
+        assert kern == "bf16", kern                        # (strided layers with long halo'd rows may not fit: fp32 then)
+    got = dw.double().cpu() - 0.25
+    scale_ = float(dw_f32.abs().max())
+    if kern == "bf16":
+        assert float((got - dw_ref).abs().max()) <= 3e-5 * scale_ + 1e-6, (float((got - dw_ref).abs().max()), scale_)
+        assert float((got - dw_f32).abs().max()) <= 3e-2 * scale_
+    else:
+        assert float((got - dw_f32).abs().max()) <= 1e-4 * scale_
+    assert float((db.double().cpu() + 1.0 - db_ref).abs().max()) <= 1e-4 * float(db_ref.abs().max()) + 1e-5
+
+
 def test_prep_bf16_layout():
     """wfh[g][k][ci/8][co][ci%8] / wbh[g][k][co/8][ci][co%8] x scale, zero padding and the all-zero plane k = K."""
     from ste_gan_amd import ops

@@ -33,6 +33,11 @@ for (name, Cin, Cout, K, s, d, p, g, up, relu, Tin, Be) in LAYERS:
     t0 = st[:, 0].min()
     tick = 1.0             # s_memtime ticks are shader cycles (MI355X_MICROARCH.md); counters of different XCDs are not aligned
     print(f"{name} [{mode}]: {len(st)} blocks, event time {e0.elapsed_time(e1) * 1e3:.1f} us (incl. launch)")
+    if os.environ.get("STAMPS_ITER"):          # build with STAMP_FLAGS=-DSTEGAN_STAMPS_ITER: tops of iterations 1, 5, ..., 21
+        m = lambda a, b: np.median(st[:, b] - st[:, a]) / 4
+        print("  cycles per iteration (median over blocks), iterations 1-5, 5-9, 9-13, 13-17, 17-21: " +
+              "  ".join(f"{m(i, i + 1):.0f}" for i in range(1, 6)))
+        continue
     seg = lambda a, b: np.median(st[:, b] - st[:, a]) * tick
     p90 = lambda a, b: np.percentile(st[:, b] - st[:, a], 90) * tick
     print(f"  per block, cycles (median | p90): setup {seg(0, 1):.0f} | {p90(0, 1):.0f}   first chunk {seg(1, 2):.0f} | {p90(1, 2):.0f}   "

@@ -25,7 +25,8 @@
 //   * the reduction runs over "atoms" = (tap, 8-channel block); one MFMA consumes two atoms (lane halves): with >= 16
 //     channels per chunk the halves take neighbouring channel blocks of one tap, with 8-channel chunks (first layers,
 //     narrow groups, many-tap layers where the W tile must stay small) they take neighbouring TAPS.
-//   * block = 4 waves (2 x 2), wave tile 32 TM x 32 TN, block tile up to 128 x 128; the X fragment is the MFMA's A
+//   * block = 8 waves with fixed roles: 4 consumer waves (2 x 2, wave tile 32 TM x 32 TN, block tile up to 128 x 128) only
+//     multiply, 4 producer waves only stage, one of each per SIMD (see the kernel body); the X fragment is the MFMA's A
 //     operand, so an accumulator tile holds its output channel on the lane and 4 runs of 4 consecutive time steps in
 //     its registers: the epilogue loads / stores 16 bytes per lane; split-K and its fixed-order epilogue kernel are
 //     shared with the fp32 kernel; blocks are mapped to tiles XCD-aware (M tiles fastest inside one XCD's range).
@@ -71,6 +72,12 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
 // XV: 16-byte X loads (4 consecutive time slots per lane): rows and valid extent multiples of 4 floats, no upsample;
 // every segment then starts at the source position rounded DOWN to a multiple of 4 and the rounding (0..3 slots) is
 // added to the lanes' column bases instead (the fp32 kernel's XVEC idea).
+#ifdef STEGAN_BF16_ABLATE       // diagnostic builds: STEGAN_BF16_DBG bits switch parts of the kernel off (results wrong)
+#define HB_DBG(bit_) (h.dbg & (bit_))
+#else
+#define HB_DBG(bit_) false
+#endif
+
 template <int TM, int TN, int LOGNCB, bool XV>
 __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
     const DirP& p = h.d;
@@ -79,11 +86,18 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     constexpr int KS = NCB >= 2 ? NCB / 2 : 1;        // MFMA k-steps per tap (NCB >= 2) / per tap pair (NCB == 1)
     extern __shared__ __align__(16) char smem[];      // W ring (2 chunks) | X ring (2 chunks)
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 512 threads = 8 waves, two per SIMD, with fixed roles: waves 0-3 ("consumers") only read MFMA operands from LDS and
+    // multiply; waves 4-7 ("producers") only stage -- X loads, W LDS-DMA, bf16 conversion, LDS stores.  One wave alone on a
+    // SIMD runs its instruction streams back to back: measured per iteration of a 128 x 128 x 32-channel chunk
+    // (scripts/bf16_stamps.py, STEGAN_STAMPS_ITER) 912 cycles to issue the 14 vector-memory instructions, 792 for the 24
+    // MFMAs (exactly their pipe time), 332 waiting for the loads and 788 to convert and store: the matrix pipe idled 72 % of
+    // the loop.  With the roles on different waves of each SIMD the staging of chunk c + 1 runs beside the MFMAs of chunk c.
+    const int tid = threadIdx.x & 255, lane = tid & 63;           // index inside the role's 256 threads
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave inside the role
     const int wm = wave >> 1, wn = wave & 1;
 #ifdef STEGAN_STAMPS          // diagnostic builds only (scripts/bf16_stamps.py): 8 s_memtime stamps per block
-#define HSTAMP(i_) if (p.stamps && tid == 0) p.stamps[(size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#define HSTAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
 #else
 #define HSTAMP(i_)
 #endif
@@ -135,6 +149,23 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int b_lo = (int)fd_div((uint32_t)n0, fdU), u0 = n0 - b_lo * U;
     const int qbase0 = u0 * cs + off_min, qbaseN = off_min;
     const int qal0 = XV ? (qbase0 & ~3) : qbase0, qalN = XV ? (qbaseN & ~3) : qbaseN;
+    const int CCH = 8 * NCB;
+    const int nchunks = ntaps > 0 ? (p.C2_g + CCH - 1) / CCH : 0;
+    const int c_begin = split * cps;
+    const int c_end = min(nchunks, c_begin + cps);
+    const char* wt_g = (const char*)h.wh + (size_t)g * (p.K + 1) * h.Mpad * h.Cpad * 2;
+    const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = NCB * p.XROW * 16;
+    char* const Xbufs = smem + 2 * wbuf;                           // W ring of 2 | X ring of 2
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)h.src_bytes, 0x00020000);
+    const bool relu = p.in_relu != 0;
+    const int row_bytes = p.Tsrc * 4;
+    const int chunk_w = NCB * h.Mpad * 16;                         // bytes between the weights of neighbouring chunks
+
+
+    // ================= producers (waves 4-7): stage chunk c + 1 while the consumers multiply chunk c =================
+    // (each role computes only its own per-lane state inside its branch: register demand is the maximum of the two
+    // roles, not their sum)
+    if (producer) {
     constexpr int XI = XV ? HXV_MAX : HX_MAX;
     unsigned x_voff[XI];
     int x_lds[XI], x_c8[XI];             // LDS byte offset of the item's first slot (-1: no item); 8 * cg
@@ -164,9 +195,96 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         const int m = piece & (BM - 1), r = piece / BM;
         const int cb = r & (NCB - 1), tap = r >> LOGNCB;
         const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;            // dead tap of an odd pair: the zero plane
-        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : -1;
+        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
     }
 
+    // staged X values of the chunk in flight: scalar form xAr[it][j] = channel j of the item's slot; vector form
+    // xAv[it][j] = 4 slots of channel j
+    float xAr[XV ? 1 : HX_MAX][8];
+    f32x4 xAv[XV ? HXV_MAX : 1][8];
+#define HB_LOAD_X(c_, xr, xv)                                                                                   \
+    {                                                                                                           \
+        const int c0_ = (c_) * CCH;                                                                             \
+        const int lim_ = p.C2_g - c0_;                  /* live channels of this chunk (ragged last chunk)     */ \
+        const bool full_ = lim_ >= CCH;                 /* scalar: the per-load select folds away              */ \
+        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
+            if (it < h.xit && !HB_DBG(1)) {                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+                    /* channels past the group: out-of-range offset, the buffer unit returns 0 */               \
+                    const int vo_ = (full_ || x_c8[it] + j < lim_) ? (int)x_voff[it] : (int)OOB;                \
+                    const int so_ = (c0_ + j) * row_bytes;                                                      \
+                    if constexpr (XV) xv[it][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_, so_, 0)); \
+                    else xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_, so_, 0)); \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+#define HB_STORE_X(buf_, xr, xv)                                                                                \
+    if (relu) { HB_STORE_X_(buf_, xr, xv, true) } else { HB_STORE_X_(buf_, xr, xv, false) }
+#define HB_STORE_X_(buf_, xr, xv, relu)                                                                         \
+    {                                                                                                           \
+        char* Xd_ = Xbufs + (buf_) * xbuf;                                                                      \
+        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
+            if (it < h.xit && x_lds[it] >= 0 && !HB_DBG(8)) {                                                 \
+                if constexpr (XV) {                                                                             \
+                    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                          \
+                        const u32x4 v_ = {pack_bf16x2(xv[it][0][s4], xv[it][1][s4], relu), pack_bf16x2(xv[it][2][s4], xv[it][3][s4], relu), \
+                                          pack_bf16x2(xv[it][4][s4], xv[it][5][s4], relu), pack_bf16x2(xv[it][6][s4], xv[it][7][s4], relu)}; \
+                        *(u32x4*)(Xd_ + x_lds[it] + s4 * 16) = v_;                                              \
+                    }                                                                                           \
+                } else {                                                                                        \
+                    const u32x4 v_ = {pack_bf16x2(xr[it][0], xr[it][1], relu), pack_bf16x2(xr[it][2], xr[it][3], relu), \
+                                      pack_bf16x2(xr[it][4], xr[it][5], relu), pack_bf16x2(xr[it][6], xr[it][7], relu)}; \
+                    *(u32x4*)(Xd_ + x_lds[it]) = v_;                                                            \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+#define HB_DMA_W(c_, buf_)                                                                                      \
+    {                                                                                                           \
+        const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
+        char* Wd_ = smem + (buf_) * wbuf;                                                                       \
+        _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                 \
+            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !HB_DBG(2)) {                     \
+                const char* src_ = wc_ + w_off[it];                                                             \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (it * 256 + wave * 64) * 16), 16, 0, 0); \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // Pipeline, one chunk ahead, two LDS buffers per operand, ONE barrier per chunk:
+    //   iteration c: [barrier] issue W(c+1) LDS-DMA + X(c+1) loads -> MFMAs of chunk c -> convert + store X(c+1)
+    // Two blocks share a CU where the grid allows, so one block's global round trip hides under the other's MFMAs.  (A
+    // two-chunks-ahead variant -- ring of 3 W buffers, two X register sets -- was built and measured: hipcc drains
+    // vmcnt(0) at every use of an ordinary load while an LDS-DMA is in flight, and with both operands staged through
+    // registers the per-item guards around the loads make its wait counting fall back to vmcnt(0) as well; the
+    // iteration time did not move and the doubled registers cost the second block per CU.)
+#ifndef STEGAN_STAMPS_ITER
+        HSTAMP(1)
+#endif
+        if (c_begin < c_end) {
+            HB_LOAD_X(c_begin, xAr, xAv)
+            HB_DMA_W(c_begin, 0)
+            HB_STORE_X(0, xAr, xAv)
+        }
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cur = (c - c_begin) & 1;
+            __syncthreads();                // all 8 waves: chunk c is staged; nobody reads buffer cur ^ 1 any more
+            if (c + 1 < c_end) {
+                HB_LOAD_X(c + 1, xAr, xAv)
+                HB_DMA_W(c + 1, cur ^ 1)
+                HB_STORE_X(cur ^ 1, xAr, xAv)
+            }
+        }
+        return;                             // the accumulators live in the consumer waves
+    }
+#undef HB_LOAD_X
+#undef HB_STORE_X
+#undef HB_STORE_X_
+#undef HB_DMA_W
+
+    // ================= consumers (waves 0-3): LDS operand reads + MFMAs, then the epilogue =================
     // ---- per-lane operand addresses.  Reduction "atoms" (tap, cb) are BM (W) / XROW or step (X) 16-byte pieces apart; the
     // two lane halves of an MFMA take atoms 2 s and 2 s + 1 of k-step s: W offset s * 2 BM * 16 for every chunk shape
     const int hl = lane >> 5, l31 = lane & 31;
@@ -195,70 +313,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int CCH = 8 * NCB;
-    const int nchunks = ntaps > 0 ? (p.C2_g + CCH - 1) / CCH : 0;
-    const int c_begin = split * cps;
-    const int c_end = min(nchunks, c_begin + cps);
-    const char* wt_g = (const char*)h.wh + (size_t)g * (p.K + 1) * h.Mpad * h.Cpad * 2;
-    const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = NCB * p.XROW * 16;
-    char* const Xbufs = smem + 2 * wbuf;                           // W ring of 2 | X ring of 2
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)h.src_bytes, 0x00020000);
-    const bool relu = p.in_relu != 0;
-    const int row_bytes = p.Tsrc * 4;
-    const int chunk_w = NCB * h.Mpad * 16;                         // bytes between the weights of neighbouring chunks
-
-    // staged X values of the chunk in flight: scalar form xAr[it][j] = channel j of the item's slot; vector form
-    // xAv[it][j] = 4 slots of channel j
-    float xAr[XV ? 1 : HX_MAX][8];
-    f32x4 xAv[XV ? HXV_MAX : 1][8];
-#define HB_LOAD_X(c_, xr, xv)                                                                                   \
-    {                                                                                                           \
-        const int c0_ = (c_) * CCH;                                                                             \
-        const int lim_ = p.C2_g - c0_;                  /* live channels of this chunk (ragged last chunk)     */ \
-        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
-            if (it < h.xit && !(h.dbg & 1)) {                                                                   \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
-                    /* channels past the group: out-of-range offset, the buffer unit returns 0 */               \
-                    const int vo_ = (x_c8[it] + j < lim_) ? (int)x_voff[it] : (int)OOB;                         \
-                    const int so_ = (c0_ + j) * row_bytes;                                                      \
-                    if constexpr (XV) xv[it][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo_, so_, 0)); \
-                    else xr[it][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, vo_, so_, 0)); \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-#define HB_STORE_X(buf_, xr, xv)                                                                                \
-    {                                                                                                           \
-        char* Xd_ = Xbufs + (buf_) * xbuf;                                                                      \
-        _Pragma("unroll") for (int it = 0; it < XI; ++it) {                                                     \
-            if (it < h.xit && x_lds[it] >= 0 && !(h.dbg & 8)) {                                                 \
-                if constexpr (XV) {                                                                             \
-                    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                          \
-                        const u32x4 v_ = {pack_bf16x2(xv[it][0][s4], xv[it][1][s4], relu), pack_bf16x2(xv[it][2][s4], xv[it][3][s4], relu), \
-                                          pack_bf16x2(xv[it][4][s4], xv[it][5][s4], relu), pack_bf16x2(xv[it][6][s4], xv[it][7][s4], relu)}; \
-                        *(u32x4*)(Xd_ + x_lds[it] + s4 * 16) = v_;                                              \
-                    }                                                                                           \
-                } else {                                                                                        \
-                    const u32x4 v_ = {pack_bf16x2(xr[it][0], xr[it][1], relu), pack_bf16x2(xr[it][2], xr[it][3], relu), \
-                                      pack_bf16x2(xr[it][4], xr[it][5], relu), pack_bf16x2(xr[it][6], xr[it][7], relu)}; \
-                    *(u32x4*)(Xd_ + x_lds[it]) = v_;                                                            \
-                }                                                                                               \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-#define HB_DMA_W(c_, buf_)                                                                                      \
-    {                                                                                                           \
-        const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
-        char* Wd_ = smem + (buf_) * wbuf;                                                                       \
-        _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                 \
-            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !(h.dbg & 2)) {                     \
-                const char* src_ = wc_ + (w_off[it] >= 0 ? w_off[it] : 0);                                      \
-                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (it * 256 + wave * 64) * 16), 16, 0, 0); \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
 #define HB_LDS(ptr_) (*(const bf16x8*)(ptr_))
 #define HB_LOAD(a_, b_, s_)                                                                                     \
     {                                                                                                           \
@@ -273,7 +327,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_[j], a_[i], acc[i][j], 0, 0, 0);
     // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
 #define HB_COMPUTE(c_)                                                                                          \
-    if (!(h.dbg & 4)) {                                                                                         \
+    if (!HB_DBG(4)) {                                                                                           \
         const char* Wcur = smem + (((c_) - c_begin) & 1) * wbuf;                                                \
         const char* Xcur = Xbufs + (((c_) - c_begin) & 1) * xbuf;                                               \
         bf16x8 aA[TM], bA[TN], aB[TM], bB[TN];                                                                  \
@@ -287,40 +341,28 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         }                                                                                                       \
         if (s < S) { HB_MFMA(aA, bA) }                                                                          \
     }
-    // Pipeline, one chunk ahead, two LDS buffers per operand, ONE barrier per chunk:
-    //   iteration c: [barrier] issue W(c+1) LDS-DMA + X(c+1) loads -> MFMAs of chunk c -> convert + store X(c+1)
-    // Two blocks share a CU where the grid allows, so one block's global round trip hides under the other's MFMAs.  (A
-    // two-chunks-ahead variant -- ring of 3 W buffers, two X register sets -- was built and measured: hipcc drains
-    // vmcnt(0) at every use of an ordinary load while an LDS-DMA is in flight, and with both operands staged through
-    // registers the per-item guards around the loads make its wait counting fall back to vmcnt(0) as well; the
-    // iteration time did not move and the doubled registers cost the second block per CU.)
-    HSTAMP(1)
-    if (c_begin < c_end) {
-        HB_LOAD_X(c_begin, xAr, xAv)
-        HB_DMA_W(c_begin, 0)
-        HB_STORE_X(0, xAr, xAv)
-    }
+#ifndef STEGAN_STAMPS_ITER
     HSTAMP(2)
+#endif
     for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        __syncthreads();                    // chunk c's X stores and W DMA (vmcnt(0) + barrier) are visible; nobody reads cur ^ 1
+        __syncthreads();
+#ifdef STEGAN_STAMPS_ITER                   // diagnostic: tops of iterations 1, 5, 9, 13, 17, 21 in stamps 1..6
+        if (c == c_begin + 1) { HSTAMP(1) }
+        if (c == c_begin + 5) { HSTAMP(2) }
+        if (c == c_begin + 9) { HSTAMP(3) }
+        if (c == c_begin + 13) { HSTAMP(4) }
+        if (c == c_begin + 17) { HSTAMP(5) }
+        if (c == c_begin + 21) { HSTAMP(6) }
+#else
         if (c == c_begin + 1) { HSTAMP(3) }
         if (c == c_begin + 5) { HSTAMP(4) }
-        const bool more = c + 1 < c_end;
-        if (more) {
-            HB_LOAD_X(c + 1, xAr, xAv)      // into registers; written to LDS behind the MFMA loop
-            HB_DMA_W(c + 1, cur ^ 1)
-        }
+#endif
         HB_COMPUTE(c)
-        if (more) HB_STORE_X(cur ^ 1, xAr, xAv)
     }
 #undef HB_COMPUTE
 #undef HB_MFMA
 #undef HB_LOAD
 #undef HB_LDS
-#undef HB_LOAD_X
-#undef HB_STORE_X
-#undef HB_DMA_W
 
     // ---- epilogue.  The MFMAs ran with the X fragment as the A operand, so a 32 x 32 accumulator tile has its output
     // CHANNEL on the lane and 16 output COLUMNS (time) in its registers, as four runs of 4 consecutive columns
@@ -328,8 +370,10 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // consecutive, 16-byte aligned floats of one output row (unit output stride, column count a multiple of 4) a run is ONE
     // 16-byte load per fused input (residual, mask) and ONE 16-byte store.  (The first version kept channels in the
     // registers: 64 dword stores and 128 dependent scalar-per-lane loads per lane cost as much as the whole main loop.)
+#ifndef STEGAN_STAMPS_ITER
     HSTAMP(5)
-    if (h.dbg & 16) {
+#endif
+    if (HB_DBG(16)) {
         if (acc[0][0][0] == 123.456f) p.out[0] = 1.f;        // keep the accumulators alive
         return;
     }
@@ -432,9 +476,11 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         }
     }
 #undef HB_ACT16
+#ifndef STEGAN_STAMPS_ITER
     HSTAMP(6)
-#ifdef STEGAN_STAMPS
-    if (p.stamps && tid == 0) {
+#endif
+#if defined(STEGAN_STAMPS) && !defined(STEGAN_STAMPS_ITER)
+    if (p.stamps && threadIdx.x == 0) {
         __builtin_amdgcn_s_waitcnt(0);                         // stores drained (vmcnt 0)
         p.stamps[(size_t)bid_x * 8 + 7] = __builtin_amdgcn_s_memtime();
     }
@@ -443,7 +489,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 }
 
 template <int TM, int TN, int LOGNCB, bool XV>
-__global__ __launch_bounds__(256) void conv_bf16_kernel(const HP h) {
+__global__ __launch_bounds__(512) void conv_bf16_kernel(const HP h) {
     conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -557,10 +603,10 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
 template <int TM, int TN, bool XV>
 void launch_variant(int logNCB, dim3 grid, size_t lds, hipStream_t s, const HP& h) {
     switch (logNCB) {
-        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV>), grid, dim3(256), lds, s, h); break;
-        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV>), grid, dim3(256), lds, s, h); break;
-        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV>), grid, dim3(256), lds, s, h); break;
-        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV>), grid, dim3(256), lds, s, h); break;
+        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV>), grid, dim3(512), lds, s, h); break;
+        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV>), grid, dim3(512), lds, s, h); break;
+        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV>), grid, dim3(512), lds, s, h); break;
+        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV>), grid, dim3(512), lds, s, h); break;
     }
 }
 
@@ -617,24 +663,47 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     // 16-byte X loads need float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
     const bool xv = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
                     !getenv("STEGAN_BF16_NO_XV");
-    // tile: 128 rows when the padding it adds stays small; 128 columns unless the grid gets too small to fill the chip
+    // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the
+    // graph-timed microbenchmark (scripts/bf16_stamps.py, scripts/bf16_microbench.py) on the hot-path layers:
+    //   block time   = 5 (index setup + epilogue) + chunks x (0.35 + staged bytes per chunk / 68 KB per us): an iteration is
+    //                  bound by the producer waves, whose time grows with the bytes they stage;
+    //   co-residency : two blocks share a CU when their LDS allows it and the tile is not 128 x 128 (registers); each then
+    //                  runs ~20 % slower;
+    //   launch time  = rounds x block time (+ 6 + (splits + 1) x output bytes / 3 TB/s for the split-K partials and their
+    //                  epilogue kernel).
     const char* env_tile = getenv("STEGAN_BF16_TILE");                 // "MN", e.g. "22", "11" (experiments)
     const char* env_cch = getenv("STEGAN_BF16_CCH_MAX");
+    const char* env_spl = getenv("STEGAN_BF16_SPLITS");
     const int cch_max = env_cch ? atoi(env_cch) : 64;
-    int TM = (p.M_g >= 112 && round_up(p.M_g, 128) - p.M_g <= p.M_g / 6) ? 2 : 1;
-    int TN = 2;
-    {
-        const long tiles2 = ceil_div(p.M_g, 64 * TM) * (long)d->groups * phases * ((N + 127) / 128);
-        if (tiles2 < 256) TN = 1;
-        if (TN == 1 && TM == 2) {
-            const long tiles1 = ceil_div(p.M_g, 128) * (long)d->groups * phases * ((N + 63) / 64);
-            if (tiles1 < 256) TM = 1;
+    const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
+    const int max_splits = workspace ? (int)(workspace_floats / out_elems < 16 ? workspace_floats / out_elems : 16) : 1;
+    int TM = 0, TN = 0, splits = 1;
+    GeoH gm;
+    gm.ok = false;
+    double best = 1e30;
+    for (int cand = 0; cand < 4; ++cand) {
+        const int tm = cand < 2 ? 2 : 1, tn = (cand & 1) ? 1 : 2;      // (2,2) (2,1) (1,2) (1,1)
+        if (env_tile && env_tile[0] && env_tile[1] && (tm != env_tile[0] - '0' || tn != env_tile[1] - '0')) continue;
+        if (tm == 2 && p.M_g <= 64) continue;
+        const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max);
+        if (!g2.ok) continue;
+        const int cch = 8 << g2.logNCB, nch = ceil_div(p.C2_g, cch);
+        const long blocks1 = ceil_div(p.M_g, 64 * tm) * (long)d->groups * phases * ((N + 64 * tn - 1) / (64 * tn));
+        const double bytes = (double)g2.ntW * 64 * tm * cch * 2 + (double)g2.XROW * cch * 4;
+        const bool pair = g2.lds <= 80 * 1024 && !(tm == 2 && tn == 2);
+        for (int sp = 1; sp <= (max_splits < nch ? max_splits : nch); ++sp) {
+            if (env_spl && sp != atoi(env_spl) && !(atoi(env_spl) > nch && sp == nch)) continue;
+            const int per = ceil_div(nch, sp);
+            if (sp > 1 && ceil_div(nch, per) != sp) continue;          // same per-block chain as a smaller factor
+            const long blocks = blocks1 * sp;
+            const long cap = pair && blocks > 256 ? 512 : 256;
+            const double t_iter = (0.35 + bytes / 68e3) * (cap == 512 ? 1.2 : 1.0);
+            const double rounds = (double)((blocks + cap - 1) / cap);
+            double t = rounds * (5.0 + per * t_iter);
+            if (sp > 1) t += 6.0 + (sp + 1) * (double)out_elems * 4.0 / 3e6;
+            if (t < best - 1e-9) { best = t; TM = tm; TN = tn; splits = sp; gm = g2; }
         }
     }
-    if (env_tile && env_tile[0] && env_tile[1]) { TM = env_tile[0] - '0'; TN = env_tile[1] - '0'; }
-    GeoH gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max);
-    if (!gm.ok && TN == 2) { TN = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max); }
-    if (!gm.ok && TM == 2) { TM = 1; gm = plan_bf16(TM, TN, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max); }
     if (!gm.ok) return 1;
     const int BM = 64 * TM, BN = 64 * TN, NCB = 1 << gm.logNCB, CCH = 8 * NCB;
     p.CC = CCH; p.logCC = gm.logNCB + 3; p.SEG = gm.SEG; p.NSEG = gm.NSEG; p.XROW = gm.XROW; p.WR = 0; p.U0 = U;
@@ -656,15 +725,6 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     p.m_tiles = ceil_div(p.M_g, BM);
     p.tile_m = BM; p.tile_n = BN;
     const long base = nb * p.m_tiles * d->groups * phases;
-    // split-K: a chunk of the bf16 kernel is short (16x the fp32 MFMA rate), so the fixed per-block cost weighs more
-    double cost1 = 0;
-    int splits = choose_splits(base, nchunks, 0.5, &cost1);
-    if (const char* es = getenv("STEGAN_BF16_SPLITS")) { splits = atoi(es); splits = splits < 1 ? 1 : (splits > nchunks ? nchunks : splits); }
-    const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
-    if (splits > 1 && (!workspace || workspace_floats < out_elems * splits)) {
-        splits = workspace ? (int)(workspace_floats / out_elems) : 1;
-        if (splits < 2) splits = 1;
-    }
     p.splits = splits;
     p.chunks_per_split = ceil_div(nchunks, splits);
     p.splits = ceil_div(nchunks, p.chunks_per_split);

@@ -176,6 +176,14 @@ int stegan_conv1d_fwd_h(const stegan_conv_desc* d, const float* x, const uint16_
 int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* dy, const uint16_t* wbh, const float* scale,
                              const float* mask_src, const float* add_src, float* dx, float* workspace,
                              int64_t workspace_floats, void* stream);
+/* bf16 forms of stegan_conv1d_fwd_multi / stegan_conv1d_bwd_data_multi (same contract: up to 5 problems, return 1 when they
+ * cannot share one kernel variant or one of them is left to the fp32 kernels). */
+int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                              const uint16_t* const* wfh, const float* const* scale, const float* const* bias,
+                              const float* const* residual, float* const* y, void* stream);
+int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                   const uint16_t* const* wbh, const float* const* mask_src, const float* const* add_src,
+                                   float* const* dx, void* stream);
 
 /*
  * bf16-operand variant of stegan_conv1d_bwd_weight_ws (same accumulate-into-dw contract, fp32 accumulation, fp32 bias

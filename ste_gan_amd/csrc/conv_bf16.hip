@@ -117,7 +117,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     int bx, by, phase, split;
     const int nsplits = p.splits, cps = p.chunks_per_split;
     {
-        const unsigned total = gridDim.x, L = bid_x;
+        const unsigned total = bid_y /* blocks of this problem */, L = bid_x;
         const unsigned q8 = total >> 3, r8 = total & 7, xcd = L & 7;
         const unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
         const unsigned rest = fd_div(t, p.fdNY);
@@ -490,7 +490,26 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 
 template <int TM, int TN, int LOGNCB, bool XV>
 __global__ __launch_bounds__(512) void conv_bf16_kernel(const HP h) {
-    conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, gridDim.x, 0);
+}
+
+// Multi-problem launch: up to HMULTI independent convolutions that share a kernel variant (the same layer of the five
+// period discriminators: one channel structure; own weights, batch and length) in ONE grid, as in conv_direct.hip.
+constexpr int HMULTI = 5;
+struct MultiH {
+    int n;
+    int first[HMULTI + 1];          // first linear block of each problem
+    HP p[HMULTI];
+};
+static_assert(sizeof(MultiH) <= 4096, "kernel argument segment limit");
+
+template <int TM, int TN, int LOGNCB, bool XV>
+__global__ __launch_bounds__(512) void conv_bf16_multi_kernel(const MultiH a) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < HMULTI; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.first[i]) pi = i;
+    conv_bf16_body<TM, TN, LOGNCB, XV>(a.p[pi], blockIdx.x - a.first[pi], a.first[pi + 1] - a.first[pi], 0);
 }
 
 // ---- bf16 weight copies: v (Cout, Cin_g, K) fp32 -> wf[g][k][ci/8][co][ci%8], wb[g][k][co/8][ci][co%8] (x scale[co]);
@@ -618,8 +637,27 @@ void set_lds_attr() {
     (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 3, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+struct MultiCollectH {              // host side of a multi-problem launch being assembled
+    MultiH mh;
+    int TM, TN, logNCB;             // variant of the first problem, forced on the others (0 / -1: not chosen yet)
+    bool xv;                        // 16-byte X loads only when every problem's rows are float4 aligned
+    size_t lds;
+    long blocks;
+};
+
+template <int TM, int TN, bool XV>
+void launch_variant_multi(int logNCB, dim3 grid, size_t lds, hipStream_t s, const MultiH& a) {
+    switch (logNCB) {
+        case 0: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 0, XV>), grid, dim3(512), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 1, XV>), grid, dim3(512), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 2, XV>), grid, dim3(512), lds, s, a); break;
+        default: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 3, XV>), grid, dim3(512), lds, s, a); break;
+    }
+}
+
 // returns 1 when this kernel does not take the shape (caller uses the fp32 kernels)
-int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, int64_t workspace_floats, hipStream_t s) {
+int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, int64_t workspace_floats, hipStream_t s,
+                MultiCollectH* mc = nullptr) {
     DirP& p = h.d;
     int k_lo, k_hi;
     const int K_eff = live_taps(d, k_lo, k_hi);
@@ -662,7 +700,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     const long N = (long)d->B * U;
     // 16-byte X loads need float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
     const bool xv = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
-                    !getenv("STEGAN_BF16_NO_XV");
+                    !getenv("STEGAN_BF16_NO_XV") && (!mc || mc->xv);
     // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the
     // graph-timed microbenchmark (scripts/bf16_stamps.py, scripts/bf16_microbench.py) on the hot-path layers:
     //   block time   = 5 (index setup + epilogue) + chunks x (0.35 + staged bytes per chunk / 68 KB per us): an iteration is
@@ -674,9 +712,10 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     const char* env_tile = getenv("STEGAN_BF16_TILE");                 // "MN", e.g. "22", "11" (experiments)
     const char* env_cch = getenv("STEGAN_BF16_CCH_MAX");
     const char* env_spl = getenv("STEGAN_BF16_SPLITS");
-    const int cch_max = env_cch ? atoi(env_cch) : 64;
+    int cch_max = env_cch ? atoi(env_cch) : 64;
+    if (mc && mc->mh.n > 0) cch_max = 8 << mc->logNCB;            // later problems of a multi launch: the first one's variant
     const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
-    const int max_splits = workspace ? (int)(workspace_floats / out_elems < 16 ? workspace_floats / out_elems : 16) : 1;
+    const int max_splits = (workspace && !mc) ? (int)(workspace_floats / out_elems < 16 ? workspace_floats / out_elems : 16) : 1;
     int TM = 0, TN = 0, splits = 1;
     GeoH gm;
     gm.ok = false;
@@ -684,9 +723,12 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     for (int cand = 0; cand < 4; ++cand) {
         const int tm = cand < 2 ? 2 : 1, tn = (cand & 1) ? 1 : 2;      // (2,2) (2,1) (1,2) (1,1)
         if (env_tile && env_tile[0] && env_tile[1] && (tm != env_tile[0] - '0' || tn != env_tile[1] - '0')) continue;
+        if (mc && mc->mh.n > 0 && (tm != mc->TM || tn != mc->TN)) continue;
+        if (mc && tm == 2 && tn == 2) continue;                      // (keeps the (2,2) variants out of the multi kernels)
         if (tm == 2 && p.M_g <= 64) continue;
         const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max);
         if (!g2.ok) continue;
+        if (mc && mc->mh.n > 0 && g2.logNCB != mc->logNCB) continue;
         const int cch = 8 << g2.logNCB, nch = ceil_div(p.C2_g, cch);
         const long blocks1 = ceil_div(p.M_g, 64 * tm) * (long)d->groups * phases * ((N + 64 * tn - 1) / (64 * tn));
         const double bytes = (double)g2.ntW * 64 * tm * cch * 2 + (double)g2.XROW * cch * 4;
@@ -747,6 +789,16 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
                          gm.lds, gm.ntW, gm.XROW, gm.xit, gm.wit);
         if (dbg) fprintf(stderr, "          xv=%d\n", (int)xv);
     }
+    if (mc) {
+        MultiH& mh = mc->mh;
+        if (mh.n >= HMULTI) return 1;
+        if (mh.n == 0) { mc->TM = TM; mc->TN = TN; mc->logNCB = gm.logNCB; mc->lds = gm.lds; mc->blocks = 0; mh.first[0] = 0; }
+        if (gm.lds > mc->lds) mc->lds = gm.lds;
+        mh.p[mh.n] = h;
+        mc->blocks += nb * p.m_tiles * d->groups * phases;
+        mh.first[++mh.n] = (int)mc->blocks;
+        return STEGAN_OK;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         set_lds_attr<1, 1, false>(); set_lds_attr<1, 2, false>(); set_lds_attr<2, 1, false>(); set_lds_attr<2, 2, false>();
@@ -765,6 +817,29 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         if (eb > 4096) eb = 4096;
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)eb), dim3(256), 0, s, p);
     }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+template <int TM, int TN>
+void multi_go(MultiCollectH& mc, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+#define HB_ATTR(L_, V_) (void)hipFuncSetAttribute((const void*)conv_bf16_multi_kernel<TM, TN, L_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HB_ATTR(0, true) HB_ATTR(1, true) HB_ATTR(2, true) HB_ATTR(3, true)
+        HB_ATTR(0, false) HB_ATTR(1, false) HB_ATTR(2, false) HB_ATTR(3, false)
+#undef HB_ATTR
+        attr = true;
+    }
+    dim3 grid((unsigned)mc.blocks);
+    if (mc.xv) launch_variant_multi<TM, TN, true>(mc.logNCB, grid, mc.lds, s, mc.mh);
+    else launch_variant_multi<TM, TN, false>(mc.logNCB, grid, mc.lds, s, mc.mh);
+}
+
+int launch_multi_h(MultiCollectH& mc, hipStream_t s) {
+    if (mc.TM == 2) multi_go<2, 1>(mc, s);
+    else if (mc.TN == 2) multi_go<1, 2>(mc, s);
+    else multi_go<1, 1>(mc, s);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
@@ -836,4 +911,68 @@ extern "C" int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* 
     p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
     h.wh = wbh; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
     return launch_bf16(d, 1, h, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+// Up to 5 independent convolutions in ONE launch (the same layer of the period discriminators), bf16 operands: see
+// stegan_conv1d_fwd_multi.  Returns 1 when the problems cannot share a kernel variant (the caller launches them one by one).
+extern "C" int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                         const uint16_t* const* wfh, const float* const* scale, const float* const* bias,
+                                         const float* const* residual, float* const* y, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= HMULTI && descs && x && wfh && y);
+    MultiCollectH mc;
+    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i] || descs[i]->Tin % 4 != 0 || descs[i]->upsample != 1 || ((uintptr_t)x[i] % 16) != 0) mc.xv = false;
+    for (int i = 0; i < n; ++i) {
+        const stegan_conv_desc* d = descs[i];
+        int rc = check_desc(d);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(x[i] && wfh[i] && y[i]);
+        STEGAN_CHECK_ARG(d->in_act == STEGAN_ACT_NONE || d->in_act == STEGAN_ACT_RELU);
+        STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
+        const float* res = residual ? residual[i] : nullptr;
+        STEGAN_CHECK_ARG(!(d->out_btc && res));
+        HP h;
+        DirP& p = h.d;
+        p.src = x[i]; p.wt = nullptr; p.scale = scale ? scale[i] : nullptr; p.bias = bias ? bias[i] : nullptr; p.res = res;
+        p.mask = nullptr; p.out = y[i];
+        p.Csrc = d->Cin; p.Cdst = d->Cout; p.Tsrc = d->Tin; p.Tq = d->Tin * d->upsample; p.Tdst = d->Tout;
+        p.Tmask = 0; p.ups = d->upsample == 2 ? 1 : 0;
+        p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = 0; p.zero_off = 0;
+        p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
+        h.wh = wfh[i]; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+        rc = launch_bf16(d, 0, h, nullptr, 0, (hipStream_t)stream, &mc);
+        if (rc) return rc;
+    }
+    return launch_multi_h(mc, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                              const uint16_t* const* wbh, const float* const* mask_src,
+                                              const float* const* add_src, float* const* dx, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= HMULTI && descs && dy && wbh && dx);
+    MultiCollectH mc;
+    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
+    for (int i = 0; i < n; ++i)
+        if (!descs[i] || descs[i]->Tout % 4 != 0 || ((uintptr_t)dy[i] % 16) != 0) mc.xv = false;
+    for (int i = 0; i < n; ++i) {
+        const stegan_conv_desc* d = descs[i];
+        int rc = check_desc(d);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(dy[i] && wbh[i] && dx[i]);
+        const float* mk = mask_src ? mask_src[i] : nullptr;
+        STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mk);
+        HP h;
+        DirP& p = h.d;
+        p.src = dy[i]; p.wt = nullptr; p.scale = nullptr; p.bias = nullptr; p.res = add_src ? add_src[i] : nullptr; p.out = dx[i];
+        p.mask = d->in_act == STEGAN_ACT_RELU ? mk : nullptr;
+        p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
+        p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
+        p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = 0; p.zero_off = 0;
+        p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
+        h.wh = wbh[i]; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+        rc = launch_bf16(d, 1, h, nullptr, 0, (hipStream_t)stream, &mc);
+        if (rc) return rc;
+    }
+    return launch_multi_h(mc, (hipStream_t)stream);
 }

@@ -381,6 +381,14 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
         ys.append(torch.empty((B, cfg.cout, tout), device=x.device, dtype=torch.float32))
         descs.append(_desc(cfg, B, tin, tout))
     dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    whs = [_bf16_of(w) for w in wfs]
+    if all(w is not None for w in whs):
+        rc = _lib.lib().stegan_conv1d_fwd_multi_h(n, dptr, _ptr_array(xs), _ptr_array(whs), _ptr_array(scales),
+                                                  _ptr_array(biases), None, _ptr_array(ys), _stream())
+        if rc != 1:
+            check(rc, "stegan_conv1d_fwd_multi_h")
+            return ys
+        return None                     # per-problem launches (each picks bf16 or fp32 on its own)
     rc = _lib.lib().stegan_conv1d_fwd_multi(n, dptr, _ptr_array(xs), _ptr_array(wfs), _ptr_array(scales), _ptr_array(biases),
                                             None, _ptr_array(ys), _stream())
     if rc == 1:
@@ -398,6 +406,14 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins):
         dxs.append(torch.empty((B, cfg.cin, tin), device=dy.device, dtype=torch.float32))
         descs.append(_desc(cfg, B, tin, tout))
     dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    whs = [_bf16_of(w) for w in wbs]
+    if all(w is not None for w in whs):
+        rc = _lib.lib().stegan_conv1d_bwd_data_multi_h(n, dptr, _ptr_array(dys), _ptr_array(whs), None, None, _ptr_array(dxs),
+                                                       _stream())
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_data_multi_h")
+            return dxs
+        return None
     rc = _lib.lib().stegan_conv1d_bwd_data_multi(n, dptr, _ptr_array(dys), _ptr_array(wbs), None, None, _ptr_array(dxs),
                                                  _stream())
     if rc == 1:
@@ -416,7 +432,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         xs = ts[:n]
         cfgs = [l[3] for l in layers]
         ys = None
-        if PROFILER is None and not bf16_enabled() and all(c.upsample == 1 and not c.out_btc for c in cfgs):
+        if PROFILER is None and all(c.upsample == 1 and not c.out_btc for c in cfgs):
             ys = conv1d_fwd_multi(xs, cfgs, [l[4][1] for l in layers], [l[4][0] for l in layers], [l[2] for l in layers])
         if ys is None:
             ys = [conv1d_fwd(x, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], l[2], None, l[3], l[4][1])
@@ -444,7 +460,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         if any(need):
             cfgs = [l[3] for l in layers]
             out = None
-            if PROFILER is None and not bf16_enabled() and all(need):
+            if PROFILER is None and all(need):
                 out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs])
             if out is None:
                 out = [conv1d_bwd_data(g, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], None, None, l[3],

@@ -1,0 +1,86 @@
+"""-m gpu: the train step in the bf16-operand compute mode (BASELINE config 3: `ops.set_compute_dtype("bf16")`, reached from
+`cfg.train.mixed_precision` -- convolution operands rounded to bf16, fp32 accumulation / activations / weights / optimiser).
+
+Parity itself is pinned on the fp32 path (test_gpu_train_step.py, 1e-4); the kernels of this mode are pinned one by one
+against fp64 on bf16-rounded operands (test_gpu_conv_bf16.py, 2e-5).  Here the whole step is bounded against the same
+golden fixture with the tolerances bf16 rounding allows: every conv operand carries a relative error <= 2^-9, errors of
+independent roundings add in quadrature over reductions of 10^2..10^3 terms and grow over the ~40 layers of the generator."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from test_gpu_train_step import build, norms, to_batch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def bf16_mode():
+    from ste_gan_amd import ops
+    ops.set_compute_dtype("bf16")
+    yield ops
+    ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("name", list(cases.STEP_CASES))
+def test_train_step_bf16_vs_golden(name, golden, bf16_mode):
+    g = golden(name)
+    cfg, netG, netD, optG, optD, step = build(name)
+    steps = cases.STEP_CASES[name][4]
+    for s in range(steps):
+        out = step(to_batch(cases.step_batch(name, s)))
+        st = step.read_stats(out)
+        t = f"s{s}."
+        ref = g[t + "losses"]        # [loss_D, loss_G, adv, td, su, ph, fm]
+        got = np.array([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"],
+                        st["feature_matching"]])
+        np.testing.assert_allclose(got, ref[[0, 1, 3, 4, 5, 6]], rtol=3e-2, err_msg=t + "losses")
+        x_pred = out["x_pred"].cpu().numpy()
+        assert np.abs(x_pred - g[t + "x_pred"]).max() <= 3e-2, t + "x_pred"           # tanh output, |x| < 1
+        gG = norms([p.grad for p in netG.parameters()])
+        np.testing.assert_allclose(gG, g[t + "g_grad_norm"], rtol=8e-2, atol=2e-3 * g[t + "g_grad_norm"].max())
+        gD = norms([p.grad for p in netD.parameters()])
+        np.testing.assert_allclose(gD, g[t + "d_grad_norm"], rtol=8e-2, atol=2e-3 * g[t + "d_grad_norm"].max())
+        # one AdamW step moves every weight by ~lr whatever the gradient's scale: parameter norms stay within 1e-3
+        np.testing.assert_allclose(norms(netG.state_dict().values()), g[t + "g_param_norm"], rtol=1e-3)
+        np.testing.assert_allclose(norms(netD.state_dict().values()), g[t + "d_param_norm"], rtol=1e-3)
+    assert bf16_mode.LAST_CONV_KERNEL in ("bf16", "direct", "igemm")
+
+
+def test_bf16_kernels_take_the_hot_layers(bf16_mode):
+    """The mode is not a silent fp32 fallback: generator and discriminator convs run on the bf16 kernels."""
+    from ste_gan_amd.layers.conv import WNConv1d
+    ops = bf16_mode
+    conv = WNConv1d(96, 64, 3, padding=1).cuda()
+    x = torch.randn(4, 96, 48, device="cuda", requires_grad=True)
+    y = conv(x)
+    assert ops.LAST_CONV_KERNEL == "bf16"
+    y.square().sum().backward()
+    assert ops.LAST_CONV_KERNEL == "bf16"           # the weight gradient ran last
+    ops.set_compute_dtype("f32")
+    conv(x)
+    assert ops.LAST_CONV_KERNEL == "direct"
+
+
+def test_multi_problem_launch_matches_single_launches(bf16_mode):
+    """Layer L of the five period discriminators as ONE bf16 launch (stegan_conv1d_fwd_multi_h / _bwd_data_multi_h) against
+    five launches: same kernels, same arithmetic per problem -- only the tile choice may differ, so the results agree to
+    fp32 accumulation order."""
+    from ste_gan_amd.layers.conv import WNConv1d
+    ops = bf16_mode
+    torch.manual_seed(3)
+    periods = (2, 3, 5, 7, 11)
+    convs = [WNConv1d(32, 256, 3, stride=3, padding=2, out_act=2, kernel_dims=2).cuda() for _ in periods]
+    xs = [torch.randn(4 * p, 32, (192 + p - 192 % p) // p + 2, device="cuda", requires_grad=True) for p in periods]
+    ys = ops.wn_conv1d_multi(xs, convs)
+    gys = [torch.randn_like(y) for y in ys]
+    torch.autograd.backward(ys, gys)
+    dxs = [x.grad.clone() for x in xs]
+    for x in xs:
+        x.grad = None
+    for c, x, y, gy, dx in zip(convs, xs, ys, gys, dxs):
+        y1 = c(x)
+        y1.backward(gy)
+        torch.testing.assert_close(y1, y, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(x.grad, dx, rtol=1e-5, atol=1e-5 * float(dx.abs().max()))

@@ -7,7 +7,10 @@ One "step" = one full GAN train step (ste_gan/train.py:165-268: G fwd, 4 D fwd, 
 all losses incl. the frozen EMG encoder, 2 fused AdamW steps) on one synthetic batch per GPU:
 B=64, chunk_size=200 -> T_su=12 Soft-SU frames / T_emg=192 EMG samples, random-init
 full-size networks (G 768 ch, small D, 768-d 6-layer encoder), inputs resident in HBM before timing.
-Metric: EMG frames/s = n_gpus * B * 192 * steps / wall time (weak scaling).  dtype f32 (the parity path).
+Metric: EMG frames/s = n_gpus * B * 192 * steps / wall time (weak scaling).  dtype = arithmetic type of the convolution
+operands: bf16 (BASELINE config 3, the default: operands rounded to bf16 while they are staged, fp32 accumulation, fp32
+activations / master weights / optimiser state) or f32 (the parity path, --dtype f32; at N=1 its step time is also
+measured in the same run and reported as "fp32_parity_path").
 
 Extra objects on the JSON line (task contract): "roofline" for the dominant kernel (per-launch HIP-event
 timing of every conv launch in a separate instrumented pass; algorithmic FLOPs = nominal dense MACs x 2,
@@ -27,7 +30,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 B, T_SU, T_EMG = 64, 12, 192
-FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_PEAK_TFLOPS = {"f32": 157.3,   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+                    "bf16": 2500.0}  # ... v_mfma_f32_32x32x16_bf16, dense (~2.5 PF; never the 2:1-sparsity figure)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
+STEP_GFLOP = 1016.9                 # required nominal work of one step at B=64, T_emg=192 (508.4 GMAC)
+STEP_GBYTES = 6.58                  # ... layer-boundary traffic with fp32 activations (what this path stores)
 
 
 def make_cfg(workload):
@@ -140,8 +147,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the fp32 parity-path timing beside a bf16 run")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="arithmetic type of the convolution operands (accumulation, activations, weights and optimiser state "
                          "stay fp32): f32 = parity path, bf16 = BASELINE config 3")
     ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
@@ -228,13 +236,14 @@ def main():
         all_fl = 2.0 * sum(v["nominal_macs"] for v in agg.values())
         traffic = None      # HBM bytes per launch from the committed PMC passes (bench.py itself cannot run rocprofv3)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            key = "conv_direct_kernel" if name.startswith("conv_direct_kernel") else name
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+            key = name.split("<")[0]
             traffic = tj[key]["hbm_bytes_per_launch"]
         except Exception:
             pass
-        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_per_step": a["launches"] // args.profile_steps, "avg_launch_us": round(avg_ms * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 4),
                 "live_tap_frac": round(a["live_macs"] / a["nominal_macs"], 4),
@@ -242,6 +251,24 @@ def main():
                                      "ms_per_step": round(all_ms / args.profile_steps, 3),
                                      "per_kernel_ms_per_step": {k: round(v["ms"] / args.profile_steps, 3) for k, v in agg.items()}}}
 
+    # the same step on the fp32 parity path (exact fp32 MFMA), measured in the same process
+    f32_path = None
+    if world == 1 and args.dtype == "bf16" and not args.no_f32:
+        ops.set_compute_dtype("f32")
+        from ste_gan_amd.train import GraphedTrainStep
+        st32 = GraphedTrainStep(eager_step, batch, warmup=2) if graphed else eager_step
+        for _ in range(2):
+            st32(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n32 = max(5, args.steps // 2)
+        for _ in range(n32):
+            st32(batch)
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t1) / n32
+        f32_path = {"dtype": "f32", "ms_per_step": round(1e3 * d32, 3), "value": round(B * T_EMG / d32, 1), "unit": "EMG frames/s",
+                    "steps": n32, "note": "exact fp32 MFMA path, the one the parity tests pin to the reference within 1e-4"}
+        ops.set_compute_dtype(args.dtype)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -257,10 +284,20 @@ def main():
                 "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": "full GAN train step (G + small MPD/MSD D + multi-TD/SU/phoneme/FM losses + 2x AdamW), "
-                                       "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, fp32 parity path",
+                                       "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, " +
+                                       ("bf16 conv operands, fp32 accumulation / activations / weights (BASELINE config 3)"
+                                        if args.dtype == "bf16" else "fp32 parity path"),
                            "global_batch": world * B, "parallelism": f"dp{world}",
                            "launch": "hipGraph replay" if graphed else "eager"},
-                "roofline": roof, "cpu_baseline": cpu, "generator_inference": gi,
+                "roofline": roof,
+                # whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds)
+                "step_rooflines": {"algorithmic_gflop": STEP_GFLOP, "layer_boundary_gbytes": STEP_GBYTES,
+                                   "per_gpu_tflops": round(STEP_GFLOP / (1e3 * dt / args.steps), 2),
+                                   "mfma_frac": round(STEP_GFLOP / (1e3 * dt / args.steps) / MFMA_PEAK_TFLOPS[args.dtype], 4),
+                                   "per_gpu_gbytes_per_s": round(STEP_GBYTES / (dt / args.steps), 1),
+                                   "hbm_frac": round(STEP_GBYTES / (dt / args.steps) / HBM_PEAK_GBS, 4),
+                                   "binding": "neither: the step is bound by launch / per-block latency chains (DESIGN.md section 6)"},
+                "fp32_parity_path": f32_path, "cpu_baseline": cpu, "generator_inference": gi,
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -11,7 +11,9 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        fam = ("conv_direct_kernel" if "conv_direct_kernel" in n else "conv_wgrad_kernel" if "conv_wgrad_kernel" in n else
+        fam = ("conv_bf16_kernel" if ("conv_bf16_kernel" in n or "conv_bf16_multi_kernel" in n) else
+               "conv_wgrad_bf16_kernel" if "conv_wgrad_bf16_kernel" in n else
+               "conv_direct_kernel" if "conv_direct_kernel" in n else "conv_wgrad_kernel" if "conv_wgrad_kernel" in n else
                "conv_igemm_kernel<2>" if "conv_igemm_kernel<2" in n else "conv_splitk_epilogue_kernel" if "splitk_epilogue" in n
                else "assemble_batch_kernel" if "assemble_batch" in n else None)
         if fam is None:
@@ -23,7 +25,7 @@ def per_kernel(d, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, --kernel-trace only) around "
-                 "`python bench.py --steps 1 --warmup 1 --profile-steps 1 --no-cpu-baseline --no-graph`; FETCH_SIZE doubled per "
+                 "`python3 bench.py --steps 1 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-f32 --no-graph`; FETCH_SIZE doubled per "
                  "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads), counters are in KiB; "
                  "summarised by scripts/pmc_traffic.py"}
 for fam in fetch:

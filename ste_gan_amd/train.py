@@ -18,8 +18,12 @@
   stream, the D-gradient exchange overlapping the multi-TD and EMG-encoder losses, which do not depend on D
   (SURVEY.md section 5.8).
 
-On the CPU the reference's autocast/GradScaler disable themselves, i.e. its parity path is plain fp32
-(SURVEY.md 3.3 (v)); this trainer computes in fp32 throughout.
+Arithmetic.  ``cfg.train.mixed_precision`` selects, as in the reference (train.py:151,181,204: fp16 autocast +
+GradScaler on CUDA), the reduced-precision path: here the convolution operands are rounded to bf16 while they are
+staged (``ops.set_compute_dtype("bf16")``: fp32 accumulation, activations, master weights and optimiser state, no
+loss scaling needed -- bf16 keeps fp32's exponent range).  With the flag off the step runs on the exact fp32 MFMA
+kernels: that is the parity path -- on the CPU the reference's autocast / GradScaler disable themselves, so its
+own parity path is plain fp32 too.
 """
 from __future__ import annotations
 
@@ -293,6 +297,9 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
         raise RuntimeError("ste_gan_amd.train runs on MI355X (cuda device) only; there is no CPU fallback")
     rank, world = dist_info()
     is_main = rank == 0
+    from . import ops
+    ops.set_compute_dtype("bf16" if bool(cfg.train.get("mixed_precision", False)) else "f32")
+    logging.info(f"Convolution operand type: {ops.COMPUTE_DTYPE} (cfg.train.mixed_precision)")
     logging.info("Initializing Models")
     netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD = build_training_objects(cfg, device, emg_enc_ckpt)
     writer = _summary_writer(model_directory) if is_main else _NullWriter()

@@ -117,6 +117,123 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
     }
 }
 
+// ---- short sequences (T <= 32: the training chunks): q / k / v / dO of the (batch, head) and the live rows of the
+// relative-position table are staged in LDS once, coalesced, and every phase then runs out of LDS.  (The general kernels
+// above read them from global memory inside their inner loops -- ~100 dependent L1 round trips per thread: 36 us forward
+// and 57 us backward per call at T = 12 in the round-2 profile, for 2 MFLOP of work per block.)
+constexpr int ATT_TMAX = 32;
+
+// LDS floats: q, k, v, (dO) as [A][T] | emb rows rel = -(T-1)..(T-1) as [2T-1][A + 1] (odd pitch: the T x T threads of
+// the logits phase read one column of DIFFERENT rows at a time) | scores [T][T] (| dS [T][T])
+__device__ __forceinline__ void att_stage(float* dst, const float* src, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
+                                                             float* __restrict__ P, float* __restrict__ O, int H, int A,
+                                                             int T, int R, float inv_sqrt_d) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int Cm = H * A, AT = A * T;
+    const int EP = A + 1;
+    float* qs = sm; float* ks = qs + AT; float* vs = ks + AT; float* es = vs + AT; float* Ps = es + (2 * T - 1) * EP;
+    const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
+    att_stage(qs, qkv + base, AT);
+    att_stage(ks, qkv + base + (size_t)Cm * T, AT);
+    att_stage(vs, qkv + base + (size_t)2 * Cm * T, AT);
+    // table row for rel = r - (T - 1): zero when |rel| > R - 1 (masked below)
+    for (int i = threadIdx.x; i < (2 * T - 1) * A; i += 256) {
+        const int r = i / A, a = i - r * A, rel = r - (T - 1);
+        es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
+    }
+    __syncthreads();
+    for (int ij = threadIdx.x; ij < T * T; ij += 256) {
+        const int i = ij / T, j = ij - i * T, rel = j - i;
+        const float* er = es + (rel + T - 1) * EP;
+        float qk = 0.f, qe = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float qa = qs[a * T + i];
+            qk += qa * ks[a * T + j];
+            qe += qa * er[a];
+        }
+        Ps[ij] = (rel > R - 1 || rel < -(R - 1)) ? qk * inv_sqrt_d + (-1e8f) : qk * inv_sqrt_d + qe;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Pb = P + (size_t)blockIdx.x * T * T;
+    for (int i = wave; i < T; i += 4) {              // T <= 32 < 64: one element per lane
+        const float sv = lane < T ? Ps[i * T + lane] : -INFINITY;
+        float m = sv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float ex = lane < T ? expf(sv - m) : 0.f;
+        const float se = wave_sum(ex);
+        const float pr = ex * (1.f / se);
+        if (lane < T) { Ps[i * T + lane] = pr; Pb[i * T + lane] = pr; }
+    }
+    __syncthreads();
+    float* Ob = O + ((size_t)b * Cm + h * A) * T;
+    for (int ai = threadIdx.x; ai < AT; ai += 256) {
+        const int a = ai / T, i = ai - a * T;
+        float s = 0.f;
+        for (int j = 0; j < T; ++j) s += Ps[i * T + j] * vs[a * T + j];
+        Ob[ai] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
+                                                             const float* __restrict__ P, const float* __restrict__ dO,
+                                                             float* __restrict__ dqkv, int H, int A, int T, int R,
+                                                             float inv_sqrt_d) {
+    extern __shared__ float sm[];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int Cm = H * A, AT = A * T;
+    const int EP = A + 1;
+    float* qs = sm; float* ks = qs + AT; float* vs = ks + AT; float* ds = vs + AT; float* es = ds + AT;
+    float* Ps = es + (2 * T - 1) * EP; float* Ss = Ps + T * T;
+    const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
+    att_stage(qs, qkv + base, AT);
+    att_stage(ks, qkv + base + (size_t)Cm * T, AT);
+    att_stage(vs, qkv + base + (size_t)2 * Cm * T, AT);
+    att_stage(ds, dO + ((size_t)b * Cm + h * A) * T, AT);
+    att_stage(Ps, P + (size_t)blockIdx.x * T * T, T * T);
+    for (int i = threadIdx.x; i < (2 * T - 1) * A; i += 256) {
+        const int r = i / A, a = i - r * A, rel = r - (T - 1);
+        es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
+    }
+    __syncthreads();
+    // dP[i][j] = sum_a dO[a][i] v[a][j]
+    for (int ij = threadIdx.x; ij < T * T; ij += 256) {
+        const int i = ij / T, j = ij - i * T;
+        float s = 0.f;
+        for (int a = 0; a < A; ++a) s += ds[a * T + i] * vs[a * T + j];
+        Ss[ij] = s;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < T; i += 4) {
+        const float pv = lane < T ? Ps[i * T + lane] : 0.f, dp = lane < T ? Ss[i * T + lane] : 0.f;
+        const float r = wave_sum(dp * pv);
+        if (lane < T) Ss[i * T + lane] = pv * (dp - r);
+    }
+    __syncthreads();
+    float* dq = dqkv + base;
+    float* dk = dqkv + base + (size_t)Cm * T;
+    float* dv = dqkv + base + (size_t)2 * Cm * T;
+    for (int ai = threadIdx.x; ai < AT; ai += 256) {
+        const int a = ai / T, i = ai - a * T;
+        float sv = 0.f, sk = 0.f, sq = 0.f;
+        for (int r = 0; r < T; ++r) {
+            sv += Ps[r * T + i] * ds[a * T + r];
+            sk += Ss[r * T + i] * qs[a * T + r];
+            sq += Ss[i * T + r] * (ks[a * T + r] * inv_sqrt_d + es[(r - i + T - 1) * EP + a]);    // zero row when masked
+        }
+        dv[ai] = sv;
+        dk[ai] = sk * inv_sqrt_d;
+        dq[ai] = sq;
+    }
+}
+
 // y = LayerNorm_C(x + r) * gamma + beta on (B, C, T); one wave per (b, t) column; saves xhat and rstd
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -175,6 +292,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B,
                                            int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream) {
     STEGAN_CHECK_ARG(qkv && rel_emb && probs && out && B > 0 && H > 0 && A > 0 && T > 0 && max_rel > 0);
+    const size_t lds_s = ((size_t)3 * A * T + (size_t)(2 * T - 1) * (A + 1) + (size_t)T * T) * sizeof(float);
+    if (T <= ATT_TMAX && lds_s <= 64 * 1024) {
+        hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(B * H), dim3(256), lds_s, (hipStream_t)stream, qkv, rel_emb, probs, out, H,
+                           A, T, max_rel, 1.f / sqrtf((float)A));
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, out, H, A, T,
                        max_rel, 1.f / sqrtf((float)A));
     STEGAN_LAUNCH_CHECK();
@@ -185,6 +309,13 @@ extern "C" int stegan_relpos_attention_bwd(const float* qkv, const float* rel_em
                                            float* workspace, float* dqkv, int32_t B, int32_t H, int32_t A, int32_t T,
                                            int32_t max_rel, void* stream) {
     STEGAN_CHECK_ARG(qkv && rel_emb && probs && dout && workspace && dqkv && B > 0 && H > 0 && A > 0 && T > 0);
+    const size_t lds_s = ((size_t)4 * A * T + (size_t)(2 * T - 1) * (A + 1) + (size_t)2 * T * T) * sizeof(float);
+    if (T <= ATT_TMAX && lds_s <= 64 * 1024) {
+        hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * H), dim3(256), lds_s, (hipStream_t)stream, qkv, rel_emb, probs, dout,
+                           dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A));
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, dout,
                        workspace, dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A));
     STEGAN_LAUNCH_CHECK();

@@ -41,6 +41,7 @@ import torch
 import torch.distributed as dist
 
 from . import constants as K
+from . import ops
 from .constants import DataType
 from .losses.emg_encoder_loss import EMGEncoderLoss, EMGEncoderLossOutput
 from .losses.gan_losses import feature_matching_loss, lsgan_loss
@@ -285,6 +286,18 @@ def init_distributed_from_env() -> Optional[torch.device]:
 
 def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug: bool, emg_enc_ckpt: Path = None,
           loaders=None):
+    """``cfg.train.mixed_precision`` selects the compute mode for the duration of the run (see the module docstring);
+    the mode in force before the call is restored afterwards.  Everything else: :func:`_train`."""
+    previous = ops.COMPUTE_DTYPE
+    ops.set_compute_dtype("bf16" if bool(cfg.train.get("mixed_precision", False)) else "f32")
+    try:
+        return _train(cfg, model_directory, checkpoint, torch_device, debug, emg_enc_ckpt, loaders)
+    finally:
+        ops.set_compute_dtype(previous)
+
+
+def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug: bool, emg_enc_ckpt: Path = None,
+           loaders=None):
     """Full training run -- ste_gan/train.py:39-499.  ``loaders`` = (train, valid, test) DataLoaders whose batches
     are dicts keyed by ``DataType`` (data/collate.py:54-61); when omitted they come from ``loaders_via_config``.
 
@@ -297,8 +310,6 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
         raise RuntimeError("ste_gan_amd.train runs on MI355X (cuda device) only; there is no CPU fallback")
     rank, world = dist_info()
     is_main = rank == 0
-    from . import ops
-    ops.set_compute_dtype("bf16" if bool(cfg.train.get("mixed_precision", False)) else "f32")
     logging.info(f"Convolution operand type: {ops.COMPUTE_DTYPE} (cfg.train.mixed_precision)")
     logging.info("Initializing Models")
     netG, netD, emg_encoder, multi_td_loss, emg_encoder_loss, optG, optD = build_training_objects(cfg, device, emg_enc_ckpt)

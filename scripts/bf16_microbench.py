@@ -31,7 +31,7 @@ LAYERS = [
     ("E enc 768->768 k1 T12", 768, 768, 1, 1, 1, 0, 1, 1, False, 12, B),
     ("E enc 768->768 k3 s2 T96", 768, 768, 3, 2, 1, 1, 1, 1, False, 96, B),
 ]
-ENV = {"tile": "STEGAN_BF16_TILE", "cch": "STEGAN_BF16_CCH_MAX", "splits": "STEGAN_BF16_SPLITS", "noxv": "STEGAN_BF16_NO_XV", "dbg": "STEGAN_BF16_DBG"}
+ENV = {"wr": "STEGAN_BF16_WGRAD_R", "wsl": "STEGAN_BF16_WGRAD_SLICES", "tile": "STEGAN_BF16_TILE", "cch": "STEGAN_BF16_CCH_MAX", "splits": "STEGAN_BF16_SPLITS", "noxv": "STEGAN_BF16_NO_XV", "dbg": "STEGAN_BF16_DBG"}
 
 
 def timeit(fn, n=20):
@@ -61,7 +61,8 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("--variants="):
             variants = a.split("=", 1)[1].split(";")
-    print(f"{'layer':32s} {'GFLOP':>7s} | {'variant':18s} | {'f32 fwd':>8s} {'bf16 fwd':>8s} {'TF':>6s} | {'f32 bwd':>8s} {'bf16 bwd':>8s} {'TF':>6s}")
+    print(f"{'layer':32s} {'GFLOP':>7s} | {'variant':18s} | {'f32 fwd':>8s} {'bf16 fwd':>8s} {'TF':>6s} | {'f32 bwd':>8s} {'bf16 bwd':>8s} {'TF':>6s}"
+          f" | {'f32 wgr':>8s} {'bf16 wgr':>8s} {'TF':>6s}")
     for (name, Cin, Cout, K, s, d, p, g, up, relu, Tin, Be) in LAYERS:
         if only and only not in name: continue
         c = ops.ConvCfg(Cin, Cout, K, s, d, p, g, up, 1 if relu else 0)
@@ -74,6 +75,8 @@ def main():
         wf, wb = ops.prep_weights(w, c, None, sc)
         t_f = timeit(lambda: ops.conv1d_fwd(x, w, sc, bias, None, c, wf))
         t_b = timeit(lambda: ops.conv1d_bwd_data(dy, w, sc, x if relu else None, None, c, Tin, wb))
+        dw = torch.zeros_like(w); db = torch.zeros(Cout, device="cuda")
+        t_w = timeit(lambda: ops.conv1d_bwd_weight(x, dy, c, dw, db))
         ops.set_compute_dtype("bf16")
         wf, wb = ops.prep_weights(w, c, None, sc)
         for v in variants:
@@ -85,8 +88,11 @@ def main():
             kf = ops.LAST_CONV_KERNEL
             t_bh = timeit(lambda: ops.conv1d_bwd_data(dy, w, sc, x if relu else None, None, c, Tin, wb))
             kb = ops.LAST_CONV_KERNEL
+            t_wh = timeit(lambda: ops.conv1d_bwd_weight(x, dy, c, dw, db))
+            kw = ops.LAST_CONV_KERNEL
             print(f"{name:32s} {gf:7.2f} | {v:18s} | {t_f:8.1f} {t_fh:8.1f} {gf/t_fh*1e3:6.0f}{'' if kf == 'bf16' else '*'} | "
-                  f"{t_b:8.1f} {t_bh:8.1f} {gf/t_bh*1e3:6.0f}{'' if kb == 'bf16' else '*'}", flush=True)
+                  f"{t_b:8.1f} {t_bh:8.1f} {gf/t_bh*1e3:6.0f}{'' if kb == 'bf16' else '*'} | "
+                  f"{t_w:8.1f} {t_wh:8.1f} {gf/t_wh*1e3:6.0f}{'' if kw == 'bf16' else '*'}", flush=True)
         ops.set_compute_dtype("f32")
 
 

@@ -77,6 +77,14 @@ class GANTrainStep:
         self.d_params = [p for p in netD.parameters()]
         self.comm = FlatGradAllReduce(process_group) if dist.is_available() and dist.is_initialized() else None
         self.last: Dict[str, torch.Tensor] = {}
+        import os
+        self.overlap_encoder = os.environ.get("STEGAN_OVERLAP_ENCODER", "1") != "0"
+        self._side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def _set_d_grad(self, flag: bool):
         for p in self.d_params:
@@ -111,27 +119,41 @@ class GANTrainStep:
                 self.optD.flat.gather_grads()      # any gradient autograd did not write through its arena view
                 d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
 
-        # ---- D-independent generator losses first: they overlap the D-gradient all-reduce
+        # ---- D-independent generator losses (multi-TD, frozen EMG encoder): they overlap the D-gradient all-reduce, and --
+        # on a side HIP stream forked here and joined before the losses are summed -- the optimiser step of D and the two
+        # generator-side discriminator passes below.  The encoder branch (T_su = 12 frames: short, latency-bound launches
+        # that fill a fraction of the chip) and the discriminator branch share no data until loss_G; autograd runs each
+        # op's backward on the stream of its forward, so the two branches overlap in loss_G.backward() as well.
         loss_G = 0
-        if t.loss_multi_td_error:
-            td_error = self.multi_td_loss(x_t, x_pred_t)
-            loss_G = loss_G + t.loss_multi_td_weight * td_error
-            out["multi_td"] = td_error.detach()
-        enc_out: Optional[EMGEncoderLossOutput] = None
-        if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
-            enc_out = self.emg_encoder_loss(x_pred_t, speech_units_t, phoneme_targets)
-            if t.loss_speech_unit_error:
-                loss_G = loss_G + t.loss_speech_unit_weight * enc_out.speech_unit_loss
-                out["speech_unit"] = enc_out.speech_unit_loss.detach()
-            if t.loss_phoneme_error:
-                loss_G = loss_G + t.loss_phoneme_weight * enc_out.phoneme_loss
-                out["phoneme"] = enc_out.phoneme_loss.detach()
-            out["phoneme_counters"] = enc_out._counters
-        if t.loss_waveform_error:
-            from . import ops
-            wave_loss = ops.mse_loss(x_pred_t, x_t)
-            loss_G = loss_G + t.loss_waveform_weight * wave_loss
-            out["waveform"] = wave_loss.detach()
+        main_stream = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_encoder else None
+        if side is not None:
+            side.wait_stream(main_stream)                      # x_pred, the batch
+            torch.cuda.set_stream(side)
+        try:
+            loss_side = 0
+            if t.loss_multi_td_error:
+                td_error = self.multi_td_loss(x_t, x_pred_t)
+                loss_side = loss_side + t.loss_multi_td_weight * td_error
+                out["multi_td"] = td_error.detach()
+            enc_out: Optional[EMGEncoderLossOutput] = None
+            if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
+                enc_out = self.emg_encoder_loss(x_pred_t, speech_units_t, phoneme_targets)
+                if t.loss_speech_unit_error:
+                    loss_side = loss_side + t.loss_speech_unit_weight * enc_out.speech_unit_loss
+                    out["speech_unit"] = enc_out.speech_unit_loss.detach()
+                if t.loss_phoneme_error:
+                    loss_side = loss_side + t.loss_phoneme_weight * enc_out.phoneme_loss
+                    out["phoneme"] = enc_out.phoneme_loss.detach()
+                out["phoneme_counters"] = enc_out._counters
+            if t.loss_waveform_error:
+                from . import ops
+                wave_loss = ops.mse_loss(x_pred_t, x_t)
+                loss_side = loss_side + t.loss_waveform_weight * wave_loss
+                out["waveform"] = wave_loss.detach()
+        finally:
+            if side is not None:
+                torch.cuda.set_stream(main_stream)
 
         if t.loss_adversarial:
             if d_handle is not None:
@@ -146,6 +168,9 @@ class GANTrainStep:
             D_fake = netD(x_pred_t)
             with torch.no_grad():
                 D_real = netD(x_t)
+            if side is not None:
+                main_stream.wait_stream(side)                  # join: the side branch's loss terms are complete
+            loss_G = loss_G + loss_side
             if t.loss_adversarial:
                 loss_G = loss_G + lsgan_loss(D_fake, 1.0, unit_grad=True)
             if t.loss_feat_match_error:

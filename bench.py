@@ -224,7 +224,7 @@ def main():
         if os.environ.get("STEGAN_BENCH_DETAIL"):
             by = ops.profiler_by_shape(ops.PROFILER)
             print("mode B Cin Cout K s d g up Tin Tout | launches/step ms/step TFLOP/s", file=sys.stderr)
-            for shape, (n, ms, macs) in sorted(by.items(), key=lambda kv: -kv[1][1])[:40]:
+            for shape, (n, ms, macs) in sorted(by.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("STEGAN_BENCH_DETAIL_N", "40"))]:
                 print(shape, "|", n // args.profile_steps, round(ms / args.profile_steps, 3),
                       round(2 * macs / (ms * 1e-3) / 1e12, 1), file=sys.stderr)
         ops.PROFILER = None

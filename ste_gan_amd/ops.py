@@ -127,7 +127,7 @@ def profiler_by_shape(prof: "ConvProfiler"):
     torch.cuda.synchronize()
     agg = {}
     for name, nominal, live, e0, e1, shape in prof.records:
-        a = agg.setdefault(shape, [0, 0.0, 0])
+        a = agg.setdefault(shape + (name.split("<")[0].split(" ")[0],), [0, 0.0, 0])
         a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += nominal
     return agg
 

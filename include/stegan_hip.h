@@ -242,6 +242,13 @@ int stegan_wn_backward1(const float* v, const float* g, const float* dw, float* 
 int64_t stegan_spectral_norm_workspace_floats(int32_t rows, int32_t cols);
 int stegan_spectral_norm_fwd(const float* w_orig, float* u, float* v, float* scale, float* sigma,
                              float* workspace, int32_t rows, int32_t cols, int32_t power_iterate, void* stream);
+/* The same for n <= 8 independent layers (all spectral-norm convs of one scale discriminator, discriminator.py:100-113)
+ * in one launch per stage: per-layer arrays of the single-layer arguments; u_save / v_save (arrays, or NULL, or NULL
+ * entries) receive copies of the updated u / v for the backward pass (torch clones them for the same reason). */
+int stegan_spectral_norm_fwd_multi(int32_t n, const float* const* w_orig, float* const* u, float* const* v,
+                                   float* const* scale, float* const* sigma, float* const* u_save,
+                                   float* const* v_save, float* const* workspace, const int32_t* rows,
+                                   const int32_t* cols, int32_t power_iterate, void* stream);
 /* dw_orig = dw/sigma - (<dw,W>/sigma^2) u v^T, dw = raw-direction gradient of stegan_conv1d_bwd_weight
  * (autograd of weight_orig / sigma with u, v held constant).  workspace: >= rows floats. */
 int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,

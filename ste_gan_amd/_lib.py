@@ -59,6 +59,7 @@ SIGNATURES = {
     "stegan_wn_scale1": [_P, _P, _P, _I32, _I32, _P],
     "stegan_wn_backward1": [_P, _P, _P, _P, _P, _I32, _I32, _P],
     "stegan_spectral_norm_fwd": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stegan_spectral_norm_fwd_multi": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_spectral_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "stegan_mpd_fold_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stegan_mpd_fold_bwd": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],

@@ -97,20 +97,25 @@ __global__ __launch_bounds__(256) void avgpool421_bwd_kernel(const float* __rest
 // ---------------- spectral norm: one power iteration + sigma --------------------------------
 // stage 1: partial[rc][j] = sum_{i in row chunk rc} W[i][j] * u[i]       (deterministic two-stage column sums)
 constexpr int SN_ROWS = 32;
-__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u,
-                                                     float* __restrict__ partial, int R, int Cn) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * SN_ROWS;
-    if (j >= Cn) return;
+__device__ __forceinline__ void sn_wtu_body(const float* __restrict__ W, const float* __restrict__ u,
+                                            float* __restrict__ partial, int R, int Cn, int bx, int by) {
+    const int j = bx * 256 + threadIdx.x;
+    const int r0 = by * SN_ROWS;
+    if (j >= Cn || r0 >= R) return;
     float s = 0.f;
     const int r1 = min(R, r0 + SN_ROWS);
     for (int i = r0; i < r1; ++i) s += W[(size_t)i * Cn + j] * u[i];
-    partial[(size_t)blockIdx.y * Cn + j] = s;
+    partial[(size_t)by * Cn + j] = s;
+}
+
+__global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                     float* __restrict__ partial, int R, int Cn) {
+    sn_wtu_body(W, u, partial, R, Cn, blockIdx.x, blockIdx.y);
 }
 
 // stage 2 (single block): t = sum partial; v = t / max(||t||, eps)
-__global__ __launch_bounds__(1024) void sn_vnorm_kernel(const float* __restrict__ partial, float* __restrict__ v,
-                                                        int nchunks, int Cn, float eps) {
+__device__ __forceinline__ void sn_vnorm_body(const float* __restrict__ partial, float* __restrict__ v,
+                                              float* __restrict__ v_save, int nchunks, int Cn, float eps) {
     __shared__ float red[16];
     __shared__ float inv;
     float ss = 0.f;
@@ -129,13 +134,22 @@ __global__ __launch_bounds__(1024) void sn_vnorm_kernel(const float* __restrict_
         inv = 1.f / fmaxf(sqrtf(a), eps);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < Cn; j += 1024) v[j] *= inv;
+    for (int j = threadIdx.x; j < Cn; j += 1024) {
+        const float t = v[j] * inv;
+        v[j] = t;
+        if (v_save) v_save[j] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void sn_vnorm_kernel(const float* __restrict__ partial, float* __restrict__ v,
+                                                        int nchunks, int Cn, float eps) {
+    sn_vnorm_body(partial, v, nullptr, nchunks, Cn, eps);
 }
 
 // stage 3: s[i] = <W[i,:], v>   (one wave per row)
-__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ v,
-                                                    float* __restrict__ s, int R, int Cn) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void sn_wv_body(const float* __restrict__ W, const float* __restrict__ v,
+                                           float* __restrict__ s, int R, int Cn, int bx) {
+    const int row = bx * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const float* wr = W + (size_t)row * Cn;
@@ -145,10 +159,15 @@ __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W,
     if (lane == 0) s[row] = a;
 }
 
+__global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ v,
+                                                    float* __restrict__ s, int R, int Cn) {
+    sn_wv_body(W, v, s, R, Cn, blockIdx.x);
+}
+
 // stage 4 (single block): u = s / max(||s||,eps) (if update_u); sigma = <u, s>; scale[:] = 1/sigma; sigma_out
-__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* __restrict__ s, float* __restrict__ u,
-                                                         float* __restrict__ scale, float* __restrict__ sigma_out,
-                                                         int R, float eps, int update_u) {
+__device__ __forceinline__ void sn_finish_body(const float* __restrict__ s, float* __restrict__ u,
+                                               float* __restrict__ u_save, float* __restrict__ scale,
+                                               float* __restrict__ sigma_out, int R, float eps, int update_u) {
     __shared__ float red[16];
     __shared__ float bc;
     float ss = 0.f;
@@ -166,6 +185,7 @@ __global__ __launch_bounds__(1024) void sn_finish_kernel(const float* __restrict
     for (int i = threadIdx.x; i < R; i += 1024) {
         float ui = update_u ? s[i] * bc : u[i];
         if (update_u) u[i] = ui;
+        if (u_save) u_save[i] = ui;
         dot += ui * s[i];
     }
     dot = wave_sum(dot);
@@ -181,6 +201,42 @@ __global__ __launch_bounds__(1024) void sn_finish_kernel(const float* __restrict
     __syncthreads();
     const float inv_sigma = 1.f / bc;
     for (int i = threadIdx.x; i < R; i += 1024) scale[i] = inv_sigma;
+}
+
+__global__ __launch_bounds__(1024) void sn_finish_kernel(const float* __restrict__ s, float* __restrict__ u,
+                                                         float* __restrict__ scale, float* __restrict__ sigma_out,
+                                                         int R, float eps, int update_u) {
+    sn_finish_body(s, u, nullptr, scale, sigma_out, R, eps, update_u);
+}
+
+// All spectral-norm layers of one discriminator in ONE launch per stage (the layers are independent: 4 launches per
+// forward instead of 4 per layer); same per-layer arithmetic as the single-layer kernels above.
+constexpr int SN_MULTI = 8;
+struct SNMulti {
+    int n, update_u;
+    float eps;
+    struct E {
+        const float* W;
+        float *u, *v, *scale, *sigma, *partial, *svec, *u_save, *v_save;
+        int R, Cn, nch;
+    } e[SN_MULTI];
+};
+
+__global__ __launch_bounds__(256) void sn_wtu_multi_kernel(const SNMulti a) {
+    const SNMulti::E& e = a.e[blockIdx.z];
+    sn_wtu_body(e.W, e.u, e.partial, e.R, e.Cn, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(1024) void sn_vnorm_multi_kernel(const SNMulti a) {
+    const SNMulti::E& e = a.e[blockIdx.x];
+    sn_vnorm_body(e.partial, e.v, e.v_save, e.nch, e.Cn, a.eps);
+}
+__global__ __launch_bounds__(256) void sn_wv_multi_kernel(const SNMulti a) {
+    const SNMulti::E& e = a.e[blockIdx.y];
+    sn_wv_body(e.W, e.v, e.svec, e.R, e.Cn, blockIdx.x);
+}
+__global__ __launch_bounds__(1024) void sn_finish_multi_kernel(const SNMulti a) {
+    const SNMulti::E& e = a.e[blockIdx.x];
+    sn_finish_body(e.svec, e.u, e.u_save, e.scale, e.sigma, e.R, a.eps, a.update_u);
 }
 
 // dW_orig = dw/sigma - (<dw, W>/sigma^2) u v^T      two kernels: row dots -> total, then elementwise
@@ -298,6 +354,34 @@ extern "C" int stegan_spectral_norm_fwd(const float* w_orig, float* u, float* v,
     }
     hipLaunchKernelGGL(sn_wv_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w_orig, v, svec, rows, cols);
     hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(1024), 0, s, svec, u, scale, sigma, rows, eps, power_iterate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_spectral_norm_fwd_multi(int32_t n, const float* const* w_orig, float* const* u, float* const* v,
+                                              float* const* scale, float* const* sigma, float* const* u_save,
+                                              float* const* v_save, float* const* workspace, const int32_t* rows,
+                                              const int32_t* cols, int32_t power_iterate, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= SN_MULTI && w_orig && u && v && scale && sigma && workspace && rows && cols);
+    SNMulti a;
+    a.n = n; a.update_u = power_iterate; a.eps = 1e-12f;
+    int max_cb = 0, max_nch = 0, max_rb = 0;
+    for (int i = 0; i < n; ++i) {
+        STEGAN_CHECK_ARG(w_orig[i] && u[i] && v[i] && scale[i] && sigma[i] && workspace[i] && rows[i] > 0 && cols[i] > 0);
+        SNMulti::E& e = a.e[i];
+        e.W = w_orig[i]; e.u = u[i]; e.v = v[i]; e.scale = scale[i]; e.sigma = sigma[i];
+        e.R = rows[i]; e.Cn = cols[i]; e.nch = ceil_div(rows[i], SN_ROWS);
+        e.partial = workspace[i]; e.svec = workspace[i] + (size_t)e.nch * e.Cn;
+        e.u_save = u_save ? u_save[i] : nullptr; e.v_save = v_save ? v_save[i] : nullptr;
+        max_cb = max(max_cb, ceil_div(e.Cn, 256)); max_nch = max(max_nch, e.nch); max_rb = max(max_rb, ceil_div(e.R, 4));
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (power_iterate) {
+        hipLaunchKernelGGL(sn_wtu_multi_kernel, dim3(max_cb, max_nch, n), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(sn_vnorm_multi_kernel, dim3(n), dim3(1024), 0, s, a);
+    }
+    hipLaunchKernelGGL(sn_wv_multi_kernel, dim3(max_rb, n), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sn_finish_multi_kernel, dim3(n), dim3(1024), 0, s, a);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

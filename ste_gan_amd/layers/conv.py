@@ -153,9 +153,11 @@ class SNConv1d(nn.Module):
                                                   self._prep[1][0].device == w.device else None))
         return self._prep[1]
 
-    def forward(self, x):
+    def forward(self, x, pre=None):
+        """``pre``: this forward's spectral-norm state from :func:`ops.spectral_norm_multi` (all layers of the
+        discriminator in one call); None: the layer runs its own power iteration."""
         return ops.sn_conv1d(x, self.weight_orig, self.weight_u, self.weight_v, self.bias, self.cfg, self.training,
-                             self.prepared())
+                             self.prepared(), pre)
 
 
 def NormedConv1d(*args, **kwargs):

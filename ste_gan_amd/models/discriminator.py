@@ -72,8 +72,14 @@ class _ScaleDisc(nn.Module):
     def forward(self, x_bct):
         fmaps = []
         x = x_bct
-        for layer in self.layers:
-            x = layer(x)
+        pre = [None] * len(self.layers)
+        if (getattr(self, "norm", "weight_norm") == "spectral_norm" and ops.SN_BATCHED and x.is_cuda
+                and len(self.layers) <= 8):
+            # the power iterations of all layers, ahead of the first conv, in 4 launches (they depend on the weights only)
+            keep = torch.is_grad_enabled() and any(l.weight_orig.requires_grad for l in self.layers)
+            pre = ops.spectral_norm_multi([(l.weight_orig, l.weight_u, l.weight_v) for l in self.layers], self.training, keep)
+        for layer, pr in zip(self.layers, pre):
+            x = layer(x) if pr is None else layer(x, pr)
             fmaps.append(x)
         fmaps.append(self.output(x))
         return fmaps

@@ -7,6 +7,7 @@ tensor is not on the GPU or the library is missing -- there is no eager / CPU fa
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, replace
 from typing import Optional
 
@@ -505,24 +506,33 @@ class _SNConvFn(torch.autograd.Function):
     """y = out_act( (w_orig (*) x) / sigma + bias ), sigma = u^T W v after one in-place power iteration."""
 
     @staticmethod
-    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None):
+    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None):
         wf, wb = prepared if prepared is not None else (None, None)
-        rows = w_orig.shape[0]
-        cols = w_orig.numel() // rows
-        L = _lib.lib()
-        ws = torch.empty(int(L.stegan_spectral_norm_workspace_floats(rows, cols)), device=x.device, dtype=torch.float32)
-        scale = torch.empty(rows, device=x.device, dtype=torch.float32)
-        sigma = torch.empty(1, device=x.device, dtype=torch.float32)
-        check(L.stegan_spectral_norm_fwd(_p(w_orig), _p(u), _p(v), _p(scale), _p(sigma), _p(ws), rows, cols,
-                                         int(training), _stream()), "stegan_spectral_norm_fwd")
+        need_w = ctx.needs_input_grad[1]
+        if pre is not None:
+            # (scale, sigma, u copy, v copy) of THIS forward, computed for all layers of the discriminator at once
+            # (spectral_norm_multi): the power iteration has already advanced u / v in place
+            scale, sigma, u_keep, v_keep = pre
+            if need_w and (u_keep is None or v_keep is None):
+                raise RuntimeError("ste_gan_amd.sn_conv1d: precomputed spectral-norm state lacks the u / v copies")
+        else:
+            rows = w_orig.shape[0]
+            cols = w_orig.numel() // rows
+            L = _lib.lib()
+            ws = torch.empty(int(L.stegan_spectral_norm_workspace_floats(rows, cols)), device=x.device, dtype=torch.float32)
+            scale = torch.empty(rows, device=x.device, dtype=torch.float32)
+            sigma = torch.empty(1, device=x.device, dtype=torch.float32)
+            check(L.stegan_spectral_norm_fwd(_p(w_orig), _p(u), _p(v), _p(scale), _p(sigma), _p(ws), rows, cols,
+                                             int(training), _stream()), "stegan_spectral_norm_fwd")
+            # u / v are cloned because the next forward power-iterates them in place (torch clones them too) -- but only
+            # the weight gradient reads them, so frozen-weight passes (generator step, no_grad) skip the two copies
+            u_keep = u.clone() if need_w else u
+            v_keep = v.clone() if need_w else v
         y = conv1d_fwd(x, w_orig, scale, bias, None, cfg, wf)
         ctx.cfg = cfg
         ctx.wb = wb
-        # u / v are cloned because the next forward power-iterates them in place (torch clones them too) -- but only the
-        # weight gradient reads them, so frozen-weight passes (generator step, no_grad) skip the two copies
-        need_w = ctx.needs_input_grad[1]
-        ctx.save_for_backward(x, w_orig, u.clone() if need_w else u, v.clone() if need_w else v, scale, sigma,
-                              y if cfg.out_act != ACT_NONE else None)
+        ctx.save_for_backward(x, w_orig, u_keep if u_keep is not None else u, v_keep if v_keep is not None else v, scale,
+                              sigma, y if cfg.out_act != ACT_NONE else None)
         return y
 
     @staticmethod
@@ -545,11 +555,47 @@ class _SNConvFn(torch.autograd.Function):
             check(_lib.lib().stegan_spectral_norm_bwd(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
                                                       rows, w_orig.numel() // rows, _stream()),
                   "stegan_spectral_norm_bwd")
-        return dx, dw_orig, None, None, db, None, None, None
+        return dx, dw_orig, None, None, db, None, None, None, None
 
 
-def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None) -> Tensor:
-    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared)
+def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None) -> Tensor:
+    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre)
+
+
+SN_BATCHED = os.environ.get("STEGAN_SN_BATCHED", "1") != "0"      # scale discriminator: all spectral-norm layers' power iterations in one call (0: per layer)
+
+
+def spectral_norm_multi(layers, training: bool, keep_uv: bool):
+    """One forward's spectral-norm state of up to 8 layers -- ``layers`` = [(weight_orig, u, v), ...] -- in four launches
+    (stegan_spectral_norm_fwd_multi) instead of four per layer: the layers' power iterations are independent of each other
+    and of the activations, so running them ahead of the first conv gives the reference's values (conv.py:92-94,
+    discriminator.py:100-113).  In training mode u / v advance in place, exactly once.  Returns, per layer, the ``pre``
+    argument of :func:`sn_conv1d`: (scale (rows,), sigma (1,), u copy, v copy); the copies are None unless ``keep_uv``
+    (they are what the weight gradient reads after later forwards have moved u / v on)."""
+    n = len(layers)
+    L = _lib.lib()
+    dev = layers[0][0].device
+    rows = [int(w.shape[0]) for w, _, _ in layers]
+    cols = [int(w.numel() // w.shape[0]) for w, _, _ in layers]
+    nws = [int(L.stegan_spectral_norm_workspace_floats(r, c)) for r, c in zip(rows, cols)]
+    # one allocation: [workspace | scale | sigma (padded to 4) | u copy | v copy] per layer, 16-byte aligned pieces
+    sizes = []
+    for r, c, w_ in zip(rows, cols, nws):
+        sizes += [w_, r, 4, r if keep_uv else 0, c if keep_uv else 0]
+    offs, tot = [], 0
+    for z in sizes:
+        offs.append(tot)
+        tot += (z + 3) & ~3
+    flat = torch.empty(tot, device=dev, dtype=torch.float32)
+    views = [flat[o:o + z] for o, z in zip(offs, sizes)]
+    ws, scale, sigma, uk, vk = (views[i::5] for i in range(5))
+    sigma = [t[:1] for t in sigma]
+    i32 = lambda xs: (C.c_int32 * n)(*xs)
+    check(L.stegan_spectral_norm_fwd_multi(
+        n, _ptr_array([w for w, _, _ in layers]), _ptr_array([u for _, u, _ in layers]), _ptr_array([v for _, _, v in layers]),
+        _ptr_array(scale), _ptr_array(sigma), _ptr_array(uk) if keep_uv else None, _ptr_array(vk) if keep_uv else None,
+        _ptr_array(ws), i32(rows), i32(cols), int(training), _stream()), "stegan_spectral_norm_fwd_multi")
+    return [(scale[i], sigma[i], uk[i] if keep_uv else None, vk[i] if keep_uv else None) for i in range(n)]
 
 
 # ---------------------------------------------------------------------------------------------

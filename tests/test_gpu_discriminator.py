@@ -82,6 +82,37 @@ def test_eval_mode_does_not_power_iterate():
     close(a[5][-1].detach().cpu().numpy(), ref[5][-1].detach().numpy(), 5e-5, "eval logits")
 
 
+def test_batched_spectral_norm_equals_per_layer():
+    """All spectral-norm layers in one call (ops.spectral_norm_multi) == each layer running its own power iteration:
+    same bits in the feature maps / logits and the u / v buffers over two training forwards; the gradients (whose
+    batch-slice partial sums meet in fp32 atomics, so their last bits vary from run to run) to 1e-6 of their scale."""
+    from ste_gan_amd import ops
+    from ste_gan_amd.models.discriminator import Discriminator
+    res = []
+    for batched in (True, False):
+        ops.SN_BATCHED = batched
+        try:
+            d = Discriminator(8)
+            d.load_state_dict(fill_state_dict(oshapes.discriminator_shapes(False)))
+            d = d.cuda()
+            sn = d.multi_scale_disc[0]
+            xs = ops.btc_to_bct(cases.disc_input("disc_full_t192").cuda())
+            f1 = sn(xs)
+            f2 = sn(xs * 0.5)
+            (f1[-1].square().mean() + f2[-1].mean() + f1[2].abs().mean()).backward()
+            res.append(([f.detach().clone() for f in f1 + f2], [p.grad.clone() for p in sn.parameters()],
+                        [b.clone() for b in sn.buffers()]))
+        finally:
+            ops.SN_BATCHED = True
+    for what, a, b in zip(("outputs", "gradients", "buffers"), res[0], res[1]):
+        assert len(a) == len(b)
+        for i, (ta, tb) in enumerate(zip(a, b)):
+            if what == "gradients":
+                assert float((ta - tb).abs().max()) <= 1e-6 * float(tb.abs().max()) + 1e-30, f"{what}[{i}]"
+            else:
+                assert torch.equal(ta, tb), f"{what}[{i}] {tuple(ta.shape)}: max diff {float((ta - tb).abs().max()):.3e}"
+
+
 def test_reflect_pad_too_large_raises():
     from ste_gan_amd.models.discriminator import DiscriminatorSmall
     d = DiscriminatorSmall(8).cuda()

@@ -405,6 +405,11 @@ int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, 
  * torch.tanh generator.py:160).  Pointers must be 16-byte aligned.
  */
 int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream);
+/* out[i] = (dy[i] + add[i]) * act'(.): the sum autograd forms when a tensor has two consumers (a discriminator feature
+ * map: the next conv and the feature-matching L1 term, train.py:236-239), folded into the activation backward.
+ * add may be NULL (= stegan_act_bwd). */
+int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,7 @@ SIGNATURES = {
     "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
+    "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
 }
 

@@ -3,13 +3,19 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      float* __restrict__ out, long n, int act) {
+// add != nullptr: a second gradient of the same tensor (the feature-matching term of a discriminator feature map, known
+// since the forward pass) is summed in here instead of by a separate elementwise kernel in front of this one
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
+                                                      const float* __restrict__ y, float* __restrict__ out, long n, int act) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 1024;
     for (; i < n; i += stride) {
         if (i + 3 < n) {
             float4 d = *reinterpret_cast<const float4*>(dy + i);
+            if (add) {
+                const float4 e = *reinterpret_cast<const float4*>(add + i);
+                d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w;
+            }
             const float4 v = *reinterpret_cast<const float4*>(y + i);
             if (act == STEGAN_ACT_LRELU || act == STEGAN_ACT_RELU) {
                 const float ns = act == STEGAN_ACT_LRELU ? 0.1f : 0.f;
@@ -24,7 +30,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             for (long j = i; j < n; ++j) {
                 const float v = y[j];
                 const float ns = act == STEGAN_ACT_LRELU ? 0.1f : 0.f;
-                out[j] = dy[j] * (act == STEGAN_ACT_TANH ? (1.f - v * v) : (v > 0.f ? 1.f : ns));
+                out[j] = (dy[j] + (add ? add[j] : 0.f)) * (act == STEGAN_ACT_TANH ? (1.f - v * v) : (v > 0.f ? 1.f : ns));
             }
         }
     }
@@ -32,13 +38,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream) {
+extern "C" int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
+                                  void* stream) {
     STEGAN_CHECK_ARG(dy && y && out && n > 0);
     STEGAN_CHECK_ARG(act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH || act == STEGAN_ACT_RELU);
-    STEGAN_CHECK_ARG(((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    STEGAN_CHECK_ARG(((uintptr_t)dy | (uintptr_t)add | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
     long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, y, out, (long)n, act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, add, y, out, (long)n, act);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream) {
+    return stegan_act_bwd_add(dy, nullptr, y, out, n, act, stream);
 }

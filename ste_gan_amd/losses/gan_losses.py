@@ -15,8 +15,9 @@ def lsgan_loss(d_out, target: float, weight: float = 1.0, unit_grad: bool = Fals
     return ops.multi_pair_loss([scale[-1] for scale in d_out], None, 1, weight, target=float(target), unit_grad=unit_grad)
 
 
-def feature_matching_loss(d_fake, d_real, weight: float = 1.0, unit_grad: bool = False):
-    """weight * sum_i sum_{j<last} l1(D_fake[i][j], D_real[i][j].detach()) -- train.py:257-262."""
+def feature_matching_loss(d_fake, d_real, weight: float = 1.0, unit_grad: bool = False, fold: bool = False):
+    """weight * sum_i sum_{j<last} l1(D_fake[i][j], D_real[i][j].detach()) -- train.py:257-262.
+    ``fold``: see ``ops.multi_pair_loss`` (the feature maps' producers add the gradients themselves)."""
     fake = [d_fake[i][j] for i in range(len(d_fake)) for j in range(len(d_fake[i]) - 1)]
     real = [d_real[i][j] for i in range(len(d_fake)) for j in range(len(d_fake[i]) - 1)]
-    return ops.multi_pair_loss(fake, real, 0, weight, unit_grad=unit_grad)
+    return ops.multi_pair_loss(fake, real, 0, weight, unit_grad=unit_grad, fold=fold)

@@ -329,6 +329,8 @@ class _WNConvFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.wb = wb
         ctx.save_for_backward(x, v, g, scale, y if cfg.out_act != ACT_NONE else None)
+        if not cfg.out_btc:
+            _fm_announce(y, cfg.out_act, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
@@ -341,7 +343,7 @@ class _WNConvFn(torch.autograd.Function):
             if y is not None:
                 y = y.transpose(1, 2).contiguous()
         if cfg.out_act != ACT_NONE:
-            dy = act_bwd(dy, y, cfg.out_act)
+            dy = act_bwd(dy, y, cfg.out_act, None if cfg.out_btc else _fm_take(y))
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         dx = dv = dg = db = dres = None
         if ctx.needs_input_grad[0]:
@@ -441,6 +443,9 @@ class _WNConvMultiFn(torch.autograd.Function):
         ctx.layers, ctx.n = layers, n
         ctx.wgrad = any(ctx.needs_input_grad[2 + n:])
         ctx.save_for_backward(*xs, *ys)
+        for y, c in zip(ys, cfgs):
+            if not c.out_btc:
+                _fm_announce(y, c.out_act, any(ctx.needs_input_grad))
         return tuple(ys)
 
     @staticmethod
@@ -451,7 +456,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         gs = []
         for dy, y, l in zip(dys, ys, layers):
             g = _gpu_f32(dy, "grad_output")
-            gs.append(act_bwd(g, y, l[3].out_act) if l[3].out_act != ACT_NONE else g)
+            gs.append(act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g)
         if ctx.wgrad:
             for x, g, l in zip(xs, gs, layers):
                 if l[5] is not None:
@@ -492,11 +497,64 @@ def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None) -
     return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink)
 
 
-def act_bwd(dy: Tensor, y: Tensor, act: int) -> Tensor:
-    """dy * act'(.) expressed through the stored OUTPUT y (lrelu: sign(y) = sign(pre); tanh: 1 - y^2)."""
+def act_bwd(dy: Tensor, y: Tensor, act: int, add: Optional[Tensor] = None) -> Tensor:
+    """(dy [+ add]) * act'(.) expressed through the stored OUTPUT y (lrelu: sign(y) = sign(pre); tanh: 1 - y^2)."""
     out = torch.empty_like(dy)
-    check(_lib.lib().stegan_act_bwd(_p(dy), _p(y), _p(out), dy.numel(), act, _stream()), "stegan_act_bwd")
+    if add is not None and (add.numel() != dy.numel() or not dy.is_contiguous()):
+        raise RuntimeError("ste_gan_amd.act_bwd: folded gradient does not match the activation gradient")
+    check(_lib.lib().stegan_act_bwd_add(_p(dy), _p(add), _p(y), _p(out), dy.numel(), act, _stream()), "stegan_act_bwd_add")
     return out
+
+
+# ---- folding the feature-matching gradient into the producer's activation backward -------------------------------
+# A discriminator feature map y has two consumers in the generator step: the next conv and the feature-matching L1 term
+# (train.py:236-239).  Its second gradient is known since the FORWARD pass (the loss kernel writes it next to the loss),
+# so instead of returning it to autograd -- which sums the two with one elementwise kernel per feature map, 48 a step --
+# multi_pair_loss(fold=True) parks it here and the conv that produced y adds it inside its activation backward.  Keys are
+# (data_ptr, numel) of y's storage; a conv announces its activated output while a fold window is open
+# (fm_fold_begin .. fm_fold_end, the train step's generator phase); fm_fold_end() raises when a parked gradient was never
+# collected, so a graph shape this shortcut does not cover fails loudly instead of dropping a term.
+_FM_WINDOW = False
+_FM_FOLDABLE: set = set()
+_FM_PENDING: dict = {}
+FM_FOLD_STATS = {"parked": 0, "collected": 0}      # of the last closed window (tests)
+_FM_COUNT = [0, 0]
+
+
+def fm_fold_begin():
+    global _FM_WINDOW
+    _FM_FOLDABLE.clear(); _FM_PENDING.clear()
+    _FM_COUNT[0] = _FM_COUNT[1] = 0
+    _FM_WINDOW = True
+
+
+def fm_fold_end():
+    global _FM_WINDOW
+    _FM_WINDOW = False
+    left = len(_FM_PENDING)
+    _FM_FOLDABLE.clear(); _FM_PENDING.clear()
+    FM_FOLD_STATS["parked"], FM_FOLD_STATS["collected"] = _FM_COUNT
+    if left:
+        raise RuntimeError(f"ste_gan_amd: {left} folded feature-matching gradient(s) were never collected by their producers")
+
+
+def fm_fold_abort():
+    """Close the window without the check (exception paths)."""
+    global _FM_WINDOW
+    _FM_WINDOW = False
+    _FM_FOLDABLE.clear(); _FM_PENDING.clear()
+
+
+def _fm_announce(y: Tensor, act: int, needs_grad: bool):
+    if _FM_WINDOW and needs_grad and act != ACT_NONE and y.is_contiguous():
+        _FM_FOLDABLE.add((y.data_ptr(), y.numel()))
+
+
+def _fm_take(y: Tensor):
+    g = _FM_PENDING.pop((y.data_ptr(), y.numel()), None) if _FM_PENDING else None
+    if g is not None:
+        _FM_COUNT[1] += 1
+    return g
 
 
 # ---------------------------------------------------------------------------------------------
@@ -533,6 +591,7 @@ class _SNConvFn(torch.autograd.Function):
         ctx.wb = wb
         ctx.save_for_backward(x, w_orig, u_keep if u_keep is not None else u, v_keep if v_keep is not None else v, scale,
                               sigma, y if cfg.out_act != ACT_NONE else None)
+        _fm_announce(y, cfg.out_act, any(ctx.needs_input_grad))
         return y
 
     @staticmethod
@@ -541,7 +600,7 @@ class _SNConvFn(torch.autograd.Function):
         x, w_orig, u, v, scale, sigma, y = ctx.saved_tensors
         dy = _gpu_f32(dy, "grad_output")
         if cfg.out_act != ACT_NONE:
-            dy = act_bwd(dy, y, cfg.out_act)
+            dy = act_bwd(dy, y, cfg.out_act, _fm_take(y))
         dx = dw_orig = db = None
         if ctx.needs_input_grad[0]:
             dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True)
@@ -741,7 +800,9 @@ class _MultiPairLossFn(torch.autograd.Function):
     as they are instead of being multiplied by a device scalar that is known to be one."""
 
     @staticmethod
-    def forward(ctx, mode: int, weight: float, target, unit_grad: bool, n: int, *ts):
+    def forward(ctx, mode: int, weight: float, target, unit_grad: int, n: int, *ts):
+        fold = unit_grad == 2          # unit upstream gradient AND gradients parked for the producers (see _fm_announce)
+        unit_grad = bool(unit_grad)
         a_list, b_list = ts[:n], (ts[n:] if target is None else (None,) * n)
         loss = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
         grads, restores = [], []
@@ -756,6 +817,11 @@ class _MultiPairLossFn(torch.autograd.Function):
             da = torch.empty_like(af) if ctx.needs_input_grad[5 + i] else None
             check(L.stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target or 0.0), af.numel(), mode, float(weight), _p(loss),
                                              _p(da), _stream()), "stegan_pair_loss_fwd_bwd")
+            key = (af.data_ptr(), af.numel())
+            if fold and da is not None and key in _FM_FOLDABLE and key not in _FM_PENDING:
+                _FM_PENDING[key] = da          # collected by the conv that produced a_i, inside its activation backward
+                _FM_COUNT[0] += 1
+                da = None
             grads.append(da); restores.append(restore)
         ctx.restores, ctx.unit_grad, ctx.n_extra = restores, unit_grad, len(ts) - n
         ctx.save_for_backward(*[g for g in grads if g is not None])
@@ -775,10 +841,16 @@ class _MultiPairLossFn(torch.autograd.Function):
         return (None, None, None, None, None, *out, *([None] * ctx.n_extra))
 
 
-def multi_pair_loss(a_list, b_list, mode: int, weight: float = 1.0, target=None, unit_grad: bool = False):
+def multi_pair_loss(a_list, b_list, mode: int, weight: float = 1.0, target=None, unit_grad: bool = False,
+                    fold: bool = False):
+    """``fold`` (needs ``unit_grad``, and an open fm_fold_begin() window): gradients of inputs that are the activated
+    outputs of this package's convs are not returned to autograd but added by those convs' backward passes."""
     a_list = list(a_list)
     extra = [] if target is not None else [b.detach() for b in b_list]
-    return _MultiPairLossFn.apply(mode, float(weight), target, bool(unit_grad), len(a_list), *a_list, *extra)
+    if fold and not unit_grad:
+        raise ValueError("multi_pair_loss: fold requires unit_grad")
+    return _MultiPairLossFn.apply(mode, float(weight), target, 2 if fold else int(bool(unit_grad)), len(a_list), *a_list,
+                                  *extra)
 
 
 def l1_loss(a, b):

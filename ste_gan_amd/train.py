@@ -79,6 +79,9 @@ class GANTrainStep:
         self.last: Dict[str, torch.Tensor] = {}
         import os
         self.overlap_encoder = os.environ.get("STEGAN_OVERLAP_ENCODER", "1") != "0"
+        # feature-matching gradients are added inside the discriminator convs' activation backward instead of by one
+        # autograd accumulation kernel per feature map (ops.fm_fold_begin)
+        self.fold_fm = os.environ.get("STEGAN_FOLD_FM", "1") != "0"
         self._side = None
 
     def _side_stream(self):
@@ -164,6 +167,10 @@ class GANTrainStep:
 
         # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
         self._set_d_grad(False)          # D's weight grads from loss_G are discarded by the reference: skip them
+        from . import ops as _ops
+        fold = self.fold_fm and bool(t.loss_feat_match_error)
+        if fold:
+            _ops.fm_fold_begin()         # the feature maps' producers add the feature-matching gradients themselves
         try:
             D_fake = netD(x_pred_t)
             with torch.no_grad():
@@ -175,11 +182,14 @@ class GANTrainStep:
                 loss_G = loss_G + lsgan_loss(D_fake, 1.0, unit_grad=True)
             if t.loss_feat_match_error:
                 w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
-                loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True)
+                loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
                 loss_G = loss_G + loss_feat_w
                 out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
             loss_G.backward()
+            if fold:
+                _ops.fm_fold_end()       # raises if a parked gradient was not collected
         finally:
+            _ops.fm_fold_abort()
             self._set_d_grad(True)
         self.optG.finalize_grads()
         if self.comm is not None:

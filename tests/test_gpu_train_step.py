@@ -220,3 +220,31 @@ def test_graph_replay_matches_golden(golden):
                 st["num_correct_phones_no_silence"]] == g[f"s{s}.counters"].tolist()
         close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
         close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
+
+
+def test_feature_matching_fold_equals_autograd_accumulation():
+    """The feature-matching gradients added inside the discriminator convs' activation backward (ops.fm_fold_begin) give
+    the generator the same gradients as returning them to autograd: every feature map is parked and collected, and the
+    per-tensor gradients agree to fp32 atomics noise."""
+    from ste_gan_amd import ops
+    name = next(iter(cases.STEP_CASES))
+    grads = []
+    for fold in (True, False):
+        cfg, netG, netD, optG, optD, step = build(name)
+        step.fold_fm = fold
+        step(to_batch(cases.step_batch(name, 0)))
+        if fold:
+            n_fmaps = sum(len(d.layers) for d in list(netD.multi_pooled_disc) + list(netD.multi_scale_disc))
+            assert ops.FM_FOLD_STATS == {"parked": n_fmaps, "collected": n_fmaps}
+        grads.append([p.grad.clone() for p in netG.parameters()])
+    for a, b in zip(*grads):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+
+
+def test_fold_window_reports_uncollected_gradients():
+    from ste_gan_amd import ops
+    ops.fm_fold_begin()
+    ops._FM_PENDING[(1234, 8)] = torch.zeros(8)
+    with pytest.raises(RuntimeError, match="never collected"):
+        ops.fm_fold_end()
+    assert not ops._FM_PENDING and not ops._FM_WINDOW

@@ -397,6 +397,19 @@ int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2, void* str
 
 /* ---- elementwise helpers of the backward pass --------------------------------------------- */
 /* dx[b,c,t] = dxe[b,c,2t] + dxe[b,c,2t+1]   (backward of nn.Upsample(scale_factor=2), conv.py:40,55) */
+/*
+ * Single-output-channel convs (the output layer of every sub-discriminator, discriminator.py:31,60,81,113) as streaming
+ * fp32 VALU kernels -- same arguments and results as stegan_conv1d_fwd / _bwd_data / _bwd_weight with the RAW direction
+ * tensor w (1, Cin, K) and scale (1 value or NULL).  Return 1 (nothing launched) unless Cout == 1, groups == 1,
+ * upsample == 1, K <= 8, no input activation / residual / mask / add / (B, T, C) output.
+ */
+int stegan_conv1d_fwd_skinny(const stegan_conv_desc* d, const float* x, const float* w, const float* scale,
+                             const float* bias, const float* residual, float* y, void* stream);
+int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
+                                  const float* mask_src, const float* add_src, float* dx, void* stream);
+int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                    void* stream);
+
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);
 
 /*

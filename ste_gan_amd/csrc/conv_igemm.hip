@@ -354,6 +354,11 @@ inline int bwd_weight_splits(ConvK& p, int groups) {
     const int chunks = ceil_div(p.R, KC);
     const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * groups;
     int splits = (int)((1024 + tiles - 1) / tiles);
+    // every split ends in one atomic per output element, and same-address atomics serialise in L2 (~13 ns each): beyond a
+    // few hundred splits a tiny dw (8 -> 32 channels: ONE tile, 880 splits of one 16-deep chunk each) is atomics-bound
+    static const char* env_cap = getenv("STEGAN_WGRAD_SPLIT_CAP");
+    const int cap = env_cap ? atoi(env_cap) : 256;
+    if (splits > cap) splits = cap;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     p.r_chunks_per_split = ceil_div(chunks, splits);

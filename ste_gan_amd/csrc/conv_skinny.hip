@@ -1,0 +1,257 @@
+// "Skinny" convolutions: the single-output-channel convs that end every sub-discriminator (discriminator.py:31,60,81,
+// 113: 512 -> 1 / 1024 -> 1, k = 3) in all three directions, on the vector ALUs in exact fp32.
+//
+// A 1-row GEMM has nothing for a matrix core: in the 64-row MFMA tiles of conv_direct.hip / conv_igemm.hip 63 rows are
+// padding, and those kernels' per-block chains (stage a chunk, barrier, multiply, next chunk) made each of these tiny
+// layers cost 15-30 us -- 24 forward, 16 input-gradient and 8 weight-gradient launches a step.  Each direction is a
+// streaming pass over ONE tensor (x, dx, x again), i.e. HBM-bound at a few microseconds:
+//
+//   forward   y[b, t]       = act(scale * sum_{ci, k} w[ci, k] * x[b, ci, t s + k d - p] + bias)
+//   d/dx      dx[b, ci, q]  = scale * sum_k w[ci, k] * dy[b, (q + p - k d) / s]          (terms with s | (q + p - k d))
+//   d/dw      dw[ci, k]    += sum_{b, t} dy[b, t] * x[b, ci, t s + k d - p]               (raw direction gradient)
+//
+// Every entry point returns 1 for a shape it does not take (caller falls through to the general kernels).
+#include "common.h"
+
+extern "C" int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream);
+
+namespace {
+
+constexpr int SK_KMAX = 8;
+
+struct SkP {
+    const float* x;       // (B, Cin, Tin)
+    const float* w;       // (1, Cin, K)
+    const float* dy;      // (B, 1, Tout)
+    const float* scale;   // 1 value or null
+    const float* bias;    // 1 value or null
+    float* out;           // y (B, 1, Tout) | dx (B, Cin, Tin) | dw (1, Cin, K)
+    int B, Cin, K, stride, dil, pad, Tin, Tout, out_act;
+    int TT, CL;           // forward: time-tile width, channel lanes per block (TT * CL <= 256)
+    int per;              // weight gradient: batch rows per block
+    FastDiv fdTT, fdS, fdTin, fdCT, fdCL;
+};
+
+__device__ __forceinline__ float sk_act(float v, int act) {
+    if (act == STEGAN_ACT_LRELU) return v > 0.f ? v : 0.1f * v;
+    if (act == STEGAN_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == STEGAN_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// forward: block = (batch row, tile of TT <= 8 output steps); thread = (output step, channel lane); a channel lane walks
+// channels lane, lane + CL, ...  The (ci, t) planes are dense, so the TT lanes of a channel lane read one contiguous run
+// and neighbouring channel lanes the next rows.  The kernel is bound by load round trips, not bytes: all 2 K loads of
+// FOUR channels are issued before their first use, and short tiles give many channel lanes (few trips each) and many
+// blocks -- the first version (64-step tiles, one load per multiply-add) took 35 us for 1024 channels x 48 steps.
+// Partial sums meet in LDS, in fixed order.
+__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const SkP p) {
+    __shared__ float red[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int cl = (int)fd_div((uint32_t)tid, p.fdTT), tl = tid - cl * p.TT;
+    const int t = blockIdx.y * p.TT + tl;
+    const bool live = cl < p.CL && t < p.Tout;
+    int qk[SK_KMAX];
+    bool ok[SK_KMAX];
+#pragma unroll
+    for (int k = 0; k < SK_KMAX; ++k) {
+        const int q = t * p.stride + k * p.dil - p.pad;
+        ok[k] = live && k < p.K && q >= 0 && q < p.Tin;
+        qk[k] = ok[k] ? q : 0;
+    }
+    const float* xb = p.x + (size_t)b * p.Cin * p.Tin;
+    constexpr int NCH = 4;                                  // channels in flight per thread: NCH x 2 K independent loads
+    float acc[NCH];
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) acc[u] = 0.f;
+    if (live) {
+        for (int c = cl; c < p.Cin; c += NCH * p.CL) {
+            float xv[NCH][SK_KMAX], wv[NCH][SK_KMAX];
+            bool has[NCH];
+#pragma unroll
+            for (int u = 0; u < NCH; ++u) {
+                has[u] = c + u * p.CL < p.Cin;
+                const int cc = has[u] ? c + u * p.CL : c;
+#pragma unroll
+                for (int k = 0; k < SK_KMAX; ++k) {
+                    if (k < p.K) {                          // uniform
+                        xv[u][k] = xb[(size_t)cc * p.Tin + qk[k]];
+                        wv[u][k] = p.w[cc * p.K + k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NCH; ++u)
+#pragma unroll
+                for (int k = 0; k < SK_KMAX; ++k)
+                    if (k < p.K) acc[u] += (ok[k] && has[u]) ? xv[u][k] * wv[u][k] : 0.f;
+        }
+    }
+    red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (cl == 0 && t < p.Tout) {
+        float s = 0.f;
+        for (int j = 0; j < p.CL; ++j) s += red[j * p.TT + tl];       // fixed order: deterministic
+        if (p.scale) s *= p.scale[0];
+        if (p.bias) s += p.bias[0];
+        p.out[(size_t)b * p.Tout + t] = sk_act(s, p.out_act);
+    }
+}
+
+// input gradient: one thread per dx element, consecutive threads consecutive addresses; dy (B x Tout floats) and w stay
+// in cache.
+__global__ __launch_bounds__(256) void conv_cout1_bwd_data_kernel(const SkP p, long n) {
+    const float sc = p.scale ? p.scale[0] : 1.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const uint32_t b = fd_div((uint32_t)e, p.fdCT);
+        const uint32_t r = (uint32_t)e - b * (uint32_t)(p.Cin * p.Tin);
+        const uint32_t ci = fd_div(r, p.fdTin);
+        const int q = (int)(r - ci * p.Tin);
+        const float* dyb = p.dy + (size_t)b * p.Tout;
+        const float* wc = p.w + (size_t)ci * p.K;
+        float s = 0.f;
+        for (int k = 0; k < p.K; ++k) {
+            const int a = q + p.pad - k * p.dil;
+            if (a < 0) continue;
+            const int t = (int)fd_div((uint32_t)a, p.fdS);
+            if (t * p.stride != a || t >= p.Tout) continue;
+            s += wc[k] * dyb[t];
+        }
+        p.out[e] = s * sc;
+    }
+}
+
+// weight gradient: block = (CL channels, slice of `per` batch rows, tile of TT <= 64 input steps); thread = (input step
+// q, channel): it walks the batch rows of its slice with x[b, c, q] -- consecutive lanes consecutive addresses, the CL
+// rows of a block contiguous -- against the <= K dy values that pair with q, then the TT steps of a channel meet in LDS
+// and one thread per (channel, tap) adds the block's sum into dw with an fp32 atomic (as the split-K sums of the general
+// weight-gradient kernels do).  (A lane-per-channel version read x with a row stride between lanes: 64 cache lines per
+// load instruction, 32 us.)
+__global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
+    __shared__ float red[SK_KMAX][256];
+    const int tid = threadIdx.x;
+    const int cl = (int)fd_div((uint32_t)tid, p.fdTT), tl = tid - cl * p.TT;
+    const int c = blockIdx.x * p.CL + cl, q = blockIdx.z * p.TT + tl;
+    const bool live = cl < p.CL && c < p.Cin && q < p.Tin;
+    const int b0 = blockIdx.y * p.per, b1 = min(p.B, b0 + p.per);
+    int tk[SK_KMAX];
+    bool ok[SK_KMAX];
+#pragma unroll
+    for (int k = 0; k < SK_KMAX; ++k) {
+        const int a = q + p.pad - k * p.dil;
+        const int t = (int)fd_div((uint32_t)(a < 0 ? 0 : a), p.fdS);
+        ok[k] = live && k < p.K && a >= 0 && t * p.stride == a && t < p.Tout;
+        tk[k] = ok[k] ? t : 0;
+    }
+    float acc[SK_KMAX];
+#pragma unroll
+    for (int k = 0; k < SK_KMAX; ++k) acc[k] = 0.f;
+    if (live) {
+        const float* xr = p.x + (size_t)c * p.Tin + q;
+        const size_t xs = (size_t)p.Cin * p.Tin;
+#pragma unroll 4
+        for (int b = b0; b < b1; ++b) {
+            const float xv = xr[b * xs];
+            const float* dyb = p.dy + (size_t)b * p.Tout;
+#pragma unroll
+            for (int k = 0; k < SK_KMAX; ++k)
+                if (k < p.K) acc[k] += ok[k] ? dyb[tk[k]] * xv : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SK_KMAX; ++k) red[k][tid] = acc[k];
+    __syncthreads();
+    // thread (k, channel lane): sum of the channel's TT steps
+    if (tid < p.CL * p.K) {
+        const int k = (int)fd_div((uint32_t)tid, p.fdCL), cj = tid - k * p.CL;
+        const int cc = blockIdx.x * p.CL + cj;
+        if (cc < p.Cin) {
+            float s = 0.f;
+            for (int j = 0; j < p.TT; ++j) s += red[k][cj * p.TT + j];
+            atomicAdd(&p.out[(size_t)cc * p.K + k], s);
+        }
+    }
+}
+
+// Cout == 1, ungrouped, no upsample / input activation / residual / (B, T, C) output: everything else returns 1
+int fill(const stegan_conv_desc* d, SkP& p) {
+    if (!d) return STEGAN_E_ARG;
+    if (d->Cout != 1 || d->groups != 1 || d->upsample != 1 || d->in_act != STEGAN_ACT_NONE || d->out_btc) return 1;
+    if (d->K < 1 || d->K > SK_KMAX || d->B <= 0 || d->Cin <= 0 || d->Tin <= 0 || d->Tout <= 0 || d->stride < 1 ||
+        d->dilation < 1 || d->pad < 0)
+        return 1;
+    if ((int64_t)d->B * d->Cin * d->Tin >= (1ll << 31)) return 1;
+    const int span = d->Tin + 2 * d->pad - d->dilation * (d->K - 1) - 1;
+    if (span < 0 || d->Tout != span / d->stride + 1) return STEGAN_E_ARG;
+    p.B = d->B; p.Cin = d->Cin; p.K = d->K; p.stride = d->stride; p.dil = d->dilation; p.pad = d->pad;
+    p.Tin = d->Tin; p.Tout = d->Tout; p.out_act = d->out_act;
+    p.fdS = make_fastdiv((uint32_t)d->stride);
+    p.fdTin = make_fastdiv((uint32_t)d->Tin);
+    p.fdCT = make_fastdiv((uint32_t)(d->Cin * d->Tin));
+    p.TT = p.CL = p.per = 1;
+    p.fdTT = make_fastdiv(1); p.fdCL = make_fastdiv(1);
+    p.x = p.w = p.dy = p.scale = p.bias = nullptr;
+    p.out = nullptr;
+    return STEGAN_OK;
+}
+
+}  // namespace
+
+extern "C" int stegan_conv1d_fwd_skinny(const stegan_conv_desc* d, const float* x, const float* w, const float* scale,
+                                        const float* bias, const float* residual, float* y, void* stream) {
+    SkP p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    if (residual) return 1;
+    STEGAN_CHECK_ARG(x && w && y);
+    STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
+    p.x = x; p.w = w; p.scale = scale; p.bias = bias; p.out = y;
+    p.TT = d->Tout < 8 ? d->Tout : 8;
+    p.CL = 256 / p.TT;
+    if (p.CL > d->Cin) p.CL = d->Cin;
+    p.fdTT = make_fastdiv((uint32_t)p.TT);
+    hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3((unsigned)d->B, (unsigned)ceil_div(d->Tout, p.TT)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
+                                             const float* mask_src, const float* add_src, float* dx, void* stream) {
+    SkP p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    if (mask_src || add_src) return 1;
+    STEGAN_CHECK_ARG(dy && w && dx);
+    p.dy = dy; p.w = w; p.scale = scale; p.out = dx;
+    const long n = (long)d->B * d->Cin * d->Tin;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_cout1_bwd_data_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, n);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
+                                               float* db, void* stream) {
+    SkP p;
+    int rc = fill(d, p);
+    if (rc) return rc;
+    STEGAN_CHECK_ARG(x && dy && dw);
+    p.x = x; p.dy = dy; p.out = dw;
+    p.TT = d->Tin < 64 ? d->Tin : 64;
+    p.CL = 256 / p.TT;
+    if (p.CL > d->Cin) p.CL = d->Cin;
+    if (p.CL * d->K > 256) p.CL = 256 / d->K;
+    p.fdTT = make_fastdiv((uint32_t)p.TT); p.fdCL = make_fastdiv((uint32_t)p.CL);
+    const int cblocks = ceil_div(d->Cin, p.CL), qtiles = ceil_div(d->Tin, p.TT);
+    int slices = ceil_div(512, cblocks * qtiles);             // ~2 blocks per CU; every slice ends in Cin x K atomics
+    if (slices > d->B) slices = d->B;
+    if (slices > 64) slices = 64;
+    p.per = ceil_div(d->B, slices);
+    hipLaunchKernelGGL(conv_cout1_wgrad_kernel, dim3((unsigned)cblocks, (unsigned)ceil_div(d->B, p.per), (unsigned)qtiles),
+                       dim3(256), 0, (hipStream_t)stream, p);
+    STEGAN_LAUNCH_CHECK();
+    if (db) return stegan_bias_grad(dy, db, d->B, 1, d->Tout, stream);
+    return STEGAN_OK;
+}

@@ -111,6 +111,8 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
         name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     elif kind == "bf16":
         name = "conv_wgrad_bf16_kernel" if mode == 2 else "conv_bf16_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
+    elif kind == "skinny":
+        name = ("conv_cout1_fwd_kernel", "conv_cout1_bwd_data_kernel", "conv_cout1_wgrad_kernel")[mode]
     elif mode == 2:
         name = "bwd_weight (conv_wgrad_kernel | conv_igemm_kernel<2>)"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -221,6 +223,12 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
         if residual.shape != y.shape:
             raise RuntimeError(f"residual shape {list(residual.shape)} does not match conv output {list(y.shape)}")
     d = _desc(cfg, B, tin, tout)
+    if cfg.cout == 1 and SKINNY:             # single-output-channel convs: streaming VALU kernels (conv_skinny.hip)
+        rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_skinny(C.byref(d), _p(x), _p(w), _p(scale), _p(bias),
+                                                                      _p(residual), _p(y), _stream()), "skinny")
+        if rc != 1:
+            check(rc, "stegan_conv1d_fwd_skinny")
+            return y
     wfh = _bf16_of(wf)
     if wfh is not None:
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
@@ -252,6 +260,13 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     B, _, tout = dy.shape
     dx = torch.empty((B, cfg.cin, tin * cfg.upsample), device=dy.device, dtype=torch.float32)
     d = _desc(cfg, B, tin, tout)
+    if cfg.cout == 1 and SKINNY:
+        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_skinny(C.byref(d), _p(dy), _p(_gpu_f32(w, "weight")),
+                                                                           _p(scale), _p(mask_src), _p(add_src), _p(dx),
+                                                                           _stream()), "skinny")
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_data_skinny")
+            return dx
     wbh = _bf16_of(wb)
     if wbh is not None:
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
@@ -281,6 +296,12 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     """Accumulates into dw (and db)."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
+    if cfg.cout == 1 and SKINNY:
+        rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_skinny(C.byref(d), _p(x), _p(dy), _p(dw), _p(db),
+                                                                             _stream()), "skinny")
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_weight_skinny")
+            return
     ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
     if COMPUTE_DTYPE == "bf16":
         rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_h(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
@@ -621,6 +642,7 @@ def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None
     return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre)
 
 
+SKINNY = os.environ.get("STEGAN_SKINNY", "1") != "0"   # Cout == 1 convs on the streaming kernels of conv_skinny.hip
 SN_BATCHED = os.environ.get("STEGAN_SN_BATCHED", "1") != "0"      # scale discriminator: all spectral-norm layers' power iterations in one call (0: per layer)
 
 

@@ -102,3 +102,55 @@ def test_bad_shape_raises():
         ops.conv1d_fwd(torch.randn(2, 7, 16, device="cuda"), torch.randn(8, 8, 3, device="cuda"), None, None, None, c)
     with pytest.raises(RuntimeError):       # no silent CPU fallback
         ops.conv1d_fwd(torch.randn(2, 8, 16), torch.randn(8, 8, 3), None, None, None, c)
+
+
+# (B, Cin, K, stride, dil, pad, Tin, out_act)
+SKINNY_CASES = [
+    (64, 1024, 3, 1, 1, 1, 48, 0),      # MSD output conv of the hot path
+    (22, 512, 3, 1, 1, 1, 4, 0),        # MPD output conv, H = 4
+    (10, 512, 3, 1, 1, 1, 5, 0),        # odd H
+    (3, 70, 3, 1, 1, 1, 50, 2),         # ragged channels, leaky-ReLU epilogue
+    (2, 33, 5, 2, 1, 2, 71, 0),         # stride 2, k5, rows longer than one 64-step tile
+    (2, 16, 3, 1, 3, 3, 130, 3),        # dilation 3, tanh, three tiles
+    (1, 8, 8, 1, 1, 0, 9, 0),           # K = 8 (the kernel's tap limit), no padding
+    (2, 300, 1, 1, 1, 0, 7, 0),         # 1x1
+]
+
+
+@pytest.mark.parametrize("cfg", SKINNY_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_single_output_channel_kernels(cfg):
+    """conv_skinny.hip (Cout == 1: forward, input gradient, weight gradient) against F.conv1d + autograd in fp64, and the
+    kernel selection: these shapes must take the streaming kernels, everything they decline the general ones."""
+    from ste_gan_amd import ops
+    B, Cin, K, s, d, p, Tin, act = cfg
+    gen = torch.Generator().manual_seed(hash(cfg) % (2 ** 31))
+    x = torch.randn(B, Cin, Tin, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(1, Cin, K, generator=gen, dtype=torch.float64) / (Cin * K) ** 0.5).requires_grad_(True)
+    scale = 0.5 + torch.rand(1, generator=gen, dtype=torch.float64)
+    bias = torch.randn(1, generator=gen, dtype=torch.float64)
+    c = ops.ConvCfg(Cin, 1, K, s, d, p, 1, 1, 0, act)
+    Tout = c.tout(Tin)
+    pre = F.conv1d(x, w * scale.view(-1, 1, 1), bias, stride=s, dilation=d, padding=p)
+    y_ref = {0: lambda v: v, 2: lambda v: F.leaky_relu(v, 0.1), 3: torch.tanh}[act](pre)
+    dy = torch.randn(B, 1, Tout, generator=gen, dtype=torch.float64)
+    dx_ref, dw_ref = torch.autograd.grad(pre, [x, w], dy)
+    dw_ref = dw_ref / scale.view(-1, 1, 1)
+    xg, wg, sg, bg, dyg = (t.detach().float().cuda() for t in (x, w, scale, bias, dy))
+    y = ops.conv1d_fwd(xg, wg, sg, bg, None, c)
+    assert ops.LAST_CONV_KERNEL == "skinny"
+    torch.testing.assert_close(y.double().cpu(), y_ref.detach(), rtol=1e-5, atol=1e-5)
+    dx = ops.conv1d_bwd_data(dyg, wg, sg, None, None, c, Tin)
+    assert ops.LAST_CONV_KERNEL == "skinny"
+    torch.testing.assert_close(dx.double().cpu(), dx_ref, rtol=1e-5, atol=1e-5 * float(dx_ref.abs().max()))
+    dw = torch.full_like(wg, 0.25)
+    db = torch.full((1,), -1.0, device="cuda")
+    ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
+    assert ops.LAST_CONV_KERNEL == "skinny"
+    torch.testing.assert_close(dw.double().cpu() - 0.25, dw_ref, rtol=1e-4, atol=2e-5 * float(dw_ref.abs().max()))
+    torch.testing.assert_close(db.double().cpu() + 1.0, dy.sum((0, 2)), rtol=1e-4, atol=1e-4 * float(dy.abs().sum()))
+    # declined: residual (forward), mask / add (input gradient), more than one output channel
+    res = torch.randn(B, 1, Tout, device="cuda")
+    y2 = ops.conv1d_fwd(xg, wg, sg, bg, res, c)
+    assert ops.LAST_CONV_KERNEL != "skinny"
+    torch.testing.assert_close(y2.double().cpu(), {0: lambda v: v, 2: lambda v: F.leaky_relu(v, 0.1), 3: torch.tanh}[act](
+        pre.detach() + res.double().cpu()), rtol=2e-5, atol=2e-5)

@@ -198,7 +198,11 @@ def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = 
     if bufs is None:
         bufs = (torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 0)), device=w3.device, dtype=torch.float32),
                 torch.zeros(int(L.stegan_conv_prep_floats(C.byref(d), 1)), device=w3.device, dtype=torch.float32))
-    check(L.stegan_conv_prep(C.byref(d), _p(w3), _p(scale), _p(bufs[0]), _p(bufs[1]), _stream()), "stegan_conv_prep")
+    # bf16 mode keeps ONLY the bf16 copies current (the fp32 buffers then merely carry them as ``.h``): every conv runs on
+    # the bf16 or the single-output-channel kernels, and a shape both decline goes to the implicit-GEMM kernel, which reads
+    # the raw tensor -- conv1d_fwd / conv1d_bwd_data never hand the fp32 copies to a kernel in that mode
+    if COMPUTE_DTYPE != "bf16":
+        check(L.stegan_conv_prep(C.byref(d), _p(w3), _p(scale), _p(bufs[0]), _p(bufs[1]), _stream()), "stegan_conv_prep")
     if COMPUTE_DTYPE == "bf16":
         for which, b in enumerate(bufs):
             if getattr(b, "h", None) is None:
@@ -238,7 +242,7 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
         if rc != 1:
             check(rc, "stegan_conv1d_fwd_h")
             return y
-    if wf is not None:
+    if wf is not None and COMPUTE_DTYPE != "bf16":       # (bf16 mode does not maintain the fp32 copies: prep_weights)
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
         rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_t(C.byref(d), _p(x), _p(wf), _p(scale), _p(bias),
                                                                  _p(residual), _p(y), _p(ws), ws.numel(), _stream()),
@@ -277,7 +281,7 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_h")
             return dx
-    if wb is not None:
+    if wb is not None and COMPUTE_DTYPE != "bf16":
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
         rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_t(C.byref(d), _p(dy), _p(wb), _p(us), _p(mask_src),
@@ -413,6 +417,8 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
             check(rc, "stegan_conv1d_fwd_multi_h")
             return ys
         return None                     # per-problem launches (each picks bf16 or fp32 on its own)
+    if COMPUTE_DTYPE == "bf16":
+        return None                     # (the fp32 copies are not maintained in bf16 mode)
     rc = _lib.lib().stegan_conv1d_fwd_multi(n, dptr, _ptr_array(xs), _ptr_array(wfs), _ptr_array(scales), _ptr_array(biases),
                                             None, _ptr_array(ys), _stream())
     if rc == 1:
@@ -437,6 +443,8 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins):
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_multi_h")
             return dxs
+        return None
+    if COMPUTE_DTYPE == "bf16":
         return None
     rc = _lib.lib().stegan_conv1d_bwd_data_multi(n, dptr, _ptr_array(dys), _ptr_array(wbs), None, None, _ptr_array(dxs),
                                                  _stream())

@@ -178,7 +178,8 @@ class ConvPack:
         L = _lib.lib()
         check(L.stegan_wn_scales(self.n, P(self.t_v), P(self.t_g), P(self.t_s), P(self.t_rows), P(self.t_cols),
                                  self.max_rows, s), "stegan_wn_scales")
-        check(L.stegan_conv_prep_multi(self.n, P(self.t_prep), self.max_tiles, s), "stegan_conv_prep_multi")
+        if not ops.bf16_enabled():          # bf16 mode maintains only the bf16 copies (ops.prep_weights)
+            check(L.stegan_conv_prep_multi(self.n, P(self.t_prep), self.max_tiles, s), "stegan_conv_prep_multi")
         if ops.bf16_enabled():
             if self.t_prep_h is None:
                 self._build_bf16_table()

@@ -4,9 +4,12 @@
 ``parse_args`` keep the reference's signatures and CLI flags (train.py:39-46,505-574).  The hot loop
 (train.py:165-268) lives in :class:`GANTrainStep`:
 
-* same order of operations -- G forward; D(fake.detach()), D(real); LSGAN D loss; optD step; then with the
+* same dependencies and values -- G forward; D(fake.detach()), D(real); LSGAN D loss; optD step; then with the
   UPDATED D: D(fake), D(real); adversarial + multi-TD + speech-unit + phoneme + feature-matching losses;
-  optG step; the spectral-norm power iteration runs on each of the four D forwards;
+  optG step; the spectral-norm power iteration runs on each of the four D forwards.  The D-independent terms
+  (multi-TD, EMG encoder) and their gradient w.r.t. the generated EMG are evaluated on a side HIP stream beside the
+  discriminator step rather than after it (they read nothing it writes), and enter the generator's backward pass
+  as a second root;
 * every arithmetic op is a libstegan_hip.so kernel; no ``.item()`` inside the step -- the loss scalars and the
   phoneme counters are read back once, by :meth:`GANTrainStep.read_stats`;
 * work the reference does only to throw away is skipped: D's weight gradients inside ``loss_G.backward()``
@@ -109,6 +112,54 @@ class GANTrainStep:
         netG.train()
         x_pred_t = netG(s_t1, sess_idx, spk_mode_idx)                                   # train.py:182
 
+        # ---- D-independent generator losses (multi-TD, frozen EMG encoder) and THEIR gradient w.r.t. the generated EMG.
+        # The reference computes them inside the generator step (train.py:213-256), after the discriminator update, but
+        # they read nothing the discriminator step writes.  Here they run -- forward AND backward, down to d loss / d x_pred
+        # -- on a side HIP stream forked right after the generator forward, beside the whole discriminator step; the
+        # generator step then hands that gradient to autograd together with the discriminator-side losses
+        # (autograd.backward([loss, x_pred], [1, g_side])), so the generator is still traversed once and its parameters
+        # receive the same sums.  The encoder branch works on T_su = 12 frames: ~130 short, latency-bound launches that
+        # fill a fraction of the chip, 2.3 ms when they run alone.  (The first arrangement forked the branch inside the
+        # generator step and relied on loss_G.backward() to overlap the two sub-graphs; the round-2 kernel trace showed the
+        # captured graph running them one after the other: 0.8 ms of encoder forward and 1.5 ms of encoder backward with
+        # every other queue idle.)
+        main_stream = torch.cuda.current_stream()
+        side = self._side_stream() if self.overlap_encoder else None
+        loss_side = None
+        g_side = None
+        if side is not None:
+            side.wait_stream(main_stream)                      # x_pred, the batch
+            torch.cuda.set_stream(side)
+        try:
+            xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
+            if t.loss_multi_td_error:
+                td_error = self.multi_td_loss(x_t, xp)
+                loss_side = t.loss_multi_td_weight * td_error
+                out["multi_td"] = td_error.detach()
+            if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
+                enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets)
+                if t.loss_speech_unit_error:
+                    term = t.loss_speech_unit_weight * enc_out.speech_unit_loss
+                    loss_side = term if loss_side is None else loss_side + term
+                    out["speech_unit"] = enc_out.speech_unit_loss.detach()
+                if t.loss_phoneme_error:
+                    term = t.loss_phoneme_weight * enc_out.phoneme_loss
+                    loss_side = term if loss_side is None else loss_side + term
+                    out["phoneme"] = enc_out.phoneme_loss.detach()
+                out["phoneme_counters"] = enc_out._counters
+            if t.loss_waveform_error:
+                from . import ops
+                wave_loss = ops.mse_loss(xp, x_t)
+                term = t.loss_waveform_weight * wave_loss
+                loss_side = term if loss_side is None else loss_side + term
+                out["waveform"] = wave_loss.detach()
+            if loss_side is not None:
+                (g_side,) = torch.autograd.grad(loss_side, xp)
+                loss_side = loss_side.detach()
+        finally:
+            if side is not None:
+                torch.cuda.set_stream(main_stream)
+
         # ---- discriminator step (train.py:189-199)
         d_handle = None
         if t.loss_adversarial:
@@ -121,42 +172,6 @@ class GANTrainStep:
             if self.comm is not None:
                 self.optD.flat.gather_grads()      # any gradient autograd did not write through its arena view
                 d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
-
-        # ---- D-independent generator losses (multi-TD, frozen EMG encoder): they overlap the D-gradient all-reduce, and --
-        # on a side HIP stream forked here and joined before the losses are summed -- the optimiser step of D and the two
-        # generator-side discriminator passes below.  The encoder branch (T_su = 12 frames: short, latency-bound launches
-        # that fill a fraction of the chip) and the discriminator branch share no data until loss_G; autograd runs each
-        # op's backward on the stream of its forward, so the two branches overlap in loss_G.backward() as well.
-        loss_G = 0
-        main_stream = torch.cuda.current_stream()
-        side = self._side_stream() if self.overlap_encoder else None
-        if side is not None:
-            side.wait_stream(main_stream)                      # x_pred, the batch
-            torch.cuda.set_stream(side)
-        try:
-            loss_side = 0
-            if t.loss_multi_td_error:
-                td_error = self.multi_td_loss(x_t, x_pred_t)
-                loss_side = loss_side + t.loss_multi_td_weight * td_error
-                out["multi_td"] = td_error.detach()
-            enc_out: Optional[EMGEncoderLossOutput] = None
-            if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
-                enc_out = self.emg_encoder_loss(x_pred_t, speech_units_t, phoneme_targets)
-                if t.loss_speech_unit_error:
-                    loss_side = loss_side + t.loss_speech_unit_weight * enc_out.speech_unit_loss
-                    out["speech_unit"] = enc_out.speech_unit_loss.detach()
-                if t.loss_phoneme_error:
-                    loss_side = loss_side + t.loss_phoneme_weight * enc_out.phoneme_loss
-                    out["phoneme"] = enc_out.phoneme_loss.detach()
-                out["phoneme_counters"] = enc_out._counters
-            if t.loss_waveform_error:
-                from . import ops
-                wave_loss = ops.mse_loss(x_pred_t, x_t)
-                loss_side = loss_side + t.loss_waveform_weight * wave_loss
-                out["waveform"] = wave_loss.detach()
-        finally:
-            if side is not None:
-                torch.cuda.set_stream(main_stream)
 
         if t.loss_adversarial:
             if d_handle is not None:
@@ -175,17 +190,25 @@ class GANTrainStep:
             D_fake = netD(x_pred_t)
             with torch.no_grad():
                 D_real = netD(x_t)
-            if side is not None:
-                main_stream.wait_stream(side)                  # join: the side branch's loss terms are complete
-            loss_G = loss_G + loss_side
+            loss_main = None
             if t.loss_adversarial:
-                loss_G = loss_G + lsgan_loss(D_fake, 1.0, unit_grad=True)
+                loss_main = lsgan_loss(D_fake, 1.0, unit_grad=True)
             if t.loss_feat_match_error:
                 w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
                 loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
-                loss_G = loss_G + loss_feat_w
+                loss_main = loss_feat_w if loss_main is None else loss_main + loss_feat_w
                 out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
-            loss_G.backward()
+            if side is not None:
+                main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
+            # one pass through the generator for both gradient sources
+            roots, grads = [], []
+            if loss_main is not None:
+                roots.append(loss_main); grads.append(None)
+            if g_side is not None:
+                roots.append(x_pred_t); grads.append(g_side)
+            if roots:
+                torch.autograd.backward(roots, grads)
+            loss_G = (loss_main.detach() if loss_main is not None else 0) + (loss_side if loss_side is not None else 0)
             if fold:
                 _ops.fm_fold_end()       # raises if a parked gradient was not collected
         finally:
@@ -198,7 +221,7 @@ class GANTrainStep:
             self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
         else:
             self.optG.step(finalized=True)
-        out["generator"] = loss_G.detach()
+        out["generator"] = loss_G.detach() if torch.is_tensor(loss_G) else torch.zeros((), device=x_pred_t.device)
         out["x_pred"] = x_pred_t.detach()
         self.last = out
         return out

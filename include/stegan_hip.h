@@ -307,6 +307,11 @@ int stegan_add_layernorm_bwd(const float* dy, const float* xhat, const float* rs
  */
 int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64_t n, int32_t mode, float weight,
                              float* loss_slot, float* da, void* stream);
+/* n pairs in one launch (the feature-matching sum, train.py:257-262): weight * sum_i mean(|a_i - b_i|) (mode 0) or
+ * weight * sum_i mean((a_i - b_i)^2) (mode 1) is ADDED to *loss_slot and each da[i] (may be NULL) receives pair i's
+ * gradient; b == NULL or b[i] == NULL: the constant `target`. */
+int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel, float target,
+                           int32_t mode, float weight, float* loss_slot, float* const* da, void* stream);
 /* out = x * (*scalar_dev): chains an upstream 0-dim gradient into a stored unit gradient without a host sync. */
 int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
 /*

@@ -14,14 +14,14 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // mode 0: L1 |a-b|, mode 1: MSE (a-b)^2;  b == nullptr -> constant target
-__global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                        float target, long n, int mode, float w_over_n,
-                                                        float* __restrict__ loss_slot, float* __restrict__ da, int vec) {
+__device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, const float* __restrict__ b, float target, long n,
+                                               int mode, float w_over_n, float* __restrict__ loss_slot,
+                                               float* __restrict__ da, int vec, long bid, long nblocks) {
     __shared__ float red[4];
     float s = 0.f;
     // HBM-bound (read a, b; write da): 16 bytes per lane when the three arrays are 16-byte aligned
     const long n4 = vec ? (n >> 2) : 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = bid * 256 + threadIdx.x; i < n4; i += nblocks * 256) {
         const float4 av = reinterpret_cast<const float4*>(a)[i];
         float4 bv = make_float4(target, target, target, target);
         if (b) bv = reinterpret_cast<const float4*>(b)[i];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
         }
         if (da) reinterpret_cast<float4*>(da)[i] = make_float4(g[0], g[1], g[2], g[3]);
     }
-    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    for (long i = (n4 << 2) + bid * 256 + threadIdx.x; i < n; i += nblocks * 256) {
         const float d = a[i] - (b ? b[i] : target);
         if (mode == 0) {
             s += fabsf(d);
@@ -46,6 +46,35 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
     }
     s = block_sum_256(s, red);
     if (threadIdx.x == 0 && loss_slot) atomicAdd(loss_slot, s * w_over_n);
+}
+
+__global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float target, long n, int mode, float w_over_n,
+                                                        float* __restrict__ loss_slot, float* __restrict__ da, int vec) {
+    pair_loss_body(a, b, target, n, mode, w_over_n, loss_slot, da, vec, blockIdx.x, gridDim.x);
+}
+
+// Up to PL_MULTI pairs in ONE launch (the ~35 terms of the feature-matching sum, train.py:257-262: one after the other
+// their launches were 0.35 ms of a 12 ms step, each a few microseconds of work): pair i owns blocks first[i]..first[i+1].
+constexpr int PL_MULTI = 64;
+struct PairMulti {
+    int n, mode;
+    float target;
+    float* loss_slot;
+    int first[PL_MULTI + 1];
+    struct E { const float* a; const float* b; float* da; long n; float w_over_n; int vec; } e[PL_MULTI];
+};
+static_assert(sizeof(PairMulti) <= 4096, "kernel argument segment limit");
+
+__global__ __launch_bounds__(256) void pair_loss_multi_kernel(const PairMulti m) {
+    int lo = 0, hi = m.n - 1;                       // last i with first[i] <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (m.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PairMulti::E& e = m.e[lo];
+    pair_loss_body(e.a, e.b, m.target, e.n, m.mode, e.w_over_n, m.loss_slot, e.da, e.vec, (long)blockIdx.x - m.first[lo],
+                   (long)m.first[lo + 1] - m.first[lo]);
 }
 
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -295,6 +324,34 @@ extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float ta
     const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) % 16) == 0;
     hipLaunchKernelGGL(pair_loss_kernel, dim3(nblk(vec ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, target,
                        (long)n, mode, weight / (float)n, loss_slot, da, vec);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                      float target, int32_t mode, float weight, float* loss_slot, float* const* da,
+                                      void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && a && numel && loss_slot && (mode == 0 || mode == 1));
+    for (int base = 0; base < n; base += PL_MULTI) {
+        PairMulti m;
+        m.n = n - base < PL_MULTI ? n - base : PL_MULTI;
+        m.mode = mode; m.target = target; m.loss_slot = loss_slot;
+        int blocks = 0;
+        for (int i = 0; i < m.n; ++i) {
+            const int j = base + i;
+            STEGAN_CHECK_ARG(a[j] && numel[j] > 0);
+            PairMulti::E& e = m.e[i];
+            e.a = a[j]; e.b = b ? b[j] : nullptr; e.da = da ? da[j] : nullptr; e.n = numel[j];
+            e.w_over_n = weight / (float)numel[j];
+            e.vec = (((uintptr_t)e.a | (uintptr_t)e.b | (uintptr_t)e.da) % 16) == 0;
+            m.first[i] = blocks;
+            int nb = nblk(e.vec ? (e.n + 3) / 4 : e.n);
+            if (nb > 128) nb = 128;                   // the launch as a whole fills the chip; fewer atomics per pair
+            blocks += nb;
+        }
+        m.first[m.n] = blocks;
+        hipLaunchKernelGGL(pair_loss_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
+    }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

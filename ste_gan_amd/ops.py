@@ -837,6 +837,7 @@ class _MultiPairLossFn(torch.autograd.Function):
         loss = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
         grads, restores = [], []
         L = _lib.lib()
+        afs, bfs, das = [], [], []
         for i, (a, b) in enumerate(zip(a_list, b_list)):
             af, bf, restore = _memory_order_pair(a, b)
             af = _gpu_f32(af, "input")
@@ -845,14 +846,18 @@ class _MultiPairLossFn(torch.autograd.Function):
                 if bf.numel() != af.numel():
                     raise RuntimeError(f"The size of tensor a ({list(a.shape)}) must match the size of tensor b ({list(b.shape)})")
             da = torch.empty_like(af) if ctx.needs_input_grad[5 + i] else None
-            check(L.stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target or 0.0), af.numel(), mode, float(weight), _p(loss),
-                                             _p(da), _stream()), "stegan_pair_loss_fwd_bwd")
+            afs.append(af); bfs.append(bf); das.append(da); restores.append(restore)
+        # every pair in ONE launch (stegan_pair_loss_multi), all adding into the one loss word
+        check(L.stegan_pair_loss_multi(len(afs), _ptr_array(afs), _ptr_array(bfs), (C.c_int64 * len(afs))(*[t.numel() for t in afs]),
+                                       float(target or 0.0), mode, float(weight), _p(loss), _ptr_array(das), _stream()),
+              "stegan_pair_loss_multi")
+        for af, da in zip(afs, das):
             key = (af.data_ptr(), af.numel())
             if fold and da is not None and key in _FM_FOLDABLE and key not in _FM_PENDING:
                 _FM_PENDING[key] = da          # collected by the conv that produced a_i, inside its activation backward
                 _FM_COUNT[0] += 1
                 da = None
-            grads.append(da); restores.append(restore)
+            grads.append(da)
         ctx.restores, ctx.unit_grad, ctx.n_extra = restores, unit_grad, len(ts) - n
         ctx.save_for_backward(*[g for g in grads if g is not None])
         ctx.has = [g is not None for g in grads]

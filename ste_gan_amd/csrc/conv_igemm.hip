@@ -263,44 +263,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     }
 }
 
-// db[c] += sum_{b,t} dy[b,c,t] : grid (channel, batch slice).  The block's threads run over the flattened (b, t) pairs of
-// its slice -- 16 bytes per lane when rows are float4 aligned -- so short rows (T = 12) keep every lane busy (the first
-// version put the threads along t only: 12 of 256 lanes active, up to 119 us per call in the round-2 profile).
 __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db,
                                                         int B, int C, int T, int per, FastDiv fdT, int vec) {
-    const int c = blockIdx.x;
-    const int b0 = blockIdx.y * per, b1 = min(B, b0 + per);
-    float s = 0.f;
-    if (vec) {                                      // T % 4 == 0, aligned base: fdT divides by T / 4
-        const int T4 = T >> 2, n = (b1 - b0) * T4;
-        for (int r = threadIdx.x; r < n; r += 256) {
-            const int bi = (int)fd_div((uint32_t)r, fdT), t4 = r - bi * T4;
-            const float4 v = *reinterpret_cast<const float4*>(dy + ((size_t)(b0 + bi) * C + c) * T + 4 * t4);
-            s += (v.x + v.y) + (v.z + v.w);
-        }
-    } else {
-        const int n = (b1 - b0) * T;
-        for (int r = threadIdx.x; r < n; r += 256) {
-            const int bi = (int)fd_div((uint32_t)r, fdT), t = r - bi * T;
-            s += dy[((size_t)(b0 + bi) * C + c) * T + t];
-        }
-    }
-    __shared__ float part[4];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&db[c], part[0] + part[1] + part[2] + part[3]);
-}
-
-// batch slices per channel: enough blocks to fill the chip, each with >= 256 elements
-inline int bias_grad_slices(int B, int C, int T) {
-    int sl = 1024 / (C > 0 ? C : 1);
-    if (sl < 1) sl = 1;
-    const long per_ch = (long)B * T;
-    if (sl > per_ch / 256) sl = (int)(per_ch / 256);
-    if (sl < 1) sl = 1;
-    if (sl > B) sl = B;
-    return sl;
+    bias_grad_body(dy, db, B, C, T, per, fdT, vec, blockIdx.x, blockIdx.y);
 }
 
 inline void launch_bias_grad(const float* dy, float* db, int B, int C, int T, hipStream_t s) {

@@ -279,10 +279,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
 }
 
 // dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
+// The bias gradient rides in the same launch: blocks past the first `rb` are bias_grad_body (channel, batch slice) blocks
+// over the fp32 dy (one launch less per layer: 52 a step).
+struct BiasArgs { const float* dy; float* db; int B, C, T, per, slices, vec; FastDiv fdT; };
+
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                     long per_tap, int slices, int K, int k_lo, int K_eff) {
+                                                                     long per_tap, int slices, int K, int k_lo, int K_eff,
+                                                                     int rb, const BiasArgs ba) {
+    if ((int)blockIdx.x >= rb) {
+        const int j = (int)blockIdx.x - rb;                  // channel-major: the slices of a channel are neighbours
+        bias_grad_body(ba.dy, ba.db, ba.B, ba.C, ba.T, ba.per, ba.fdT, ba.vec, j / ba.slices, j % ba.slices);
+        return;
+    }
     const long total = per_tap * K_eff;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
         const int kk = (int)(i / per_tap);
         const long r = i - (long)kk * per_tap;             // co * Cin_g + ci
         const float* src = partial + i;
@@ -421,10 +431,16 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
         const long per_tap = (long)h.Cout * h.Cin_g;
         long rb = (per_tap * h.K_eff + 255) / 256;
         if (rb > 2048) rb = 2048;
-        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, h.partial, dw, per_tap, h.slices,
-                           d->K, h.k_lo, h.K_eff);
+        BiasArgs ba;
+        ba.dy = dy; ba.db = db; ba.B = d->B; ba.C = d->Cout; ba.T = d->Tout;
+        ba.slices = db ? bias_grad_slices(d->B, d->Cout, d->Tout) : 0;
+        ba.per = db ? ceil_div(d->B, ba.slices) : 1;
+        ba.slices = db ? ceil_div(d->B, ba.per) : 0;
+        ba.vec = (d->Tout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+        ba.fdT = make_fastdiv((uint32_t)(ba.vec ? d->Tout / 4 : d->Tout));
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)(rb + (long)ba.slices * d->Cout)), dim3(256), 0, s,
+                           h.partial, dw, per_tap, h.slices, d->K, h.k_lo, h.K_eff, (int)rb, ba);
     }
     STEGAN_LAUNCH_CHECK();
-    if (db) return stegan_bias_grad(dy, db, d->B, d->Cout, d->Tout, stream);
     return STEGAN_OK;
 }

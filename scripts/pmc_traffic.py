@@ -15,7 +15,7 @@ def per_kernel(d, counter):
                "conv_wgrad_bf16_kernel" if "conv_wgrad_bf16_kernel" in n else
                "conv_direct_kernel" if "conv_direct_kernel" in n else "conv_wgrad_kernel" if "conv_wgrad_kernel" in n else
                "conv_igemm_kernel<2>" if "conv_igemm_kernel<2" in n else "conv_splitk_epilogue_kernel" if "splitk_epilogue" in n
-               else "assemble_batch_kernel" if "assemble_batch" in n else None)
+               else "conv_cout1_kernels" if "conv_cout1" in n else "assemble_batch_kernel" if "assemble_batch" in n else None)
         if fam is None:
             continue
         agg[fam][0] += 1

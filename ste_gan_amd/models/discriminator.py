@@ -9,6 +9,7 @@ MPD feature maps are returned as (B,C,H,p) *views* of the period-folded (B*p,C,H
 from __future__ import annotations
 
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -69,15 +70,21 @@ class DiscriminatorSmallerP(_PeriodDisc):
 
 
 class _ScaleDisc(nn.Module):
-    def forward(self, x_bct):
+    def sn_prepare(self):
+        """This forward's spectral-norm state of every layer (``ops.spectral_norm_multi``: the power iterations depend on
+        the weights only, so they run ahead of the first conv, all layers in 4 launches; in training mode u / v advance,
+        exactly once per call), or None for a weight-norm discriminator / the per-layer path."""
+        if not (getattr(self, "norm", "weight_norm") == "spectral_norm" and ops.SN_BATCHED and len(self.layers) <= 8
+                and self.layers[0].weight_orig.is_cuda):
+            return None
+        keep = torch.is_grad_enabled() and any(l.weight_orig.requires_grad for l in self.layers)
+        return ops.spectral_norm_multi([(l.weight_orig, l.weight_u, l.weight_v) for l in self.layers], self.training, keep)
+
+    def forward(self, x_bct, pre=None):
         fmaps = []
         x = x_bct
-        pre = [None] * len(self.layers)
-        if (getattr(self, "norm", "weight_norm") == "spectral_norm" and ops.SN_BATCHED and x.is_cuda
-                and len(self.layers) <= 8):
-            # the power iterations of all layers, ahead of the first conv, in 4 launches (they depend on the weights only)
-            keep = torch.is_grad_enabled() and any(l.weight_orig.requires_grad for l in self.layers)
-            pre = ops.spectral_norm_multi([(l.weight_orig, l.weight_u, l.weight_v) for l in self.layers], self.training, keep)
+        if pre is None:
+            pre = self.sn_prepare() or [None] * len(self.layers)
         for layer, pr in zip(self.layers, pre):
             x = layer(x) if pr is None else layer(x, pr)
             fmaps.append(x)
@@ -141,7 +148,11 @@ class _MultiDisc(nn.Module):
         joined here; autograd runs their backward passes on the same two streams.  (Round 1 measured EIGHT streams with
         the fp32 kernels and rejected them, 31.3 vs 29.0 ms/step: those kernels fill the matrix pipes on their own.  The
         bf16 kernels are short, latency-bound launches that leave most of the chip idle.)"""
-        main, side = self._fork()
+        return self._forward(x, None, True)
+
+    def _forward(self, x, sn_pre, fork: bool):
+        self._prepare_weights()                # on the calling stream, BEFORE the fork: both branches read the copies
+        main, side = self._fork() if fork else (torch.cuda.current_stream(), None)
         if side is not None:
             with torch.cuda.stream(side):
                 results = self._pooled_forward(x)
@@ -149,12 +160,21 @@ class _MultiDisc(nn.Module):
             results = self._pooled_forward(x)
         xs = ops.btc_to_bct(x)
         scale = []
-        for disc in self.multi_scale_disc:
-            scale.append(disc(xs))
+        for i, disc in enumerate(self.multi_scale_disc):
+            scale.append(disc(xs, sn_pre[i] if sn_pre is not None else None))
             xs = ops.avgpool421(xs)            # the reference also pools once more after the last scale
         if side is not None:
             main.wait_stream(side)
         return results + scale
+
+    def _prepare_weights(self):
+        """Bring every conv's prepared weight copies up to date on the CURRENT stream (a no-op when they are): the
+        copies are made lazily by the first conv that needs them, which after a fork would be on one branch's stream
+        while the other branch reads them unordered."""
+        for m in self.modules():
+            prep = getattr(m, "prepared", None)
+            if prep is not None and m is not self:
+                prep()
 
     _side = None
 
@@ -194,6 +214,7 @@ class _MultiDisc(nn.Module):
         n = x_a.shape[0]
         both = torch.cat([x_a, x_b], 0)
         res_a, res_b = [], []
+        self._prepare_weights()
         main, side = self._fork()
         if side is not None:
             with torch.cuda.stream(side):

@@ -156,17 +156,21 @@ int stegan_conv1d_bwd_data_t(const stegan_conv_desc* d, const float* dy, const f
  * precision path through torch.autocast, ste_gan/train.py:181,204): identical semantics, descriptors, epilogues and
  * fp32 activations / accumulators, but the two operands of the contraction are rounded to bf16 while they are staged
  * (v_mfma_f32_32x32x16_bf16, 16x the fp32 matrix rate).  They read bf16 copies of the direction tensor written by
- * stegan_conv_prep_bf16 (every element including the padding is written: no zero-initialisation needed):
- *     wfh[g][k][co][ci]  rows padded to 128, ci to 64, k = 0..K with plane K all zero   (forward)
- *     wbh[g][k][ci][co]  rows padded to 128, co to 64, pre-multiplied by scale[co]      (input gradient)
+ * stegan_conv_prep_bf16 (only LIVE elements are written: the caller zero-fills both buffers ONCE when it allocates
+ * them; padding rows / channels and the extra tap plane then stay zero; K < 48):
+ *     wfh[g][k][ci / 8][co][8 ci]  co padded to 128, ci to 64, k = 0..K with plane K all zero   (forward)
+ *     wbh[g][k][co / 8][ci][8 co]  ci padded to 128, co to 64, pre-multiplied by scale[co]      (input gradient)
  * of stegan_conv_prep_bf16_elems(d, 0 | 1) uint16 elements.  Return 1 (nothing enqueued) for shapes left to the exact
- * fp32 kernels: fewer than 8 reduction channels or fewer than 16 output rows per group, more than 48 live taps,
+ * fp32 kernels: fewer than 8 reduction channels or fewer than 8 output rows per group, more than 48 live taps,
  * windows that do not fit LDS.  The *_multi form takes a device table of n
  *   struct { const float* v; const float* scale; uint16_t* wfh; uint16_t* wbh;
  *            int32 Cout_g, Cin_g, K, G, Mf, Cf, Mb, Cb; int64 nf, nb; }     (M* / C* the padded dims, n* the elements)
- * and runs blocks_per_entry blocks of 256 threads per entry (grid-stride).
+ * and runs blocks_per_entry blocks of 256 threads per entry (grid-stride over the entry's tiles,
+ * stegan_conv_prep_bf16_tiles).
  */
 int64_t stegan_conv_prep_bf16_elems(const stegan_conv_desc* d, int32_t which);
+/* work items (tiles) of the copy kernel for one conv: the grid of stegan_conv_prep_bf16_multi should cover the largest */
+int64_t stegan_conv_prep_bf16_tiles(const stegan_conv_desc* d);
 int stegan_conv_prep_bf16(const stegan_conv_desc* d, const float* v, const float* scale, uint16_t* wfh, uint16_t* wbh,
                           void* stream);
 int stegan_conv_prep_bf16_multi(int32_t n, const void* table_dev, int32_t blocks_per_entry, void* stream);

@@ -95,6 +95,7 @@ INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_multi_td_workspace_floats": [_I32, _I32],
                 "stegan_conv_prep_floats": [_D, _I32],
                 "stegan_conv_prep_bf16_elems": [_D, _I32],
+                "stegan_conv_prep_bf16_tiles": [_D],
                 "stegan_conv_workspace_floats": [_D, _I32]}
 
 _lib = None

@@ -529,45 +529,86 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
     return __builtin_bit_cast(unsigned short, (__bf16)f);
 }
 
-// layout [g][k][cb][m][8]: element e = (((g (K+1) + k) CB + cb) M + m) 8 + j, channel c = 8 cb + j
-__device__ __forceinline__ void prep_bf16_elems(const PrepH& t, long e0, long stride) {
-    const int K = t.K;
-    for (long e = e0; e < t.nf + t.nb; e += stride) {
-        if (e < t.nf) {
-            const int j = (int)(e & 7);
-            long r = e >> 3;
-            const int m = (int)(r % t.Mf); r /= t.Mf;
-            const int CBf = t.Cf >> 3;
-            const int c = (int)(r % CBf) * 8 + j; r /= CBf;
-            const int k = (int)(r % (K + 1)), g = (int)(r / (K + 1));
+// Tiled copy: a block reads ROWS output channels x CIT input channels x K taps of the (Cout, Cin_g, K) tensor -- ROWS
+// contiguous runs of CIT K floats -- into LDS once and emits the 16-byte pieces of BOTH layouts from there:
+//   wf[g][k][ci / 8][co][8 ci]   : piece (k, 8-channel block, co),  consecutive threads consecutive co  -> 1 KiB runs
+//   wb[g][k][co / 8][ci][8 co]   : piece (k, 8-row block, ci) x scale[co], consecutive threads consecutive ci
+// (element e = (((g (K+1) + k) CB + cb) M + m) 8 + j).  Every weight is read once and written twice; the first version
+// gathered element by element with a K-float stride, twice per weight: 146 us for the generator's 24 M weights.  The
+// buffers are zero-filled when they are allocated and only live elements are ever written: the zero tap plane k = K and
+// the padding rows / channels stay zero.
+constexpr int PREP_LDS_FLOATS = 12288;                         // 48 KiB
+__host__ __device__ inline int prep_cit(int K) {               // input channels per tile: CIT K <= ~192 floats per row
+    int c = (192 / K) & ~7;
+    return c < 8 ? 8 : (c > 64 ? 64 : c);
+}
+__host__ __device__ inline int prep_rows(int K) { return 64 * (prep_cit(K) * K + 1) <= PREP_LDS_FLOATS ? 64 : 32; }
+__host__ __device__ inline long prep_tiles(int G, int Cout_g, int Cin_g, int K) {
+    return (long)G * ((Cout_g + prep_rows(K) - 1) / prep_rows(K)) * ((Cin_g + prep_cit(K) - 1) / prep_cit(K));
+}
+
+__device__ __forceinline__ void prep_bf16_tiles(const PrepH& t, long tile0, long tstride) {
+    __shared__ float lds[PREP_LDS_FLOATS];
+    const int K = t.K, CIT = prep_cit(K), ROWS = prep_rows(K), P = CIT * K + 1;
+    if (ROWS * P > PREP_LDS_FLOATS) return;                    // K > 47: not produced by the host (fill_prep rejects it)
+    const int mt_n = (t.Cout_g + ROWS - 1) / ROWS, ct_n = (t.Cin_g + CIT - 1) / CIT;
+    const long ntiles = (long)t.G * mt_n * ct_n;
+    const int CBf = t.Cf >> 3, CBb = t.Cb >> 3;
+    for (long tile = tile0; tile < ntiles; tile += tstride) {
+        const int ct = (int)(tile % ct_n);
+        const int mt = (int)((tile / ct_n) % mt_n);
+        const int g = (int)(tile / ((long)ct_n * mt_n));
+        const int m0 = mt * ROWS, c0 = ct * CIT;
+        const int rows = min(ROWS, t.Cout_g - m0), cols = min(CIT, t.Cin_g - c0) * K;      // live part of the tile
+        __syncthreads();                                        // previous tile's readers are done
+        for (int idx = threadIdx.x; idx < ROWS * CIT * K; idx += 256) {
+            const int r = idx / (CIT * K), j = idx - r * (CIT * K);
             float v = 0.f;
-            if (k < K && m < t.Cout_g && c < t.Cin_g) v = t.v[((size_t)(g * t.Cout_g + m) * t.Cin_g + c) * K + k];
-            t.wf[e] = to_bf16(v);
-        } else {
-            const long eb = e - t.nf;
-            const int j = (int)(eb & 7);
-            long r = eb >> 3;
-            const int m = (int)(r % t.Mb); r /= t.Mb;
-            const int CBb = t.Cb >> 3;
-            const int c = (int)(r % CBb) * 8 + j; r /= CBb;
-            const int k = (int)(r % (K + 1)), g = (int)(r / (K + 1));
-            float v = 0.f;
-            if (k < K && m < t.Cin_g && c < t.Cout_g) {
-                const int co = g * t.Cout_g + c;
-                v = t.v[((size_t)co * t.Cin_g + m) * K + k] * (t.scale ? t.scale[co] : 1.f);
+            if (r < rows && j < cols) v = t.v[((size_t)(g * t.Cout_g + m0 + r) * t.Cin_g + c0) * K + j];
+            lds[r * P + j] = v;
+        }
+        __syncthreads();
+        // forward layout: pieces (k, cbl, r), r fastest
+        const int nwf = K * (CIT / 8) * ROWS;
+        for (int pi = threadIdx.x; pi < nwf; pi += 256) {
+            const int r = pi % ROWS, q = pi / ROWS, cbl = q % (CIT / 8), k = q / (CIT / 8);
+            if (r >= rows || cbl * 8 * K >= cols) continue;     // padding stays zero
+            const float* src = lds + r * P + cbl * 8 * K + k;
+            u32x4 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2)
+                o[h2] = (unsigned)to_bf16(src[(2 * h2) * K]) | ((unsigned)to_bf16(src[(2 * h2 + 1) * K]) << 16);
+            const size_t e = ((((size_t)g * (K + 1) + k) * CBf + (c0 >> 3) + cbl) * t.Mf + m0 + r) * 8;
+            *reinterpret_cast<u32x4*>(t.wf + e) = o;
+        }
+        // input-gradient layout: pieces (k, rb, cil), cil fastest; scale[co] folded in
+        const int nwb = K * (ROWS / 8) * CIT;
+        for (int pi = threadIdx.x; pi < nwb; pi += 256) {
+            const int cil = pi % CIT, q = pi / CIT, rb = q % (ROWS / 8), k = q / (ROWS / 8);
+            if (rb * 8 >= rows || cil * K >= cols) continue;
+            float f[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = rb * 8 + jj;
+                const float sc = (t.scale && r < rows) ? t.scale[g * t.Cout_g + m0 + r] : 1.f;
+                f[jj] = lds[r * P + cil * K + k] * sc;          // rows past the group hold zeros
             }
-            t.wb[eb] = to_bf16(v);
+            u32x4 o;
+#pragma unroll
+            for (int h2 = 0; h2 < 4; ++h2) o[h2] = (unsigned)to_bf16(f[2 * h2]) | ((unsigned)to_bf16(f[2 * h2 + 1]) << 16);
+            const size_t e = ((((size_t)g * (K + 1) + k) * CBb + (m0 >> 3) + rb) * t.Mb + c0 + cil) * 8;
+            *reinterpret_cast<u32x4*>(t.wb + e) = o;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void conv_prep_bf16_kernel(const PrepH t) {
-    prep_bf16_elems(t, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+    prep_bf16_tiles(t, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void conv_prep_bf16_multi_kernel(const PrepH* __restrict__ table) {
     const PrepH t = table[blockIdx.y];
-    prep_bf16_elems(t, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256);
+    prep_bf16_tiles(t, blockIdx.x, gridDim.x);
 }
 
 void fill_prep(PrepH& t, const stegan_conv_desc* d) {
@@ -854,13 +895,19 @@ extern "C" int64_t stegan_conv_prep_bf16_elems(const stegan_conv_desc* d, int32_
     return which == 0 ? t.nf : t.nb;
 }
 
+extern "C" int64_t stegan_conv_prep_bf16_tiles(const stegan_conv_desc* d) {
+    if (!d || d->groups <= 0 || d->K <= 0) return -1;
+    return prep_tiles(d->groups, d->Cout / d->groups, d->Cin / d->groups, d->K);
+}
+
 extern "C" int stegan_conv_prep_bf16(const stegan_conv_desc* d, const float* v, const float* scale, uint16_t* wf,
                                      uint16_t* wb, void* stream) {
     STEGAN_CHECK_ARG(d && v && wf && wb && d->groups > 0 && d->K > 0 && d->Cin % d->groups == 0 && d->Cout % d->groups == 0);
     PrepH t;
     fill_prep(t, d);
     t.v = v; t.scale = scale; t.wf = wf; t.wb = wb;
-    long blocks = (t.nf + t.nb + 255) / 256;
+    STEGAN_CHECK_ARG(prep_rows(t.K) * (prep_cit(t.K) * t.K + 1) <= PREP_LDS_FLOATS);
+    long blocks = prep_tiles(t.G, t.Cout_g, t.Cin_g, t.K);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(conv_prep_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, t);
     STEGAN_LAUNCH_CHECK();

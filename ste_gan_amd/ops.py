@@ -206,7 +206,8 @@ def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = 
     if COMPUTE_DTYPE == "bf16":
         for which, b in enumerate(bufs):
             if getattr(b, "h", None) is None:
-                b.h = torch.empty(int(L.stegan_conv_prep_bf16_elems(C.byref(d), which)), device=w3.device, dtype=torch.bfloat16)
+                # zeroed ONCE: the prep kernel writes live elements only (padding rows / channels / the zero tap plane stay 0)
+                b.h = torch.zeros(int(L.stegan_conv_prep_bf16_elems(C.byref(d), which)), device=w3.device, dtype=torch.bfloat16)
         check(L.stegan_conv_prep_bf16(C.byref(d), _p(w3), _p(scale), _p(bufs[0].h), _p(bufs[1].h), _stream()),
               "stegan_conv_prep_bf16")
     return bufs

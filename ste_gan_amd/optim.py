@@ -154,17 +154,19 @@ class ConvPack:
             _, sc, wf, wb, _ = c._pack
             d = ops._desc(c.cfg, 1, 1, 1)
             nf, nb = int(L.stegan_conv_prep_bf16_elems(C.byref(d), 0)), int(L.stegan_conv_prep_bf16_elems(C.byref(d), 1))
-            wf.h = torch.empty(nf, device=dev, dtype=torch.bfloat16)
-            wb.h = torch.empty(nb, device=dev, dtype=torch.bfloat16)
+            if c.cfg.k >= 48:
+                raise ValueError("ste_gan_amd: bf16 weight copies support kernel sizes < 48")
+            wf.h = torch.zeros(nf, device=dev, dtype=torch.bfloat16)     # zero ONCE: the prep kernel writes live elements only
+            wb.h = torch.zeros(nb, device=dev, dtype=torch.bfloat16)
             G = c.cfg.groups
             cog, cig, K = c.cfg.cout // G, c.cfg.cin // G, c.cfg.k
             up = lambda a, b: (a + b - 1) // b * b
             rows.append((c.weight_v.data_ptr(), sc.data_ptr(), wf.h.data_ptr(), wb.h.data_ptr(), cog, cig, K, G,
                          up(cog, 128), up(cig, 64), up(cig, 128), up(cog, 64), nf, nb))
-            most = max(most, nf + nb)
+            most = max(most, int(L.stegan_conv_prep_bf16_tiles(C.byref(d))))
         raw = b"".join(struct.pack("<4q8i2q", *r) for r in rows)
         self.t_prep_h = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
-        self.prep_h_blocks = max(1, min(2048, (most + 255) // 256))
+        self.prep_h_blocks = max(1, min(4096, most))              # tiles of the largest conv (grid-stride beyond that)
 
     def prepare(self):
         """Scales + transposed copies for the CURRENT weights (2 launches for the whole network; 3 in bf16 mode)."""

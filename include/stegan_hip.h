@@ -316,6 +316,12 @@ int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64
  * gradient; b == NULL or b[i] == NULL: the constant `target`. */
 int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel, float target,
                            int32_t mode, float weight, float* loss_slot, float* const* da, void* stream);
+/* the same with per-pair HOST arrays: weight[i]; constant targets (b NULL / b[i] NULL) target[i] for elements
+ * [0, split[i]) and target2[i] from split[i] on (split NULL or split[i] <= 0: one target) -- the discriminator step's
+ * batched fake | real logits against zeros | ones (train.py:192-196) without slicing the batch. */
+int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                              const float* weight, const float* target, const float* target2, const int64_t* split,
+                              int32_t mode, float* loss_slot, float* const* da, void* stream);
 /* out = x * (*scalar_dev): chains an upstream 0-dim gradient into a stored unit gradient without a host sync. */
 int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
 /*

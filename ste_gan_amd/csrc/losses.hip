@@ -2,6 +2,7 @@
 // gradient w.r.t. its input in the same pass -- the reductions are wavefront shuffles + one atomic
 // per block, nothing is re-read.  All fp32.
 #include "common.h"
+#include <vector>
 
 namespace {
 
@@ -14,16 +15,21 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // mode 0: L1 |a-b|, mode 1: MSE (a-b)^2;  b == nullptr -> constant target
+// b == nullptr: constant target -- `target` for elements [0, split), `target2` from `split` on (the discriminator step's
+// batched fake | real logits: zeros for the first half of the batch, ones for the second)
 __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, const float* __restrict__ b, float target, long n,
                                                int mode, float w_over_n, float* __restrict__ loss_slot,
-                                               float* __restrict__ da, int vec, long bid, long nblocks) {
+                                               float* __restrict__ da, int vec, long bid, long nblocks,
+                                               long split = (1l << 62), float target2 = 0.f) {
     __shared__ float red[4];
     float s = 0.f;
     // HBM-bound (read a, b; write da): 16 bytes per lane when the three arrays are 16-byte aligned
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = bid * 256 + threadIdx.x; i < n4; i += nblocks * 256) {
         const float4 av = reinterpret_cast<const float4*>(a)[i];
-        float4 bv = make_float4(target, target, target, target);
+        const long e0 = i << 2;
+        float4 bv = make_float4(e0 < split ? target : target2, e0 + 1 < split ? target : target2,
+                                e0 + 2 < split ? target : target2, e0 + 3 < split ? target : target2);
         if (b) bv = reinterpret_cast<const float4*>(b)[i];
         const float d[4] = {av.x - bv.x, av.y - bv.y, av.z - bv.z, av.w - bv.w};
         float g[4];
@@ -35,7 +41,7 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
         if (da) reinterpret_cast<float4*>(da)[i] = make_float4(g[0], g[1], g[2], g[3]);
     }
     for (long i = (n4 << 2) + bid * 256 + threadIdx.x; i < n; i += nblocks * 256) {
-        const float d = a[i] - (b ? b[i] : target);
+        const float d = a[i] - (b ? b[i] : (i < split ? target : target2));
         if (mode == 0) {
             s += fabsf(d);
             if (da) da[i] = d > 0.f ? w_over_n : (d < 0.f ? -w_over_n : 0.f);
@@ -59,10 +65,9 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
 constexpr int PL_MULTI = 64;
 struct PairMulti {
     int n, mode;
-    float target;
     float* loss_slot;
     int first[PL_MULTI + 1];
-    struct E { const float* a; const float* b; float* da; long n; float w_over_n; int vec; } e[PL_MULTI];
+    struct E { const float* a; const float* b; float* da; long n, split; float w_over_n, target, target2; int vec; } e[PL_MULTI];
 };
 static_assert(sizeof(PairMulti) <= 4096, "kernel argument segment limit");
 
@@ -73,8 +78,8 @@ __global__ __launch_bounds__(256) void pair_loss_multi_kernel(const PairMulti m)
         if (m.first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const PairMulti::E& e = m.e[lo];
-    pair_loss_body(e.a, e.b, m.target, e.n, m.mode, e.w_over_n, m.loss_slot, e.da, e.vec, (long)blockIdx.x - m.first[lo],
-                   (long)m.first[lo + 1] - m.first[lo]);
+    pair_loss_body(e.a, e.b, e.target, e.n, m.mode, e.w_over_n, m.loss_slot, e.da, e.vec, (long)blockIdx.x - m.first[lo],
+                   (long)m.first[lo + 1] - m.first[lo], e.split, e.target2);
 }
 
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -328,21 +333,25 @@ extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float ta
     return STEGAN_OK;
 }
 
-extern "C" int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
-                                      float target, int32_t mode, float weight, float* loss_slot, float* const* da,
-                                      void* stream) {
-    STEGAN_CHECK_ARG(n >= 1 && a && numel && loss_slot && (mode == 0 || mode == 1));
+extern "C" int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                         const float* weight, const float* target, const float* target2,
+                                         const int64_t* split, int32_t mode, float* loss_slot, float* const* da,
+                                         void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && a && numel && weight && loss_slot && (mode == 0 || mode == 1));
     for (int base = 0; base < n; base += PL_MULTI) {
         PairMulti m;
         m.n = n - base < PL_MULTI ? n - base : PL_MULTI;
-        m.mode = mode; m.target = target; m.loss_slot = loss_slot;
+        m.mode = mode; m.loss_slot = loss_slot;
         int blocks = 0;
         for (int i = 0; i < m.n; ++i) {
             const int j = base + i;
             STEGAN_CHECK_ARG(a[j] && numel[j] > 0);
             PairMulti::E& e = m.e[i];
             e.a = a[j]; e.b = b ? b[j] : nullptr; e.da = da ? da[j] : nullptr; e.n = numel[j];
-            e.w_over_n = weight / (float)numel[j];
+            e.w_over_n = weight[j] / (float)numel[j];
+            e.target = target ? target[j] : 0.f;
+            e.target2 = target2 ? target2[j] : e.target;
+            e.split = (split && split[j] > 0) ? split[j] : (1l << 62);
             e.vec = (((uintptr_t)e.a | (uintptr_t)e.b | (uintptr_t)e.da) % 16) == 0;
             m.first[i] = blocks;
             int nb = nblk(e.vec ? (e.n + 3) / 4 : e.n);
@@ -354,6 +363,14 @@ extern "C" int stegan_pair_loss_multi(int32_t n, const float* const* a, const fl
     }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                      float target, int32_t mode, float weight, float* loss_slot, float* const* da,
+                                      void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= 4096);
+    std::vector<float> w((size_t)n, weight), t((size_t)n, target);
+    return stegan_pair_loss_multi_ex(n, a, b, numel, w.data(), t.data(), nullptr, nullptr, mode, loss_slot, da, stream);
 }
 
 extern "C" int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream) {

@@ -211,9 +211,29 @@ class _MultiDisc(nn.Module):
         fuller grids on the short late layers).  The spectral-norm scale discriminator stays two calls in the
         reference's order: in training mode each of its forwards advances the power iteration, so its two halves see
         different sigma estimates."""
-        n = x_a.shape[0]
-        both = torch.cat([x_a, x_b], 0)
         res_a, res_b = [], []
+        for e in self._forward_pair(x_a, x_b, False):
+            if e[0] == "both":
+                n = e[2]
+                res_a.append([f[:n] for f in e[1]]); res_b.append([f[n:] for f in e[1]])
+            else:
+                res_a.append(e[1]); res_b.append(e[2])
+        return res_a, res_b
+
+    def forward_pair_logits(self, x_a, x_b):
+        """The logits of :meth:`forward_pair` without slicing the batch: one entry per sub-discriminator, ("both", logits
+        of the concatenated batch (first ``n`` rows: x_a), n) or, for the spectral-norm discriminator, ("pair", logits_a,
+        logits_b) -- the argument of ``losses.gan_losses.lsgan_pair_loss``."""
+        out = []
+        for e in self._forward_pair(x_a, x_b, True):
+            out.append(("both", e[1][-1], e[2]) if e[0] == "both" else ("pair", e[1][-1], e[2][-1]))
+        return out
+
+    def _forward_pair(self, x_a, x_b, logits_only: bool):
+        n = x_a.shape[0]
+        if x_b.shape[0] != n:
+            raise ValueError("forward_pair: the two batches must have the same size")
+        both = torch.cat([x_a, x_b], 0)
         self._prepare_weights()
         main, side = self._fork()
         if side is not None:
@@ -221,20 +241,18 @@ class _MultiDisc(nn.Module):
                 pooled = self._pooled_forward(both)
         else:
             pooled = self._pooled_forward(both)
-        for fm in pooled:
-            res_a.append([f[:n] for f in fm]); res_b.append([f[n:] for f in fm])
+        out = [("both", fm, n) for fm in pooled]
         xs = ops.btc_to_bct(both)
         for i, disc in enumerate(self.multi_scale_disc):
             if disc.norm == "spectral_norm":
-                res_a.append(disc(xs[:n])); res_b.append(disc(xs[n:]))      # batch-major: the halves are contiguous views
+                out.append(("pair", disc(xs[:n]), disc(xs[n:])))             # batch-major: the halves are contiguous views
             else:
-                fm = disc(xs)
-                res_a.append([f[:n] for f in fm]); res_b.append([f[n:] for f in fm])
+                out.append(("both", disc(xs), n))
             if i + 1 < len(self.multi_scale_disc):
                 xs = ops.avgpool421(xs)
         if side is not None:
             main.wait_stream(side)
-        return res_a, res_b
+        return out
 
 
 class DiscriminatorSmall(_MultiDisc):

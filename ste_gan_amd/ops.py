@@ -831,9 +831,12 @@ class _MultiPairLossFn(torch.autograd.Function):
     as they are instead of being multiplied by a device scalar that is known to be one."""
 
     @staticmethod
-    def forward(ctx, mode: int, weight: float, target, unit_grad: int, n: int, *ts):
+    def forward(ctx, mode: int, weight, target, unit_grad: int, n: int, *ts):
         fold = unit_grad == 2          # unit upstream gradient AND gradients parked for the producers (see _fm_announce)
         unit_grad = bool(unit_grad)
+        spec = None
+        if isinstance(weight, tuple):  # per-pair (weights, targets, targets2, splits): multi_pair_loss_const
+            spec, weight, target = weight, 0.0, 0.0
         a_list, b_list = ts[:n], (ts[n:] if target is None else (None,) * n)
         loss = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
         grads, restores = [], []
@@ -849,9 +852,17 @@ class _MultiPairLossFn(torch.autograd.Function):
             da = torch.empty_like(af) if ctx.needs_input_grad[5 + i] else None
             afs.append(af); bfs.append(bf); das.append(da); restores.append(restore)
         # every pair in ONE launch (stegan_pair_loss_multi), all adding into the one loss word
-        check(L.stegan_pair_loss_multi(len(afs), _ptr_array(afs), _ptr_array(bfs), (C.c_int64 * len(afs))(*[t.numel() for t in afs]),
-                                       float(target or 0.0), mode, float(weight), _p(loss), _ptr_array(das), _stream()),
-              "stegan_pair_loss_multi")
+        m = len(afs)
+        numel = (C.c_int64 * m)(*[t.numel() for t in afs])
+        if spec is None:
+            check(L.stegan_pair_loss_multi(m, _ptr_array(afs), _ptr_array(bfs), numel, float(target or 0.0), mode,
+                                           float(weight), _p(loss), _ptr_array(das), _stream()), "stegan_pair_loss_multi")
+        else:
+            ws_, t1, t2, sp = spec
+            fa = lambda xs: (C.c_float * m)(*[float(v) for v in xs])
+            check(L.stegan_pair_loss_multi_ex(m, _ptr_array(afs), None, numel, fa(ws_), fa(t1), fa(t2),
+                                              (C.c_int64 * m)(*[int(v) for v in sp]), mode, _p(loss), _ptr_array(das),
+                                              _stream()), "stegan_pair_loss_multi_ex")
         for af, da in zip(afs, das):
             key = (af.data_ptr(), af.numel())
             if fold and da is not None and key in _FM_FOLDABLE and key not in _FM_PENDING:
@@ -887,6 +898,18 @@ def multi_pair_loss(a_list, b_list, mode: int, weight: float = 1.0, target=None,
         raise ValueError("multi_pair_loss: fold requires unit_grad")
     return _MultiPairLossFn.apply(mode, float(weight), target, 2 if fold else int(bool(unit_grad)), len(a_list), *a_list,
                                   *extra)
+
+
+def multi_pair_loss_const(a_list, mode: int, weights, targets, targets2=None, splits=None, unit_grad: bool = False):
+    """sum_i weights[i] * mean over a_i of |a - t| (mode 0) or (a - t)^2 (mode 1) against CONSTANT targets in one launch:
+    t = targets[i] for the first splits[i] elements of a_i in memory order and targets2[i] for the rest (splits[i] = 0:
+    one target).  The discriminator step's batched fake | real logits meet zeros | ones this way without being sliced
+    (slicing costs autograd two zero-fills, two copies and an add per tensor on the way back)."""
+    a_list = list(a_list)
+    n = len(a_list)
+    spec = (tuple(weights), tuple(targets), tuple(targets2 if targets2 is not None else targets),
+            tuple(splits if splits is not None else [0] * n))
+    return _MultiPairLossFn.apply(mode, spec, 0.0, int(bool(unit_grad)), n, *a_list)
 
 
 def l1_loss(a, b):

@@ -47,7 +47,7 @@ from . import constants as K
 from . import ops
 from .constants import DataType
 from .losses.emg_encoder_loss import EMGEncoderLoss, EMGEncoderLossOutput
-from .losses.gan_losses import feature_matching_loss, lsgan_loss
+from .losses.gan_losses import lsgan_pair_loss, feature_matching_loss, lsgan_loss
 from .losses.time_domain_loss import MultiTimeDomainFeatureLoss
 from .models.discriminator import init_emg_discriminators
 from .models.emg_encoder import load_emg_encoder
@@ -163,9 +163,13 @@ class GANTrainStep:
         # ---- discriminator step (train.py:189-199)
         d_handle = None
         if t.loss_adversarial:
-            D_fake_det, D_real = netD.forward_pair(x_pred_t.detach(), x_t)          # train.py:190-191, batched
-            # both terms are plain summands of the scalar handed to backward(): unit upstream gradient (ops.multi_pair_loss)
-            loss_D = lsgan_loss(D_fake_det, 0.0, unit_grad=True) + lsgan_loss(D_real, 1.0, unit_grad=True)
+            if hasattr(netD, "forward_pair_logits"):
+                # train.py:190-196 on the concatenated batch: fake | real logits against zeros | ones, unsliced, one launch
+                loss_D = lsgan_pair_loss(netD.forward_pair_logits(x_pred_t.detach(), x_t), 0.0, 1.0, unit_grad=True)
+            else:
+                D_fake_det, D_real = netD(x_pred_t.detach()), netD(x_t)
+                # both terms are plain summands of the scalar handed to backward(): unit upstream gradient
+                loss_D = lsgan_loss(D_fake_det, 0.0, unit_grad=True) + lsgan_loss(D_real, 1.0, unit_grad=True)
             loss_D.backward()
             self.optD.finalize_grads()
             out["discriminator"] = loss_D.detach()

@@ -137,3 +137,48 @@ def test_folded_weights_unit_grad_path_vs_oracle():
         close(got, want, 2e-4, "dx_fake")
     else:
         assert flips <= 3 and np.linalg.norm(got - want) <= 1e-2 * np.linalg.norm(want), f"dx_fake (l2) with {flips} kink flips"
+
+
+def test_discriminator_loss_on_the_unsliced_batch():
+    """losses.gan_losses.lsgan_pair_loss over _MultiDisc.forward_pair_logits == the reference's sum of
+    mse(D(fake), 0) + mse(D(real), 1) over the sub-discriminators (train.py:192-196): value and weight gradients, for
+    logits kept as ONE tensor per stateless sub-discriminator (split constant targets) and as a pair for the spectral-norm
+    one; and ops.multi_pair_loss_const against plain torch on ragged sizes / odd splits."""
+    import torch.nn.functional as F
+    from ste_gan_amd import ops
+    from ste_gan_amd.losses.gan_losses import lsgan_loss, lsgan_pair_loss
+    from ste_gan_amd.models.discriminator import DiscriminatorSmall
+    gen = torch.Generator().manual_seed(5)
+    ts = [torch.randn(s, generator=gen).cuda().requires_grad_(True) for s in ((6, 1, 7), (4, 1, 3, 5), (10,), (2, 1, 1029))]
+    splits, t1, t2, ws = [21, 0, 3, 1029], [0.0, 1.0, 0.25, 0.0], [1.0, 1.0, -1.0, 1.0], [2.0, 1.0, 0.5, 2.0]
+    loss = ops.multi_pair_loss_const(ts, 1, ws, t1, t2, splits)
+    ref = 0
+    for t, sp, a, b, w in zip(ts, splits, t1, t2, ws):
+        tgt = torch.full((t.numel(),), a, device="cuda")
+        if sp > 0:
+            tgt[sp:] = b
+        ref = ref + w * F.mse_loss(t.reshape(-1).double(), tgt.double())
+    close(float(loss), float(ref), 1e-6, "split-target loss")
+    g = torch.autograd.grad(loss, ts)
+    g_ref = torch.autograd.grad(ref, ts)
+    for a, b in zip(g, g_ref):
+        close(a.cpu().numpy(), b.cpu().numpy(), 1e-5, "split-target gradient")
+
+    res = []
+    for unsliced in (True, False):
+        d = DiscriminatorSmall(8)
+        d.load_state_dict(fill_state_dict(oshapes.discriminator_shapes(True)))
+        d = d.cuda()
+        xa, xb = cases.disc_input("disc_small_t192").cuda(), cases.disc_input("disc_small_t192").cuda().flip(1) * 0.7
+        if unsliced:
+            loss_d = lsgan_pair_loss(d.forward_pair_logits(xa, xb), 0.0, 1.0)
+        else:
+            fa, fb = d.forward_pair(xa, xb)
+            loss_d = lsgan_loss(fa, 0.0) + lsgan_loss(fb, 1.0)
+        loss_d.backward()
+        res.append((float(loss_d), [p.grad.clone() for p in d.parameters()], [b.clone() for b in d.buffers()]))
+    close(res[0][0], res[1][0], 1e-6, "loss_D")
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.equal(a, b)

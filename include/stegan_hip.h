@@ -258,6 +258,10 @@ int stegan_spectral_norm_fwd_multi(int32_t n, const float* const* w_orig, float*
 int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
                              const float* sigma, float* workspace, float* dw_orig, int32_t rows, int32_t cols,
                              void* stream);
+/* accumulate != 0: dw_orig += ... (the parameter's gradient arena view: no autograd accumulation kernel afterwards) */
+int stegan_spectral_norm_bwd_acc(const float* w_orig, const float* dw, const float* u, const float* v,
+                                 const float* sigma, float* workspace, float* dw_orig, int32_t rows, int32_t cols,
+                                 int32_t accumulate, void* stream);
 
 /* ---- discriminator input plumbing ---------------------------------------------------------- */
 /*

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw, const float* __restrict__ rowdot,
                                                            const float* __restrict__ u, const float* __restrict__ v,
                                                            const float* __restrict__ sigma, float* __restrict__ dW,
-                                                           int R, int Cn) {
+                                                           int R, int Cn, int accumulate) {
     __shared__ float tot;
     if (threadIdx.x < 64) {            // every block re-reduces the R row dots (R <= 1024): deterministic, no atomics
         float a = 0.f;
@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
     const long total = (long)R * Cn;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int j = (int)(i % Cn), r = (int)(i / Cn);
-        dW[i] = dw[i] * inv - k * u[r] * v[j];
+        const float gv = dw[i] * inv - k * u[r] * v[j];
+        dW[i] = accumulate ? dW[i] + gv : gv;               // accumulate: straight into the parameter's .grad arena view
     }
 }
 
@@ -386,14 +387,20 @@ extern "C" int stegan_spectral_norm_fwd_multi(int32_t n, const float* const* w_o
     return STEGAN_OK;
 }
 
-extern "C" int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
-                                        const float* sigma, float* workspace, float* dw_orig, int32_t rows,
-                                        int32_t cols, void* stream) {
+extern "C" int stegan_spectral_norm_bwd_acc(const float* w_orig, const float* dw, const float* u, const float* v,
+                                            const float* sigma, float* workspace, float* dw_orig, int32_t rows,
+                                            int32_t cols, int32_t accumulate, void* stream) {
     STEGAN_CHECK_ARG(w_orig && dw && u && v && sigma && workspace && dw_orig && rows > 0 && cols > 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w_orig, dw, workspace, rows, cols);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nblocks((long)rows * cols)), dim3(256), 0, s, dw, workspace, u, v, sigma,
-                       dw_orig, rows, cols);
+                       dw_orig, rows, cols, accumulate);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
+                                        const float* sigma, float* workspace, float* dw_orig, int32_t rows,
+                                        int32_t cols, void* stream) {
+    return stegan_spectral_norm_bwd_acc(w_orig, dw, u, v, sigma, workspace, dw_orig, rows, cols, 0, stream);
 }

@@ -144,6 +144,7 @@ class SNConv1d(nn.Module):
         self.register_buffer("weight_u", nn.functional.normalize(torch.randn(out_channels), dim=0, eps=1e-12))
         self.register_buffer("weight_v", nn.functional.normalize(torch.randn(w[0].numel()), dim=0, eps=1e-12))
         self._prep = None
+        self.grad_sink = False      # set by optim.FlatParams: .grad tensors are persistent, zeroed arena views
 
     def prepared(self):
         w = self.weight_orig
@@ -156,8 +157,12 @@ class SNConv1d(nn.Module):
     def forward(self, x, pre=None):
         """``pre``: this forward's spectral-norm state from :func:`ops.spectral_norm_multi` (all layers of the
         discriminator in one call); None: the layer runs its own power iteration."""
-        return ops.sn_conv1d(x, self.weight_orig, self.weight_u, self.weight_v, self.bias, self.cfg, self.training,
-                             self.prepared(), pre)
+        sink = None
+        w, b = self.weight_orig, self.bias
+        if (self.grad_sink and torch.is_grad_enabled() and w.requires_grad and b.requires_grad and w.grad is not None
+                and b.grad is not None and w.grad.is_contiguous() and w.grad.is_cuda):
+            sink = (w.grad, b.grad)              # FlatParams arena views (optim.FlatParams sets ``grad_sink``)
+        return ops.sn_conv1d(x, w, self.weight_u, self.weight_v, b, self.cfg, self.training, self.prepared(), pre, sink)
 
 
 def NormedConv1d(*args, **kwargs):

@@ -594,7 +594,10 @@ class _SNConvFn(torch.autograd.Function):
     """y = out_act( (w_orig (*) x) / sigma + bias ), sigma = u^T W v after one in-place power iteration."""
 
     @staticmethod
-    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None):
+    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None):
+        """``sink`` = (weight_orig.grad, bias.grad) arena views: the backward pass accumulates into them directly and
+        returns no parameter gradients (as the ConvPack sink of the weight-norm convs does)."""
+        ctx.sink = sink
         wf, wb = prepared if prepared is not None else (None, None)
         need_w = ctx.needs_input_grad[1]
         if pre is not None:
@@ -635,20 +638,23 @@ class _SNConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
+            sink = ctx.sink
             dw = torch.zeros_like(w_orig)
-            db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32)
+            db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32) if sink is None else sink[1]
             conv1d_bwd_weight(x, dy, cfg, dw, db)
             rows = w_orig.shape[0]
             ws = torch.empty(rows, device=dy.device, dtype=torch.float32)
-            dw_orig = torch.empty_like(w_orig)
-            check(_lib.lib().stegan_spectral_norm_bwd(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
-                                                      rows, w_orig.numel() // rows, _stream()),
-                  "stegan_spectral_norm_bwd")
-        return dx, dw_orig, None, None, db, None, None, None, None
+            dw_orig = torch.empty_like(w_orig) if sink is None else sink[0]
+            check(_lib.lib().stegan_spectral_norm_bwd_acc(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
+                                                          rows, w_orig.numel() // rows, 0 if sink is None else 1, _stream()),
+                  "stegan_spectral_norm_bwd_acc")
+            if sink is not None:
+                dw_orig = db = None              # already in the gradient arena
+        return dx, dw_orig, None, None, db, None, None, None, None, None
 
 
-def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None) -> Tensor:
-    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre)
+def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None) -> Tensor:
+    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre, sink)
 
 
 SKINNY = os.environ.get("STEGAN_SKINNY", "1") != "0"   # Cout == 1 convs on the streaming kernels of conv_skinny.hip

@@ -46,6 +46,9 @@ class FlatParams:
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
         self.numel = total
+        for m in module.modules():             # spectral-norm convs may accumulate straight into these views
+            if hasattr(m, "grad_sink"):
+                m.grad_sink = True
 
     def zero_grad(self):
         self.grad.zero_()

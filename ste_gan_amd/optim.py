@@ -196,6 +196,8 @@ class ConvPack:
 
     def finalize_grads(self):
         """raw dw -> (dv, dg) for every conv, written into the .grad views (1 launch)."""
+        from . import ops
+        ops.wgrad_join()                       # weight gradients launched on a side stream (ops._wgrad_sink)
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: C.c_void_p(t.data_ptr())
         check(_lib.lib().stegan_wn_backward(self.n, P(self.t_v), P(self.t_g), P(self.t_dw), P(self.t_dv), P(self.t_dg),

@@ -211,7 +211,11 @@ class GANTrainStep:
             if g_side is not None:
                 roots.append(x_pred_t); grads.append(g_side)
             if roots:
-                torch.autograd.backward(roots, grads)
+                _ops.wgrad_async(True)         # generator backward: weight gradients beside the input-gradient chain
+                try:
+                    torch.autograd.backward(roots, grads)
+                finally:
+                    _ops.wgrad_async(False)
             loss_G = (loss_main.detach() if loss_main is not None else 0) + (loss_side if loss_side is not None else 0)
             if fold:
                 _ops.fm_fold_end()       # raises if a parked gradient was not collected

@@ -84,3 +84,28 @@ def test_multi_problem_launch_matches_single_launches(bf16_mode):
         y1.backward(gy)
         torch.testing.assert_close(y1, y, rtol=1e-5, atol=1e-5)
         torch.testing.assert_close(x.grad, dx, rtol=1e-5, atol=1e-5 * float(dx.abs().max()))
+
+
+def test_generator_weight_gradients_on_side_streams_equal_inline(bf16_mode):
+    """ops._wgrad_sink: during the generator's backward pass the weight-gradient launches of the sink (ConvPack) mode run on
+    side streams beside the chain of input gradients and are joined in finalize_grads -- same gradients and parameters as
+    running them inline (one step: later steps diverge chaotically from the fp32-atomics noise alone)."""
+    name = next(iter(cases.STEP_CASES))
+    res = []
+    for streams in (4, 0):
+        old = bf16_mode.WGRAD_STREAMS
+        bf16_mode.WGRAD_STREAMS = streams
+        try:
+            cfg, netG, netD, optG, optD, step = build(name)
+            out = step(to_batch(cases.step_batch(name, 0)))
+            torch.cuda.synchronize()
+            assert not bf16_mode._WG_KEEP                       # joined: operands released
+            res.append(([p.grad.clone() for p in netG.parameters()], [p.detach().clone() for p in netG.parameters()],
+                        float(out["generator"])))
+        finally:
+            bf16_mode.WGRAD_STREAMS = old
+    for a, b in zip(res[0][0], res[1][0]):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
+    assert abs(res[0][2] - res[1][2]) <= 1e-6 * abs(res[1][2])

@@ -158,14 +158,19 @@ class _MultiDisc(nn.Module):
                 results = self._pooled_forward(x)
         else:
             results = self._pooled_forward(x)
-        xs = ops.btc_to_bct(x)
-        scale = []
-        for i, disc in enumerate(self.multi_scale_disc):
-            scale.append(disc(xs, sn_pre[i] if sn_pre is not None else None))
-            xs = ops.avgpool421(xs)            # the reference also pools once more after the last scale
+        xs = self._scale_inputs(ops.btc_to_bct(x))
+        scale = [disc(xs[i], sn_pre[i] if sn_pre is not None else None) for i, disc in enumerate(self.multi_scale_disc)]
         if side is not None:
             main.wait_stream(side)
         return results + scale
+
+    def _scale_inputs(self, xs):
+        """Inputs of the scale discriminators: x, pool(x), pool(pool(x)) (discriminator.py:150-154; the reference pools once
+        more after the last scale and discards the result)."""
+        out = [xs]
+        for _ in range(len(self.multi_scale_disc) - 1):
+            out.append(ops.avgpool421(out[-1]))
+        return out
 
     def _prepare_weights(self):
         """Bring every conv's prepared weight copies up to date on the CURRENT stream (a no-op when they are): the
@@ -180,8 +185,8 @@ class _MultiDisc(nn.Module):
 
     def _fork(self):
         """(current stream, side stream that waits for it), or (current, None): fp32 compute mode (measured: 21.9 vs 21.5
-        ms/step with the two streams, 13.6 vs 13.8 in bf16 mode) or STEGAN_D_STREAMS=0."""
-        import os
+        ms/step with the two streams, 13.6 vs 13.8 in bf16 mode) or STEGAN_D_STREAMS=0.  (A third stream for the
+        weight-norm scale discriminators: 9.97 vs 9.24 ms/step -- with the encoder branch that makes four.)"""
         main = torch.cuda.current_stream()
         if not ops.bf16_enabled() or os.environ.get("STEGAN_D_STREAMS", "1") == "0":
             return main, None
@@ -242,14 +247,12 @@ class _MultiDisc(nn.Module):
         else:
             pooled = self._pooled_forward(both)
         out = [("both", fm, n) for fm in pooled]
-        xs = ops.btc_to_bct(both)
+        xs = self._scale_inputs(ops.btc_to_bct(both))
         for i, disc in enumerate(self.multi_scale_disc):
             if disc.norm == "spectral_norm":
-                out.append(("pair", disc(xs[:n]), disc(xs[n:])))             # batch-major: the halves are contiguous views
+                out.append(("pair", disc(xs[i][:n]), disc(xs[i][n:])))      # batch-major: the halves are contiguous views
             else:
-                out.append(("both", disc(xs), n))
-            if i + 1 < len(self.multi_scale_disc):
-                xs = ops.avgpool421(xs)
+                out.append(("both", disc(xs[i]), n))
         if side is not None:
             main.wait_stream(side)
         return out

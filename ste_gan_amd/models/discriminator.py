@@ -152,17 +152,27 @@ class _MultiDisc(nn.Module):
 
     def _forward(self, x, sn_pre, fork: bool):
         self._prepare_weights()                # on the calling stream, BEFORE the fork: both branches read the copies
+        xs = self._scale_inputs(ops.btc_to_bct(x))                 # before the fork: both streams read them
         main, side = self._fork() if fork else (torch.cuda.current_stream(), None)
+        n_side = self._scales_on_side() if side is not None else 0
+        scale = [None] * len(self.multi_scale_disc)
+        run = lambda i: self.multi_scale_disc[i](xs[i], sn_pre[i] if sn_pre is not None else None)
         if side is not None:
             with torch.cuda.stream(side):
                 results = self._pooled_forward(x)
+                for i in range(len(scale) - n_side, len(scale)):       # balance: the period branch is the shorter one
+                    scale[i] = run(i)
         else:
             results = self._pooled_forward(x)
-        xs = self._scale_inputs(ops.btc_to_bct(x))
-        scale = [disc(xs[i], sn_pre[i] if sn_pre is not None else None) for i, disc in enumerate(self.multi_scale_disc)]
+        for i in range(len(scale) - n_side):
+            scale[i] = run(i)
         if side is not None:
             main.wait_stream(side)
         return results + scale
+
+    def _scales_on_side(self):
+        """How many of the LAST scale discriminators run on the period branch's stream (STEGAN_D_SIDE_SCALES)."""
+        return max(0, min(len(self.multi_scale_disc) - 1, int(os.environ.get("STEGAN_D_SIDE_SCALES", "1"))))
 
     def _scale_inputs(self, xs):
         """Inputs of the scale discriminators: x, pool(x), pool(pool(x)) (discriminator.py:150-154; the reference pools once
@@ -240,22 +250,30 @@ class _MultiDisc(nn.Module):
             raise ValueError("forward_pair: the two batches must have the same size")
         both = torch.cat([x_a, x_b], 0)
         self._prepare_weights()
+        xs = self._scale_inputs(ops.btc_to_bct(both))
         main, side = self._fork()
+        n_side = self._scales_on_side() if side is not None else 0
+        ns = len(self.multi_scale_disc)
+        scale = [None] * ns
+
+        def run(i):
+            disc = self.multi_scale_disc[i]
+            if disc.norm == "spectral_norm":
+                return ("pair", disc(xs[i][:n]), disc(xs[i][n:]))          # batch-major: the halves are contiguous views
+            return ("both", disc(xs[i]), n)
+
         if side is not None:
             with torch.cuda.stream(side):
                 pooled = self._pooled_forward(both)
+                for i in range(ns - n_side, ns):
+                    scale[i] = run(i)
         else:
             pooled = self._pooled_forward(both)
-        out = [("both", fm, n) for fm in pooled]
-        xs = self._scale_inputs(ops.btc_to_bct(both))
-        for i, disc in enumerate(self.multi_scale_disc):
-            if disc.norm == "spectral_norm":
-                out.append(("pair", disc(xs[i][:n]), disc(xs[i][n:])))      # batch-major: the halves are contiguous views
-            else:
-                out.append(("both", disc(xs[i]), n))
+        for i in range(ns - n_side):
+            scale[i] = run(i)
         if side is not None:
             main.wait_stream(side)
-        return out
+        return [("both", fm, n) for fm in pooled] + scale
 
 
 class DiscriminatorSmall(_MultiDisc):

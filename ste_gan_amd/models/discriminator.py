@@ -194,11 +194,12 @@ class _MultiDisc(nn.Module):
     _side = None
 
     def _fork(self):
-        """(current stream, side stream that waits for it), or (current, None): fp32 compute mode (measured: 21.9 vs 21.5
-        ms/step with the two streams, 13.6 vs 13.8 in bf16 mode) or STEGAN_D_STREAMS=0.  (A third stream for the
+        """(current stream, side stream that waits for it), or (current, None) with STEGAN_D_STREAMS=0.  (In fp32 mode the
+        fork lost at first, 21.9 vs 21.5 ms/step; together with the rebalanced branches and the generator's weight-gradient
+        streams it wins, 17.1 vs 19.2.)  (A third stream for the
         weight-norm scale discriminators: 9.97 vs 9.24 ms/step -- with the encoder branch that makes four.)"""
         main = torch.cuda.current_stream()
-        if not ops.bf16_enabled() or os.environ.get("STEGAN_D_STREAMS", "1") == "0":
+        if not (ops.bf16_enabled() or ops.F32_STREAMS) or os.environ.get("STEGAN_D_STREAMS", "1") == "0":
             return main, None
         if _MultiDisc._side is None:
             _MultiDisc._side = torch.cuda.Stream()

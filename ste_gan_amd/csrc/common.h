@@ -51,6 +51,18 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Block barrier used by every kernel of this library instead of a bare __syncthreads().  hipcc lowers __syncthreads() on
+// gfx950 to "s_waitcnt vmcnt(0); s_barrier" -- it does NOT wait for the issuing wave's outstanding LDS stores (lgkmcnt),
+// on the memory-model assumption that the LDS of a CU performs its operations in order.  That does not hold across SIMDs
+// with another kernel's waves co-resident on the CU: a consumer wave's first ds_read after the barrier was observed to
+// overtake the producer wave's last ds_write_b128 before it (scripts/concurrency_stress.py: 2-10 % of bf16 conv launches
+// wrong in one lane class of one wave tile whenever a second stream was busy; never when the kernel ran alone -- which is
+// why every single-stream parity test passed).  The explicit lgkmcnt(0) closes it.
+__device__ __forceinline__ void block_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // wave64 sum
 __device__ static inline float wave_sum(float v) {
 #pragma unroll
@@ -83,7 +95,7 @@ __device__ static inline void bias_grad_body(const float* __restrict__ dy, float
     __shared__ float bias_part[4];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) bias_part[threadIdx.x >> 6] = s;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) atomicAdd(&db[c], bias_part[0] + bias_part[1] + bias_part[2] + bias_part[3]);
 }
 

@@ -270,7 +270,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         }
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
-            __syncthreads();                // all 8 waves: chunk c is staged; nobody reads buffer cur ^ 1 any more
+            block_sync();                // all 8 waves: chunk c is staged; nobody reads buffer cur ^ 1 any more
             if (c + 1 < c_end) {
                 HB_LOAD_X(c + 1, xAr, xAv)
                 HB_DMA_W(c + 1, cur ^ 1)
@@ -345,7 +345,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     HSTAMP(2)
 #endif
     for (int c = c_begin; c < c_end; ++c) {
-        __syncthreads();
+        block_sync();
 #ifdef STEGAN_STAMPS_ITER                   // diagnostic: tops of iterations 1, 5, 9, 13, 17, 21 in stamps 1..6
         if (c == c_begin + 1) { HSTAMP(1) }
         if (c == c_begin + 5) { HSTAMP(2) }
@@ -560,14 +560,14 @@ __device__ __forceinline__ void prep_bf16_tiles(const PrepH& t, long tile0, long
         const int g = (int)(tile / ((long)ct_n * mt_n));
         const int m0 = mt * ROWS, c0 = ct * CIT;
         const int rows = min(ROWS, t.Cout_g - m0), cols = min(CIT, t.Cin_g - c0) * K;      // live part of the tile
-        __syncthreads();                                        // previous tile's readers are done
+        block_sync();                                        // previous tile's readers are done
         for (int idx = threadIdx.x; idx < ROWS * CIT * K; idx += 256) {
             const int r = idx / (CIT * K), j = idx - r * (CIT * K);
             float v = 0.f;
             if (r < rows && j < cols) v = t.v[((size_t)(g * t.Cout_g + m0 + r) * t.Cin_g + c0) * K + j];
             lds[r * P + j] = v;
         }
-        __syncthreads();
+        block_sync();
         // forward layout: pieces (k, cbl, r), r fastest
         const int nwf = K * (CIT / 8) * ROWS;
         for (int pi = threadIdx.x; pi < nwf; pi += 256) {

@@ -245,7 +245,7 @@ __device__ __forceinline__ void conv_direct_body(const DirP& p, const unsigned b
 #ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(3) }
 #endif
-        __syncthreads();        // hipcc drains vmcnt(0) here: this wave's DMA of chunk c has landed, and after the
+        block_sync();        // hipcc drains vmcnt(0) here: this wave's DMA of chunk c has landed, and after the
                                 // barrier so has everyone's; nobody still reads buffer cur ^ 1
 #ifndef STEGAN_STAMPS_PROLOGUE
         if (c == c_begin + 3) { STAMP(4) }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_prep_kernel(const float* __restrict_
         const int co = co0 + r, e = e0 + tx;
         t[r][tx] = (co < Cout_g && e < E) ? v[((size_t)(g * Cout_g + co)) * E + e] : 0.f;
     }
-    __syncthreads();
+    block_sync();
     for (int r = ty; r < 32; r += 8) {
         // Wf: row = e index r, column = co tx
         const int e = e0 + r, co = co0 + tx;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void conv_prep_multi_kernel(const PrepEntry* _
         const int co = co0 + r, e = e0 + tx;
         t[r][tx] = (co < t0.Cout_g && e < E) ? t0.v[((size_t)(g * t0.Cout_g + co)) * E + e] : 0.f;
     }
-    __syncthreads();
+    block_sync();
     for (int r = ty; r < 32; r += 8) {
         const int e = e0 + r, co = co0 + tx;
         if (e < E && co < t0.Cout_g) {

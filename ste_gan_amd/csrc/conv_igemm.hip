@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     load_chunk(chunk_lo * KC);
     for (int c = chunk_lo; c < chunk_hi; ++c) {
         store_chunk();
-        __syncthreads();
+        block_sync();
         if (do_bias) {
 #pragma unroll 8
             for (int r = 0; r < KC; ++r) bsum += As[r * LDA + tid];
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
+        block_sync();
     }
 
     if (do_bias && m0 + tid < p.M) atomicAdd(&p.db[g * p.Cout_g + m0 + tid], bsum);

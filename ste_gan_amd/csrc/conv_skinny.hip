@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const SkP p) {
         }
     }
     red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    __syncthreads();
+    block_sync();
     if (cl == 0 && t < p.Tout) {
         float s = 0.f;
         for (int j = 0; j < p.CL; ++j) s += red[j * p.TT + tl];       // fixed order: deterministic
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
     }
 #pragma unroll
     for (int k = 0; k < SK_KMAX; ++k) red[k][tid] = acc[k];
-    __syncthreads();
+    block_sync();
     // thread (k, channel lane): sum of the channel's TT steps
     if (tid < p.CL * p.K) {
         const int k = (int)fd_div((uint32_t)tid, p.fdCL), cj = tid - k * p.CL;

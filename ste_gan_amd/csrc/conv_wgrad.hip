@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 
     WG_LOAD(0)
     WG_STORE(0)
-    __syncthreads();
+    block_sync();
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
 #ifndef WG_EXP_NOSTAGE
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #ifndef WG_EXP_NOSTAGE
         if (c + 1 < nchunks) WG_STORE(cur ^ 1)
 #endif
-        __syncthreads();
+        block_sync();
     }
 #undef WG_LOAD
 #undef WG_STORE
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             for (int e = 0; e < 16; ++e)
                 out_s[(wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * OP + k * 32 + l31] = acc[k][e];
     }
-    __syncthreads();
+    block_sync();
     if (wn == 0) {
 #pragma unroll
         for (int k = 0; k < KT; ++k)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
                 *o += acc[k][e];
             }
     }
-    __syncthreads();
+    block_sync();
     const int run = 32 * ktaps;                           // floats per output row of this block
     const uint32_t inv = (65536u + ktaps - 1) / ktaps;    // j / ktaps == (j * inv) >> 16 for j < 256, ktaps <= 8
     float* dst = p.partial ? p.partial + (size_t)blockIdx.z * p.dw_numel : p.dw;

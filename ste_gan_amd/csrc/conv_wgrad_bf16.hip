@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
     }
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
-        __syncthreads();
+        block_sync();
         const bool more = c + 1 < nchunks;
         if (more) WG_LOAD(c + 1, adj_nxt)
         const char* Acur = smem + cur * bufsz;

@@ -127,13 +127,13 @@ __device__ __forceinline__ void sn_vnorm_body(const float* __restrict__ partial,
     }
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
         float a = 0.f;
         for (int k = 0; k < 16; ++k) a += red[k];
         inv = 1.f / fmaxf(sqrtf(a), eps);
     }
-    __syncthreads();
+    block_sync();
     for (int j = threadIdx.x; j < Cn; j += 1024) {
         const float t = v[j] * inv;
         v[j] = t;
@@ -174,13 +174,13 @@ __device__ __forceinline__ void sn_finish_body(const float* __restrict__ s, floa
     for (int i = threadIdx.x; i < R; i += 1024) ss += s[i] * s[i];
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
         float a = 0.f;
         for (int k = 0; k < 16; ++k) a += red[k];
         bc = 1.f / fmaxf(sqrtf(a), eps);
     }
-    __syncthreads();
+    block_sync();
     float dot = 0.f;
     for (int i = threadIdx.x; i < R; i += 1024) {
         float ui = update_u ? s[i] * bc : u[i];
@@ -189,16 +189,16 @@ __device__ __forceinline__ void sn_finish_body(const float* __restrict__ s, floa
         dot += ui * s[i];
     }
     dot = wave_sum(dot);
-    __syncthreads();
+    block_sync();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
-    __syncthreads();
+    block_sync();
     if (threadIdx.x == 0) {
         float a = 0.f;
         for (int k = 0; k < 16; ++k) a += red[k];
         bc = a;
         *sigma_out = a;
     }
-    __syncthreads();
+    block_sync();
     const float inv_sigma = 1.f / bc;
     for (int i = threadIdx.x; i < R; i += 1024) scale[i] = inv_sigma;
 }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
         a = wave_sum(a);
         if (threadIdx.x == 0) tot = a;
     }
-    __syncthreads();
+    block_sync();
     const float sg = *sigma;
     const float k = tot / (sg * sg), inv = 1.f / sg;
     const long total = (long)R * Cn;

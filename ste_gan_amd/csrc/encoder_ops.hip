@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
         Pb[ij] = s;
     }
-    __syncthreads();
+    block_sync();
     // phase 2: row softmax, one wave per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = wave; i < T; i += 4) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         const float inv = 1.f / se;
         for (int j = lane; j < T; j += 64) Pb[i * T + j] *= inv;
     }
-    __syncthreads();
+    block_sync();
     // phase 3: O[a][i] = sum_j P[i][j] v[a][j]
     float* Ob = O + ((size_t)b * Cm + h * A) * T;
     for (int ai = threadIdx.x; ai < A * T; ai += 256) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         for (int a = 0; a < A; ++a) s += dOb[a * T + i] * v[a * T + j];
         dSb[ij] = s;
     }
-    __syncthreads();
+    block_sync();
     // dS = P * (dP - rowsum(dP*P)), one wave per row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = wave; i < T; i += 4) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         r = wave_sum(r);
         for (int j = lane; j < T; j += 64) dSb[i * T + j] = Pb[i * T + j] * (dSb[i * T + j] - r);
     }
-    __syncthreads();
+    block_sync();
     for (int ai = threadIdx.x; ai < A * T; ai += 256) {
         const int a = ai / T, i = ai % T;
         // dv[a][i] = sum_r P[r][i] dO[a][r];  dk[a][i] = sum_r dS[r][i] q[a][r] / sqrt(d)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __rest
         const int r = i / A, a = i - r * A, rel = r - (T - 1);
         es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
     }
-    __syncthreads();
+    block_sync();
     for (int ij = threadIdx.x; ij < T * T; ij += 256) {
         const int i = ij / T, j = ij - i * T, rel = j - i;
         const float* er = es + (rel + T - 1) * EP;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __rest
         }
         Ps[ij] = (rel > R - 1 || rel < -(R - 1)) ? qk * inv_sqrt_d + (-1e8f) : qk * inv_sqrt_d + qe;
     }
-    __syncthreads();
+    block_sync();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float* Pb = P + (size_t)blockIdx.x * T * T;
     for (int i = wave; i < T; i += 4) {              // T <= 32 < 64: one element per lane
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __rest
         const float pr = ex * (1.f / se);
         if (lane < T) { Ps[i * T + lane] = pr; Pb[i * T + lane] = pr; }
     }
-    __syncthreads();
+    block_sync();
     float* Ob = O + ((size_t)b * Cm + h * A) * T;
     for (int ai = threadIdx.x; ai < AT; ai += 256) {
         const int a = ai / T, i = ai - a * T;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
         const int r = i / A, a = i - r * A, rel = r - (T - 1);
         es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
     }
-    __syncthreads();
+    block_sync();
     // dP[i][j] = sum_a dO[a][i] v[a][j]
     for (int ij = threadIdx.x; ij < T * T; ij += 256) {
         const int i = ij / T, j = ij - i * T;
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
         for (int a = 0; a < A; ++a) s += ds[a * T + i] * vs[a * T + j];
         Ss[ij] = s;
     }
-    __syncthreads();
+    block_sync();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = wave; i < T; i += 4) {
         const float pv = lane < T ? Ps[i * T + lane] : 0.f, dp = lane < T ? Ss[i * T + lane] : 0.f;
         const float r = wave_sum(dp * pv);
         if (lane < T) Ss[i * T + lane] = pv * (dp - r);
     }
-    __syncthreads();
+    block_sync();
     float* dq = dqkv + base;
     float* dk = dqkv + base + (size_t)Cm * T;
     float* dv = dqkv + base + (size_t)2 * Cm * T;

@@ -8,9 +8,9 @@ namespace {
 
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
-    __syncthreads();
+    block_sync();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    block_sync();
     return red[0] + red[1] + red[2] + red[3];
 }
 
@@ -146,16 +146,16 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
         dlow[t] = 0.f;
         drect[t] = 0.f;
     }
-    __syncthreads();
-    box9(xr, tmp, T);   __syncthreads();
-    box9(tmp, low_r, T); __syncthreads();
-    box9(xg, tmp, T);   __syncthreads();
-    box9(tmp, low_g, T); __syncthreads();
+    block_sync();
+    box9(xr, tmp, T);   block_sync();
+    box9(tmp, low_r, T); block_sync();
+    box9(xg, tmp, T);   block_sync();
+    box9(tmp, low_g, T); block_sync();
     for (int t = threadIdx.x; t < T; t += 256) {
         rect_r[t] = fabsf(xr[t] - low_r[t]);
         rect_g[t] = fabsf(xg[t] - low_g[t]);
     }
-    __syncthreads();
+    block_sync();
 
     const TDScale sc[3] = {s0, s1, s2};
     float loss_acc[3] = {0.f, 0.f, 0.f};
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
             cf[3 * maxF + f] = sgn(d3) * k * invW;
         }
         loss_acc[si] = l * S.inv_n;
-        __syncthreads();
+        block_sync();
         if (dx_gen) {
             // gather form of the frame/reflect adjoint: position t receives from padded taus t+P and its mirrors
             for (int t = threadIdx.x; t < T; t += 256) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
                 drect[t] += gr;
             }
         }
-        __syncthreads();
+        block_sync();
     }
     // loss partials: [row][3]
     for (int si = 0; si < 3; ++si) {
@@ -217,16 +217,16 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
     }
     if (!dx_gen) return;
     // rect = |x - low|:  dh = sign(x-low)*drect ; dx = dh + A^T A^T (dlow - dh)
-    __syncthreads();
+    block_sync();
     for (int t = threadIdx.x; t < T; t += 256) {
         const float h = xg[t] - low_g[t];
         const float dh = (h > 0.f ? 1.f : (h < 0.f ? -1.f : 0.f)) * drect[t];
         rect_g[t] = dh;                  // reuse as dh
         dlow[t] -= dh;
     }
-    __syncthreads();
-    box9_adjoint(dlow, tmp, T);  __syncthreads();
-    box9_adjoint(tmp, low_g, T); __syncthreads();
+    block_sync();
+    box9_adjoint(dlow, tmp, T);  block_sync();
+    box9_adjoint(tmp, low_g, T); block_sync();
     for (int t = threadIdx.x; t < T; t += 256) dx_gen[((size_t)b * T + t) * Cc + c] = rect_g[t] + low_g[t];
 }
 

@@ -227,7 +227,11 @@ class FusedAdamW:
             self.pack.zero()
 
     def finalize_grads(self):
-        """Call between backward() and step() / the gradient all-reduce when a ConvPack is attached."""
+        """Call between backward() and step() / the gradient all-reduce: joins the streams on which backward nodes wrote
+        gradients straight into the arena (ops.wgrad_join) and, with a ConvPack attached, turns the raw direction
+        gradients into (dv, dg)."""
+        from . import ops
+        ops.wgrad_join()
         if self.pack is not None:
             self.pack.finalize_grads()
 

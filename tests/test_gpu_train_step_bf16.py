@@ -109,3 +109,25 @@ def test_generator_weight_gradients_on_side_streams_equal_inline(bf16_mode):
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
     assert abs(res[0][2] - res[1][2]) <= 1e-6 * abs(res[1][2])
+
+
+def test_sink_gradients_written_on_side_streams_are_joined(bf16_mode):
+    """Backward nodes of the period branch run on the discriminators' side stream and write weight gradients straight into
+    the gradient arena (sink mode), invisibly to autograd: ops._sink_touch must have registered that stream by the end of
+    loss_D.backward(), and finalize_grads() must wait for it (ops.wgrad_join) before the optimiser reads the arena."""
+    from ste_gan_amd.losses.gan_losses import lsgan_pair_loss
+    name = next(iter(cases.STEP_CASES))
+    cfg, netG, netD, optG, optD, step = build(name)
+    b = to_batch(cases.step_batch(name, 0))
+    from ste_gan_amd.constants import DataType
+    x = b[DataType.REAL_EMG]
+    optD.zero_grad()
+    bf16_mode.wgrad_join()
+    loss = lsgan_pair_loss(netD.forward_pair_logits(x * 0.5, x), 0.0, 1.0, unit_grad=True)
+    loss.backward()
+    main = torch.cuda.current_stream().cuda_stream
+    assert any(k != main for k in bf16_mode._SINK_STREAMS), "the period branch's backward did not register its stream"
+    optD.finalize_grads()
+    assert not bf16_mode._SINK_STREAMS and not bf16_mode._WG_KEEP
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in netD.parameters())

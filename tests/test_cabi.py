@@ -23,6 +23,19 @@ def test_header_symbols_are_exported_and_bound():
     assert set(syms) == bound, f"ctypes binding out of sync with the header: {set(syms) ^ bound}"
 
 
+def test_every_exported_entry_point_is_declared():
+    """The other direction: nothing is exported (extern "C" stegan_*) that include/stegan_hip.h does not declare."""
+    import shutil
+    import subprocess
+    from ste_gan_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("stegan_")}
+    assert exported, "no stegan_* symbols found"
+    undeclared = exported - set(declared_symbols())
+    assert not undeclared, f"exported but not declared in include/stegan_hip.h: {sorted(undeclared)}"
+
+
 def test_library_loads_and_selftest():
     from ste_gan_amd import _lib
     h = _lib.lib()

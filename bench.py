@@ -186,8 +186,8 @@ def main():
     step = build_step(cfg, device)
     batch = synthetic_batch(device, seed=1000 + rank)      # rank-offset seeds: different data per replica
     eager_step = step
-    graphed = world == 1 and not args.no_graph
-    if graphed:                                            # single process: the whole step is one captured hipGraph
+    graphed = not args.no_graph
+    if graphed:        # one captured hipGraph per step; under torch.distributed three (the phases around the two all-reduces)
         from ste_gan_amd.train import GraphedTrainStep
         step = GraphedTrainStep(eager_step, batch, warmup=2)
 
@@ -308,7 +308,7 @@ def main():
                                        ("bf16 conv operands, fp32 accumulation / activations / weights (BASELINE config 3)"
                                         if args.dtype == "bf16" else "fp32 parity path"),
                            "global_batch": world * B, "parallelism": f"dp{world}",
-                           "launch": "hipGraph replay" if graphed else "eager"},
+                           "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around 2 eager RCCL all-reduces") if graphed else "eager"},
                 "roofline": roof,
                 # whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds)
                 "step_rooflines": {"algorithmic_gflop": STEP_GFLOP, "layer_boundary_gbytes": STEP_GBYTES,
@@ -321,7 +321,13 @@ def main():
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        # every rank is done (rank 0 has printed): leave without running destructors.  Tearing down captured graphs, the
+        # RCCL communicator and the process group at interpreter exit aborted intermittently on this stack (SIGABRT after
+        # the result line, exit code 134), which a launcher reads as a failed run.
+        dist.barrier()
+        torch.cuda.synchronize()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

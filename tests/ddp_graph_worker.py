@@ -1,0 +1,47 @@
+"""Child process of test_gpu_train_step.py::test_three_graph_replay_with_process_group_matches_golden."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import cases  # noqa: E402
+from test_gpu_train_step import build, close, norms, to_batch  # noqa: E402
+
+
+def main():
+    from ste_gan_amd.train import GraphedTrainStep
+    name = "step_c48_b3"
+    g = np.load(os.path.join(HERE, "golden", name + ".npz"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg, netG, netD, optG, optD, step = build(name)
+    assert step.comm is not None
+    sdG = {k: v.clone() for k, v in netG.state_dict().items()}
+    sdD = {k: v.clone() for k, v in netD.state_dict().items()}
+    gs = GraphedTrainStep(step, to_batch(cases.step_batch(name, 0)), warmup=2)
+    assert gs.graphs is not None and len(gs.graphs) == 3
+    netG.load_state_dict(sdG); netD.load_state_dict(sdD)
+    for opt in (optG, optD):
+        opt.reset_state()
+    for s in range(2):
+        out = gs(to_batch(cases.step_batch(name, s)))
+        st = gs.read_stats(out)
+        ref = g[f"s{s}.losses"]
+        close([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"],
+               st["feature_matching"]], ref[[0, 1, 3, 4, 5, 6]], 1e-4, f"s{s}.losses")
+        close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
+        close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
+    torch.cuda.synchronize()
+    print("RESULT OK", flush=True)
+    os._exit(0)
+
+
+if __name__ == "__main__":
+    main()

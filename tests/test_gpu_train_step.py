@@ -222,37 +222,19 @@ def test_graph_replay_matches_golden(golden):
         close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
 
 
-def test_three_graph_replay_with_process_group_matches_golden(golden):
+def test_three_graph_replay_with_process_group_matches_golden():
     """Under torch.distributed GraphedTrainStep captures the step's three phases as three hipGraphs (one memory pool) and
     launches the two gradient all-reduces eagerly between them: with a 1-rank RCCL group the replay must reproduce the golden
-    two-step fixture like the single-graph and the eager paths."""
+    two-step fixture like the single-graph and the eager paths.  Runs in a child process (tests/ddp_graph_worker.py) that
+    leaves with os._exit once it has printed its verdict: destroying an RCCL process group after hipGraph replays aborts
+    intermittently on this stack, which would take the whole pytest session down."""
     import os
-    import torch.distributed as dist
-    from ste_gan_amd.train import GraphedTrainStep
-    name = "step_c48_b3"
-    g = golden(name)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29300 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        cfg, netG, netD, optG, optD, step = build(name)
-        assert step.comm is not None
-        sdG = {k: v.clone() for k, v in netG.state_dict().items()}
-        sdD = {k: v.clone() for k, v in netD.state_dict().items()}
-        gs = GraphedTrainStep(step, to_batch(cases.step_batch(name, 0)), warmup=2)
-        assert gs.graphs is not None and len(gs.graphs) == 3
-        netG.load_state_dict(sdG); netD.load_state_dict(sdD)
-        for opt in (optG, optD):
-            opt.reset_state()
-        for s in range(2):
-            out = gs(to_batch(cases.step_batch(name, s)))
-            st = gs.read_stats(out)
-            ref = g[f"s{s}.losses"]
-            close([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"],
-                   st["feature_matching"]], ref[[0, 1, 3, 4, 5, 6]], 1e-4, f"s{s}.losses")
-            close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
-            close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
-    finally:
-        dist.destroy_process_group()
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_graph_worker.py")], capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(here))
+    assert "RESULT OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_feature_matching_fold_equals_autograd_accumulation():

@@ -345,6 +345,7 @@ class GraphedTrainStep:
         self._stage(self.step.optG)
         if self.graphs is None:
             self.graph.replay()
+            self._after_replay()
             return self.out
         step = self.step
         g1, g2, g3 = self.graphs
@@ -355,7 +356,16 @@ class GraphedTrainStep:
         step.exchange_g()
         step.comm.wait(step._g_handle); step._g_handle = None
         g3.replay()
+        self._after_replay()
         return self.out
+
+    def _after_replay(self):
+        """The replayed optimiser kernels changed the weights behind the host's back: mark every prepared weight copy stale
+        for EAGER users of the networks (validation, sampling).  The captured step re-derives its own copies at its start."""
+        ops.bump_weight_epoch()
+        for opt in (self.step.optG, self.step.optD):
+            if opt.pack is not None:
+                opt.pack.invalidate()
 
     read_stats = staticmethod(GANTrainStep.read_stats)
 
@@ -478,6 +488,11 @@ def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debu
         train_loader.save_session_and_speaking_mode_mapping_json(model_directory)          # train.py:121-122
 
     step_fn = GANTrainStep(cfg, netG, netD, emg_encoder_loss, multi_td_loss, optG, optD)
+    # hipGraph replay per batch SHAPE: an eager step is ~800 launches and bound by the host (22.7 ms against 8.8 ms of GPU
+    # time at B = 64).  The first batch of a shape runs eagerly -- that IS its training step, and it warms every lazy
+    # allocation -- then the step is captured (capture executes nothing) and later batches of that shape replay it.
+    graphed: Dict[tuple, GraphedTrainStep] = {}
+    use_graphs = torch.device(device).type == "cuda" and os.environ.get("STEGAN_TRAIN_GRAPH", "1") != "0"
     speech_feature_type = cfg.model.speech_feature_type
     crop = crop_to_hop(cfg.train.chunk_size)
     if crop != cfg.train.chunk_size:
@@ -492,8 +507,19 @@ def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debu
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch_dict.items()}
             if batch[DataType.REAL_EMG].shape[1] > crop >= K.HOPSIZE:
                 batch[DataType.REAL_EMG] = batch[DataType.REAL_EMG][:, :crop].contiguous()
-            out = step_fn(batch)
-            stats = step_fn.read_stats(out)
+            key = tuple((str(k), tuple(v.shape)) for k, v in batch.items() if torch.is_tensor(v))
+            stats = None
+            if not use_graphs:
+                out = step_fn(batch)
+            elif key in graphed:
+                out = graphed[key](batch)
+            else:
+                out = step_fn(batch)                                   # eager: this batch's step, and the warm-up
+                stats = step_fn.read_stats(out)                        # (read before a capture runs the Python side again)
+                if len(graphed) < 4:                                   # more distinct shapes than that: the rest stay eager
+                    graphed[key] = GraphedTrainStep(step_fn, batch, warmup=0)
+            if stats is None:
+                stats = step_fn.read_stats(out)
             for tag in tags:
                 if tag in stats:
                     writer.add_scalar(f"train_loss/{tag}", stats[tag], steps)

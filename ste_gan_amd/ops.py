@@ -140,16 +140,26 @@ def profiler_by_shape(prof: "ConvProfiler"):
 # ---------------------------------------------------------------------------------------------
 _SPLITK_MAX = 16
 _WORKSPACES = {}
+_WORKSPACES_RETIRED = []      # outgrown workspaces stay allocated: captured graphs hold their addresses (see _workspace)
 
 
 def _workspace(device, floats: int) -> Tensor:
     """Split-K scratch shared by all conv launches of a (device, stream): launches are stream ordered, and the
-    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them."""
+    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them.
+
+    A workspace that has to grow is RETIRED, never freed: a captured hipGraph bakes the address of the workspace it was
+    recorded with into its kernel nodes, so freeing an outgrown buffer would leave every earlier capture (an earlier kernel
+    of the same capture, or the graph of another batch shape in train()) writing its partial sums into memory the allocator
+    hands to someone else -- seen as a GPU memory fault in train()'s second graph.  Growth is geometric and capped at
+    512 MiB, so a stream retires at most a few buffers."""
     floats = min(floats, 1 << 27)                      # cap at 512 MiB; the kernel lowers the split to fit
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < floats:
-        ws = torch.empty(max(floats, 1 << 22), device=device, dtype=torch.float32)
+        if ws is not None:
+            _WORKSPACES_RETIRED.append(ws)
+        size = max(floats, 1 << 22, 2 * ws.numel() if ws is not None else 0)
+        ws = torch.empty(min(size, 1 << 27), device=device, dtype=torch.float32)
         _WORKSPACES[key] = ws
     return ws
 

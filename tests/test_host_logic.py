@@ -84,3 +84,43 @@ def test_conv_cfg_output_length_and_error():
     assert ConvCfg(8, 8, 3, pad=1, upsample=2).tout(12) == 24
     with pytest.raises(RuntimeError, match="Kernel size can't be greater"):
         ConvCfg(8, 8, 41).tout(8)
+
+
+def test_fold_window_bookkeeping_on_the_host():
+    """ops.fm_fold_begin / fm_fold_end: a parked feature-matching gradient that no producer collected makes the end of the
+    window raise (a graph shape the shortcut does not cover must fail loudly, not drop a loss term); the window state is
+    reset either way."""
+    from ste_gan_amd import ops
+    ops.fm_fold_begin()
+    assert ops._FM_WINDOW and not ops._FM_PENDING and not ops._FM_FOLDABLE
+    ops.fm_fold_end()                                    # nothing parked: fine
+    assert not ops._FM_WINDOW
+    ops.fm_fold_begin()
+    ops._FM_PENDING[(4096, 16)] = torch.zeros(16)
+    with pytest.raises(RuntimeError, match="never collected"):
+        ops.fm_fold_end()
+    assert not ops._FM_WINDOW and not ops._FM_PENDING
+    ops.fm_fold_begin()
+    ops._FM_FOLDABLE.add((1, 2))
+    ops.fm_fold_abort()
+    assert not ops._FM_WINDOW and not ops._FM_FOLDABLE
+
+
+def test_discriminator_pair_loss_rejects_unequal_halves():
+    """lsgan_pair_loss prices the concatenated fake | real logits as one term of weight 2: only valid for equal halves."""
+    from ste_gan_amd.losses.gan_losses import lsgan_pair_loss
+    with pytest.raises(ValueError, match="two equal halves"):
+        lsgan_pair_loss([("both", torch.zeros(5, 1, 7), 2)])
+    from ste_gan_amd import ops
+    with pytest.raises(ValueError, match="fold requires unit_grad"):
+        ops.multi_pair_loss([torch.zeros(3)], [torch.zeros(3)], 0, fold=True)
+
+
+def test_train_step_phases_exist_for_segmented_capture():
+    """GraphedTrainStep captures GANTrainStep.phase_d / phase_g / phase_opt as three graphs under torch.distributed: the
+    eager step must be exactly their composition with the two exchanges in between."""
+    import inspect
+    from ste_gan_amd.train import GANTrainStep
+    src = inspect.getsource(GANTrainStep.__call__)
+    order = [src.index(s) for s in ("self.phase_d(", "self.exchange_d(", "self.phase_g(", "self.exchange_g(", "self.phase_opt(")]
+    assert order == sorted(order)

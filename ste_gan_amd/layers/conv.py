@@ -24,6 +24,14 @@ def get_padding(kernel_size, dilation=1):
     return int((kernel_size * dilation - dilation) / 2)
 
 
+def _owner_epoch(m) -> int:
+    """Epoch of the optimiser arena that owns this layer's parameters (optim.FlatParams sets ``_owner``): the fused AdamW
+    kernel writes the weights through raw pointers, which torch's version counters cannot see, and bumps its OWN network's
+    epoch -- an update of the generator does not make the discriminator's prepared copies stale."""
+    o = getattr(m, "_owner", None)
+    return o.epoch if o is not None else 0
+
+
 class WNConv1d(nn.Module):
     """Weight-normalised Conv1d (old-style ``weight_norm``: parameters weight_g / weight_v / bias).
 
@@ -58,7 +66,7 @@ class WNConv1d(nn.Module):
             pack.prepare()
             return scale, wf, wb
         v, g = self.weight_v, self.weight_g
-        stamp = (ops.WEIGHT_EPOCH, v._version, g._version, v.data_ptr(), g.data_ptr())
+        stamp = (ops.WEIGHT_EPOCH, _owner_epoch(self), v._version, g._version, v.data_ptr(), g.data_ptr())
         if self._prep is None or self._prep[0] != stamp:
             w3 = v.detach().reshape(v.shape[0], v.shape[1], -1)
             scale = ops.wn_scale(v.detach(), g.detach())
@@ -148,7 +156,7 @@ class SNConv1d(nn.Module):
 
     def prepared(self):
         w = self.weight_orig
-        stamp = (ops.WEIGHT_EPOCH, w._version, w.data_ptr())
+        stamp = (ops.WEIGHT_EPOCH, _owner_epoch(self), w._version, w.data_ptr())
         if self._prep is None or self._prep[0] != stamp:
             self._prep = (stamp, ops.prep_weights(w.detach(), self.cfg, self._prep[1] if self._prep is not None and
                                                   self._prep[1][0].device == w.device else None))

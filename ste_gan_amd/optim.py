@@ -46,9 +46,12 @@ class FlatParams:
                 p.data = view
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
         self.numel = total
-        for m in module.modules():             # spectral-norm convs may accumulate straight into these views
-            if hasattr(m, "grad_sink"):
+        self.epoch = 0                         # bumped by every fused AdamW launch on this arena (layers.conv._owner_epoch)
+        for m in module.modules():
+            if hasattr(m, "grad_sink"):        # spectral-norm convs may accumulate straight into these views
                 m.grad_sink = True
+            if hasattr(m, "_prep"):            # layers that keep prepared weight copies of their own
+                m._owner = self
 
     def zero_grad(self):
         self.grad.zero_()
@@ -267,8 +270,7 @@ class FusedAdamW:
             C.c_void_p(self.exp_avg_sq.data_ptr()), f.numel, C.c_void_p(self._hyper.data_ptr()),
             self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step")
-        from . import ops
-        ops.bump_weight_epoch()        # parameters changed behind torch's back: transposed weight copies are stale
+        self.flat.epoch += 1           # parameters changed behind torch's back: this network's prepared copies are stale
         if self.pack is not None:
             self.pack.invalidate()
 

@@ -311,9 +311,14 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._counts = (step.optG.step_count, step.optD.step_count)
-        for opt in (step.optG, step.optD):      # make the captured step re-derive scales / transposed weight copies from
-            if opt.pack is not None:            # the live weights at its start: replay stays valid after a checkpoint load
-                opt.pack.invalidate()
+        # Prepared weight copies inside the captured step.  The generator's are re-derived at its start (its weights changed
+        # at the end of the previous step): invalidate them so that the capture records the launches.  The discriminator's
+        # weights change in the MIDDLE of a step and their copies are re-derived right there, so at the start of the next
+        # step they are current: the capture records NO preparation in front of the discriminator step (0.2 ms of launches
+        # on the critical path) and __call__ refreshes them eagerly whenever the host changed weights between replays.
+        if step.optG.pack is not None:
+            step.optG.pack.invalidate()
+        self._refresh_d()
         if step.comm is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -333,6 +338,21 @@ class GraphedTrainStep:
         step.optG.step_count, step.optD.step_count = self._counts
         self.last = self.out
 
+    def _weights_signature(self):
+        return sum(p._version for p in self.step.netD.parameters()) + sum(b._version for b in self.step.netD.buffers())
+
+    def _refresh_d(self):
+        """Bring the discriminator's prepared weight copies up to date, eagerly, on the current stream."""
+        netD = self.step.netD
+        if hasattr(netD, "_prepare_weights"):
+            netD._prepare_weights()
+        else:
+            for m in netD.modules():
+                prep = getattr(m, "prepared", None)
+                if prep is not None:
+                    prep()
+        self._d_sig = self._weights_signature()
+
     def _stage(self, opt: FusedAdamW):
         opt.step_count += 1          # host mirror of the device-side counter the captured advance kernel increments
         opt.sync_lr()
@@ -343,6 +363,9 @@ class GraphedTrainStep:
                 self.static[k].copy_(v, non_blocking=True)
         self._stage(self.step.optD)
         self._stage(self.step.optG)
+        if self._weights_signature() != self._d_sig or self.step.optD.pack is None or \
+                self.step.optD.pack.prepared_version != (self.step.optD.pack.version, ops.COMPUTE_DTYPE):
+            self._refresh_d()                  # load_state_dict / eager code touched the discriminator since the last replay
         if self.graphs is None:
             self.graph.replay()
             self._after_replay()
@@ -362,10 +385,10 @@ class GraphedTrainStep:
     def _after_replay(self):
         """The replayed optimiser kernels changed the weights behind the host's back: mark every prepared weight copy stale
         for EAGER users of the networks (validation, sampling).  The captured step re-derives its own copies at its start."""
-        ops.bump_weight_epoch()
-        for opt in (self.step.optG, self.step.optD):
-            if opt.pack is not None:
-                opt.pack.invalidate()
+        self.step.optG.flat.epoch += 1
+        if self.step.optG.pack is not None:
+            self.step.optG.pack.invalidate()
+        # (the discriminator's copies were re-derived inside the step after its update: still current)
 
     read_stats = staticmethod(GANTrainStep.read_stats)
 

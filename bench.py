@@ -219,8 +219,20 @@ def main():
     roof = None
     if args.profile_steps > 0:
         ops.PROFILER = ops.ConvProfiler()
-        for _ in range(args.profile_steps):
-            eager_step(batch)                              # instrumented pass: eager launches, HIP events per conv
+        # one stream for the instrumented pass: an event bracket around a launch on one stream would otherwise also time
+        # whatever the other streams run beside it (and the choice of the "dominant" kernel would vary from run to run)
+        saved = (eager_step.overlap_encoder, os.environ.get("STEGAN_D_STREAMS"))
+        eager_step.overlap_encoder = False
+        os.environ["STEGAN_D_STREAMS"] = "0"
+        try:
+            for _ in range(args.profile_steps):
+                eager_step(batch)                          # instrumented pass: eager launches, HIP events per conv
+        finally:
+            eager_step.overlap_encoder = saved[0]
+            if saved[1] is None:
+                os.environ.pop("STEGAN_D_STREAMS", None)
+            else:
+                os.environ["STEGAN_D_STREAMS"] = saved[1]
         agg = ops.PROFILER.summary()
         # what a HIP event pair adds to the launch it brackets: the same pair around a one-block fill kernel whose own
         # run time (~1.5 us) is negligible -- marker packets, the dispatch gap behind a marker.  The kernels of this path

@@ -154,9 +154,13 @@ class SNConv1d(nn.Module):
         self._prep = None
         self.grad_sink = False      # set by optim.FlatParams: .grad tensors are persistent, zeroed arena views
 
+    def _stamp(self):
+        w = self.weight_orig
+        return (ops.WEIGHT_EPOCH, _owner_epoch(self), w._version, w.data_ptr())
+
     def prepared(self):
         w = self.weight_orig
-        stamp = (ops.WEIGHT_EPOCH, _owner_epoch(self), w._version, w.data_ptr())
+        stamp = self._stamp()
         if self._prep is None or self._prep[0] != stamp:
             self._prep = (stamp, ops.prep_weights(w.detach(), self.cfg, self._prep[1] if self._prep is not None and
                                                   self._prep[1][0].device == w.device else None))

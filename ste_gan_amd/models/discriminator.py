@@ -186,10 +186,25 @@ class _MultiDisc(nn.Module):
         """Bring every conv's prepared weight copies up to date on the CURRENT stream (a no-op when they are): the
         copies are made lazily by the first conv that needs them, which after a fork would be on one branch's stream
         while the other branch reads them unordered."""
+        self._prepare_sn_bf16()
         for m in self.modules():
             prep = getattr(m, "prepared", None)
             if prep is not None and m is not self:
                 prep()
+
+    def _prepare_sn_bf16(self):
+        """The bf16 copies of all stale spectral-norm layers in one launch instead of one each (they are re-derived once per
+        step, right after the discriminator's update: four 20 us launches on the main stream)."""
+        from ..layers.conv import SNConv1d
+        if not ops.bf16_enabled():
+            return
+        stale = [m for m in self.modules() if isinstance(m, SNConv1d) and m.weight_orig.is_cuda
+                 and (m._prep is None or m._prep[0] != m._stamp())]
+        if len(stale) < 2 or any(m._prep is None or getattr(m._prep[1][0], "h", None) is None for m in stale):
+            return                             # first use: the per-layer path allocates the buffers
+        ops.prep_bf16_many([(m.cfg, m.weight_orig.detach(), None, m._prep[1][0], m._prep[1][1]) for m in stale])
+        for m in stale:
+            m._prep = (m._stamp(), m._prep[1])
 
     _side = None
 

@@ -223,6 +223,40 @@ def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = 
     return bufs
 
 
+def bf16_prep_row(cfg: ConvCfg, v: Tensor, scale: Optional[Tensor], wf_h: Tensor, wb_h: Tensor) -> bytes:
+    """One entry of the device table stegan_conv_prep_bf16_multi reads (struct PrepH of csrc/conv_bf16.hip)."""
+    import struct
+    L = _lib.lib()
+    d = _desc(cfg, 1, 1, 1)
+    nf, nb = int(L.stegan_conv_prep_bf16_elems(C.byref(d), 0)), int(L.stegan_conv_prep_bf16_elems(C.byref(d), 1))
+    if wf_h.numel() != nf or wb_h.numel() != nb:
+        raise RuntimeError("bf16_prep_row: companion buffers do not match the layer")
+    G = cfg.groups
+    cog, cig = cfg.cout // G, cfg.cin // G
+    up = lambda a, b: (a + b - 1) // b * b
+    return struct.pack("<4q8i2q", v.data_ptr(), scale.data_ptr() if scale is not None else 0, wf_h.data_ptr(), wb_h.data_ptr(),
+                       cog, cig, cfg.k, G, up(cog, 128), up(cig, 64), up(cig, 128), up(cog, 64), nf, nb)
+
+
+_PREP_TABLES: dict = {}
+
+
+def prep_bf16_many(entries) -> None:
+    """bf16 copies of several layers in ONE launch: ``entries`` = [(cfg, weight (Cout, Cin/g, K), scale or None, wf, wb)]
+    with wf / wb the layers' prepared fp32 buffers carrying their bf16 companions (``.h``).  The device table is cached by
+    the tensors' addresses (parameters live in a FlatParams arena: stable)."""
+    L = _lib.lib()
+    key = tuple((w.data_ptr(), wf.h.data_ptr(), wb.h.data_ptr()) for _, w, _, wf, wb in entries)
+    ent = _PREP_TABLES.get(key)
+    if ent is None:
+        raw = b"".join(bf16_prep_row(cfg, w, sc, wf.h, wb.h) for cfg, w, sc, wf, wb in entries)
+        table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(entries[0][1].device)
+        tiles = max(int(L.stegan_conv_prep_bf16_tiles(C.byref(_desc(cfg, 1, 1, 1)))) for cfg, *_ in entries)
+        ent = (table, max(1, min(4096, tiles)), [t for e in entries for t in (e[1], e[3], e[4])])      # keeps the tensors alive
+        _PREP_TABLES[key] = ent
+    check(L.stegan_conv_prep_bf16_multi(len(entries), _p(ent[0]), ent[1], _stream()), "stegan_conv_prep_bf16_multi")
+
+
 def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Tensor],
                residual: Optional[Tensor], cfg: ConvCfg, wf: Optional[Tensor] = None) -> Tensor:
     x = _gpu_f32(x, "x")

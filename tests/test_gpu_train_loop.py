@@ -132,3 +132,22 @@ def test_graph_replay_in_the_training_loop_matches_eager_launches(tmp_path, monk
             # gradient can flip single updates (and the spectral-norm vectors follow the weights): compare tensor norms
             rel = float((ta - tb).norm()) / max(float(tb.norm()), 1e-12)
             assert rel <= 1e-2, (k, rel)
+
+
+def test_train_loop_two_ranks_with_graph_replay(tmp_path):
+    """train() under torch.distributed (2 ranks on the box's one card, gloo): rank-sharded loaders, the three-graph replay of
+    the step around the two gradient all-reduces, validation / checkpoints on rank 0 behind barriers."""
+    import subprocess
+    import sys
+    _corpus(tmp_path / "corpus")
+    torch.save(fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128)), tmp_path / "enc.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29761", os.path.join(ROOT, "tests", "ddp_train_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert "RANK 0 DONE" in r.stdout and "RANK 1 DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    out = tmp_path / "run_ddp"
+    names = {p.name for p in out.iterdir()}
+    assert {".done", "netG-final.pt", "netD-final.pt", "checkpoint-final.pt"} <= names
+    sd = torch.load(out / "netG-final.pt")
+    assert all(torch.isfinite(v).all() for v in sd.values())

@@ -182,6 +182,59 @@ def test_mfcc_variant_step_vs_oracle():
     close(norms(netD.state_dict().values()), norms(d_sd.values()), 2e-5, "d params after step")
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_discriminator_step_vs_oracle(dtype):
+    """`model.discriminator_small: false` (discriminator.py:158-191: k5 s3 period stacks to 1024 channels, k41 grouped scale
+    stacks, SEVEN spectral-norm layers) through the whole train step -- batched discriminator pass with split targets, the
+    rebalanced streams, one-launch spectral norm -- against the CPU oracle's train step: fp32 within 1e-4, bf16 within the
+    tolerances of the bf16 mode (test_gpu_train_step_bf16.py)."""
+    from oracle import stegan_oracle as O
+    from oracle.detfill import det_input, det_ints
+    from ste_gan_amd import ops
+    from ste_gan_amd.constants import DataType
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.discriminator import init_emg_discriminators
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.train import GANTrainStep, make_optimizers
+    B, T = 2, 24
+    cfg = make_cfg(32)
+    cfg.model.discriminator_small = False
+    g_sd = fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", 32))
+    d_sd = fill_state_dict(oshapes.discriminator_shapes(False))
+    e_sd = fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128))
+    ops.set_compute_dtype(dtype)
+    try:
+        netG = init_emg_generator(cfg); netG.load_state_dict(g_sd)
+        netD = init_emg_discriminators(cfg); netD.load_state_dict(d_sd)
+        enc = EMGEncoderTransformer(8, 256, 48, model_size=64, num_transformer_layers=2, dim_feedforward=128); enc.load_state_dict(e_sd)
+        netG, netD, enc = netG.cuda(), netD.cuda(), enc.cuda().eval()
+        optG, optD = make_optimizers(netG, netD)
+        step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
+        su = det_input("fd.su", (B, T, 256)); x_real = det_input("fd.x", (B, 16 * T, 8), "tanh")
+        sess = det_ints("fd.s", (B,), 17); ph = det_ints("fd.ph", (B, T), 48)
+        batch = {DataType.REAL_EMG: x_real.cuda(), DataType.SPEECH_UNITS: su.cuda(), DataType.SESSION_INDEX: sess.cuda(),
+                 DataType.SPEAKING_MODE_INDEX: torch.zeros_like(sess).cuda(), DataType.PHONEMES: ph.cuda()}
+        st = step.read_stats(step(batch))
+    finally:
+        ops.set_compute_dtype("f32")
+    d_train = {k: v for k, v in d_sd.items() if not O.is_sn_buffer(d_sd, k)}
+    o = O.train_step(g_sd, d_sd, e_sd, O.adamw_init(g_sd), O.adamw_init(d_train),
+                     {"su": su, "feats": su, "x_real": x_real, "sess": sess, "phonemes": ph}, small_d=False)
+    got = [st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"], st["feature_matching"]]
+    ref = [o["loss_d"], o["loss_g"], o["loss_td"], o["loss_su"], o["loss_ph"], o["loss_fm"]]
+    if dtype == "f32":
+        close(got, ref, 1e-4, "losses")
+        assert st["num_correct_phones"] == o["num_correct_phones"]
+        close(norms(netG.state_dict().values()), norms(g_sd.values()), 2e-5, "g params after step")
+        close(norms(netD.state_dict().values()), norms(d_sd.values()), 2e-5, "d params after step")
+    else:
+        np.testing.assert_allclose(np.array(got), np.array(ref, dtype=np.float64), rtol=3e-2)
+        np.testing.assert_allclose(norms(netG.state_dict().values()), norms(g_sd.values()), rtol=1e-3)
+        np.testing.assert_allclose(norms(netD.state_dict().values()), norms(d_sd.values()), rtol=1e-3)
+
+
 def test_steps_queued_without_host_sync_match_golden(golden):
     """The training loop does not synchronise per step, so the host may be several steps ahead of the stream: nothing a
     queued step reads (AdamW step count / bias corrections, prepared weights) may depend on host state at execution time."""

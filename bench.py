@@ -114,8 +114,8 @@ def cpu_baseline(steps=2):
 
 
 def gen_infer(args, cfg, device, quiet=False):
-    """BASELINE config 2: Generator.generate on (64, 12, 256) Soft-SU -> (64, 192, 8) in the current compute mode (eager
-    launches; not the headline metric)."""
+    """BASELINE config 2: Generator.generate on (64, 12, 256) Soft-SU -> (64, 192, 8) in the current compute mode (one replayed
+    hipGraph per forward unless --no-graph; not the headline metric)."""
     from ste_gan_amd import ops as _ops
     mode = "bf16 conv operands, fp32 accumulation / activations" if _ops.bf16_enabled() else "fp32"
     from ste_gan_amd.constants import DataType
@@ -123,20 +123,34 @@ def gen_infer(args, cfg, device, quiet=False):
     torch.manual_seed(0)
     netG = init_emg_generator(cfg).to(device).eval()
     b = synthetic_batch(device, 1000)
-    run = lambda: netG.generate(b[DataType.SPEECH_UNITS], b[DataType.SESSION_INDEX], b[DataType.SPEAKING_MODE_INDEX])
-    for _ in range(args.warmup):
-        run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    eager = lambda: netG.generate(b[DataType.SPEECH_UNITS], b[DataType.SESSION_INDEX], b[DataType.SPEAKING_MODE_INDEX])
+    with torch.no_grad():
+        for _ in range(max(2, args.warmup)):
+            eager()
+        torch.cuda.synchronize()
+        run, launch = eager, "eager launches"
+        if not args.no_graph:                  # fixed shapes: the ~40 launches of a forward replay as one hipGraph
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    y_static = eager()
+            torch.cuda.current_stream().wait_stream(side)
+            run, launch = graph.replay, "hipGraph replay"
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     line = {"metric": "EMG frames/sec, generator-only inference at B=64 chunk=200 (BASELINE config 2)",
             "value": round(B * T_EMG * args.steps / dt, 1), "unit": "EMG frames/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "dtype": "bf16" if _ops.bf16_enabled() else "f32", "data": "synthetic",
-            "config": {"workload": f"Generator.generate, B=64, T_su=12 -> T_emg=192, {mode}, eager launches"},
+            "config": {"workload": f"Generator.generate, B=64, T_su=12 -> T_emg=192, {mode}, {launch}"},
             "algorithmic_tflops": round(2 * 53.02e9 * args.steps / dt / 1e12, 2)}
     if not quiet:
         print(json.dumps(line), flush=True)

@@ -203,7 +203,21 @@ def main():
     graphed = not args.no_graph
     if graphed:        # one captured hipGraph per step; under torch.distributed three (the phases around the two all-reduces)
         from ste_gan_amd.train import GraphedTrainStep
-        step = GraphedTrainStep(eager_step, batch, warmup=2)
+        if world == 1:
+            step = GraphedTrainStep(eager_step, batch, warmup=2)
+        else:
+            # every rank must take the same path (the eager step and the graphs issue the same collectives, but a rank
+            # that failed to capture must not leave the others replaying alone): agree on the outcome
+            try:
+                step = GraphedTrainStep(eager_step, batch, warmup=2)
+                ok = 1
+            except Exception as e:                         # noqa: BLE001 -- reported, then the run continues eagerly
+                print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                step, graphed = eager_step, False
 
     def barrier():
         if world > 1:

@@ -10,6 +10,10 @@ from ste_gan_amd.train import GraphedTrainStep
 
 ops.set_compute_dtype(os.environ.get("PROBE_DTYPE", "bf16"))
 dev = torch.device("cuda", 0)
+if os.environ.get("PROBE_GROUP"):            # 1-rank RCCL group: GraphedTrainStep replays three graphs around the exchanges
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 cfg = bench.make_cfg("train_step")
 if os.environ.get("PROBE_NO_TD"):
     cfg.train.loss_multi_td_error = False
@@ -42,5 +46,7 @@ for b in range(bursts):
         print("  G params", sum(nf(p) for p in eager.netG.parameters()), "D params", sum(nf(p) for p in eager.netD.parameters()))
         print("  G grads", sum(nf(p.grad) for p in eager.netG.parameters()), "D grads", sum(nf(p.grad) for p in eager.netD.parameters()))
         print("  stats", {k: v for k, v in st.items() if isinstance(v, float)})
-        sys.exit(1)
-print("no NaN in", bursts * per, "steps")
+        sys.stdout.flush()
+        os._exit(1)
+print("no NaN in", bursts * per, "steps", flush=True)
+os._exit(0)

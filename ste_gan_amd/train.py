@@ -319,19 +319,23 @@ class GraphedTrainStep:
         if step.optG.pack is not None:
             step.optG.pack.invalidate()
         self._refresh_d()
+        # capture_error_mode "thread_local": with a process group alive, the RCCL watchdog THREAD polls its work events with
+        # hipEventQuery at any time; in the default "global" mode such a call from another thread invalidates a capture in
+        # progress (hipErrorStreamCaptureInvalidated, then the watchdog aborts the process) -- seen once in three runs.
+        mode = dict(capture_error_mode="thread_local")
         if step.comm is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **mode):
                 self.out = step(self.static)
             self.graphs = None
         else:
             step._d_handle = step._g_handle = None            # nothing to await inside the captures
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
+            with torch.cuda.graph(g1, **mode):
                 step.phase_d(self.static)
-            with torch.cuda.graph(g2, pool=g1.pool()):
+            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
                 step.phase_g()
-            with torch.cuda.graph(g3, pool=g1.pool()):
+            with torch.cuda.graph(g3, pool=g1.pool(), **mode):
                 self.out = step.phase_opt()
             self.graphs = (g1, g2, g3)
         # capture ran the Python side once without executing kernels: undo its optimiser step counts

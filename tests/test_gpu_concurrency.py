@@ -83,3 +83,64 @@ def test_conv_results_do_not_depend_on_a_busy_second_stream(a, b, what, dtype):
         assert bad == 0, f"{bad} of {reps * replays} concurrent {what} results differ from the isolated one"
     finally:
         ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_encoder_and_generator_forward_do_not_depend_on_a_busy_second_stream(dtype):
+    """Module level: the frozen EMG encoder (convs, LayerNorm, relative-position attention) and the generator, replayed on one
+    stream while a discriminator-sized conv keeps a second stream busy, must return the bits they return alone."""
+    from oracle import shapes as oshapes
+    from oracle.detfill import det_input, det_ints, fill_state_dict
+    from ste_gan_amd import ops
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import EMGGeneratorGanTTS
+    ops.set_compute_dtype(dtype)
+    try:
+        enc = EMGEncoderTransformer(8, 256, 48, model_size=64, num_transformer_layers=2, dim_feedforward=128)
+        enc.load_state_dict(fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128)))
+        enc = enc.cuda().eval()
+        gen = EMGGeneratorGanTTS("SPEECH_UNITS", 256, 17, 8, channels=48)
+        gen.load_state_dict(fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", 48)))
+        gen = gen.cuda().eval()
+        x = det_input("cc.x", (16, 192, 8), "tanh").cuda()
+        su = det_input("cc.su", (16, 12, 256)).cuda()
+        sess = det_ints("cc.s", (16,), 17).cuda()
+        mb = _make(ops, *SHAPES["disc"])
+
+        def work():
+            with torch.no_grad():
+                return list(enc(x)) + [gen(su, sess, torch.zeros_like(sess))]
+
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for _ in range(2):
+            with torch.cuda.stream(s1):
+                work()
+            with torch.cuda.stream(s2):
+                _run(ops, mb, "fwd")
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in work()]
+        torch.cuda.synchronize()
+        outs = []
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(graph, stream=cap):
+                s1.wait_stream(cap); s2.wait_stream(cap)
+                with torch.cuda.stream(s1):
+                    for _ in range(4):
+                        outs.append(work())
+                with torch.cuda.stream(s2):
+                    for _ in range(40):
+                        _run(ops, mb, "fwd")
+                cap.wait_stream(s1); cap.wait_stream(s2)
+        torch.cuda.current_stream().wait_stream(cap)
+        bad = 0
+        for _ in range(8):
+            graph.replay()
+            torch.cuda.synchronize()
+            for o in outs:
+                bad += sum(int(not torch.equal(a, b)) for a, b in zip(o, ref))
+        assert bad == 0, f"{bad} module outputs differ from the isolated ones"
+    finally:
+        ops.set_compute_dtype("f32")

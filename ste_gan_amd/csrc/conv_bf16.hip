@@ -69,7 +69,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
     return __builtin_bit_cast(unsigned, s);
 }
 
-// XV: 16-byte X loads (4 consecutive time slots per lane): rows and valid extent multiples of 4 floats, no upsample;
+// XV: 16-byte X loads (4 consecutive source positions per lane; float4-aligned rows by default, see xv_eligible: a load
+// that straddles the end of a ragged row has its tail zeroed before the conversion) (with the
+// forward's nearest-x2 upsample one load feeds 8 slots: the first version sent those convs to 4-byte loads, 49 vs ~17 us);
 // every segment then starts at the source position rounded DOWN to a multiple of 4 and the rounding (0..3 slots) is
 // added to the lanes' column bases instead (the fp32 kernel's XVEC idea).
 #ifdef STEGAN_BF16_ABLATE       // diagnostic builds: STEGAN_BF16_DBG bits switch parts of the kernel off (results wrong)
@@ -148,7 +150,11 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // block, time) is a per-lane constant; the chunk's channel base and the channel within the block are a SCALAR offset.
     const int b_lo = (int)fd_div((uint32_t)n0, fdU), u0 = n0 - b_lo * U;
     const int qbase0 = u0 * cs + off_min, qbaseN = off_min;
-    const int qal0 = XV ? (qbase0 & ~3) : qbase0, qalN = XV ? (qbaseN & ~3) : qbaseN;
+    // XV with the nearest-x2 upsample (forward only): one aligned 16-byte load of 4 SOURCE positions feeds 8 slots, so the
+    // granule of the segment alignment and of an item is 8 slots instead of 4
+    const int xsh = XV ? 2 + ((p.mode == 0 && p.ups) ? 1 : 0) : 0;       // log2(slots per X item)
+    const int xgm = (1 << xsh) - 1;
+    const int qal0 = XV ? (qbase0 & ~xgm) : qbase0, qalN = XV ? (qbaseN & ~xgm) : qbaseN;
     const int CCH = 8 * NCB;
     const int nchunks = ntaps > 0 ? (p.C2_g + CCH - 1) / CCH : 0;
     const int c_begin = split * cps;
@@ -169,11 +175,12 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     constexpr int XI = XV ? HXV_MAX : HX_MAX;
     unsigned x_voff[XI];
     int x_lds[XI], x_c8[XI];             // LDS byte offset of the item's first slot (-1: no item); 8 * cg
+    int x_nv[XV ? XI : 1];               // XV: source positions of the item inside the row (< 4: the row's ragged tail)
 #pragma unroll
     for (int it = 0; it < XI; ++it) {
         const int idx = it * 256 + tid;
         const int cg = (int)fd_div((uint32_t)idx, h.fdNG), grp = idx - cg * h.NG;
-        const int slot = XV ? grp * 4 : grp;
+        const int slot = XV ? (grp << xsh) : grp;
         x_voff[it] = OOB;
         x_c8[it] = cg * 8;
         x_lds[it] = (it < h.xit && cg < NCB) ? (cg * p.XROW + slot) * 16 : -1;
@@ -181,8 +188,10 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
             const int b = b_lo + sg;
             const int q = (sg == 0 ? qal0 : qalN) + sl;
+            const int qs = p.mode == 0 ? (q >> p.ups) : q;
             if (sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
-                x_voff[it] = (unsigned)(((b * p.Csrc + g * p.C2_g + cg * 8) * p.Tsrc + (p.mode == 0 ? (q >> p.ups) : q)) * 4);
+                x_voff[it] = (unsigned)(((b * p.Csrc + g * p.C2_g + cg * 8) * p.Tsrc + qs) * 4);
+            if constexpr (XV) x_nv[it] = p.Tsrc - qs;
         }
     }
     // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece; piece = (tap * NCB + cb) * BM + m.  The bf16 weights
@@ -228,9 +237,16 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             if (it < h.xit && x_lds[it] >= 0 && !HB_DBG(8)) {                                                 \
                 if constexpr (XV) {                                                                             \
                     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                          \
-                        const u32x4 v_ = {pack_bf16x2(xv[it][0][s4], xv[it][1][s4], relu), pack_bf16x2(xv[it][2][s4], xv[it][3][s4], relu), \
-                                          pack_bf16x2(xv[it][4][s4], xv[it][5][s4], relu), pack_bf16x2(xv[it][6][s4], xv[it][7][s4], relu)}; \
-                        *(u32x4*)(Xd_ + x_lds[it] + s4 * 16) = v_;                                              \
+                        u32x4 v_ = {pack_bf16x2(xv[it][0][s4], xv[it][1][s4], relu), pack_bf16x2(xv[it][2][s4], xv[it][3][s4], relu), \
+                                    pack_bf16x2(xv[it][4][s4], xv[it][5][s4], relu), pack_bf16x2(xv[it][6][s4], xv[it][7][s4], relu)}; \
+                        /* the row ends inside the load (ragged rows): the rest belongs to the next row */      \
+                        if (s4 > 0 && s4 >= x_nv[it]) v_ = u32x4{0u, 0u, 0u, 0u};                               \
+                        if (xsh == 3) {               /* nearest x2: source position s4 -> slots 2 s4, 2 s4 + 1 */ \
+                            *(u32x4*)(Xd_ + x_lds[it] + s4 * 32) = v_;                                          \
+                            *(u32x4*)(Xd_ + x_lds[it] + s4 * 32 + 16) = v_;                                     \
+                        } else {                                                                                \
+                            *(u32x4*)(Xd_ + x_lds[it] + s4 * 16) = v_;                                          \
+                        }                                                                                       \
                     }                                                                                           \
                 } else {                                                                                        \
                     const u32x4 v_ = {pack_bf16x2(xr[it][0], xr[it][1], relu), pack_bf16x2(xr[it][2], xr[it][3], relu), \
@@ -488,8 +504,19 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #undef HSTAMP
 }
 
+// Two 512-thread blocks per CU need 4 waves per SIMD: 128 VGPRs.  Left to itself hipcc gives the 4-byte-load variants
+// 135-141 and the 128 x 128 tile 129-131 registers (ONE block per CU); told the target it fits 128 with no VGPR spill.
+#ifndef STEGAN_BF16_WAVES
+#define STEGAN_BF16_WAVES 4
+#endif
+#if STEGAN_BF16_WAVES > 0
+#define HB_OCC __attribute__((amdgpu_waves_per_eu(STEGAN_BF16_WAVES, STEGAN_BF16_WAVES)))
+#else
+#define HB_OCC
+#endif
+
 template <int TM, int TN, int LOGNCB, bool XV>
-__global__ __launch_bounds__(512) void conv_bf16_kernel(const HP h) {
+__global__ __launch_bounds__(512) HB_OCC void conv_bf16_kernel(const HP h) {
     conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, gridDim.x, 0);
 }
 
@@ -504,7 +531,7 @@ struct MultiH {
 static_assert(sizeof(MultiH) <= 4096, "kernel argument segment limit");
 
 template <int TM, int TN, int LOGNCB, bool XV>
-__global__ __launch_bounds__(512) void conv_bf16_multi_kernel(const MultiH a) {
+__global__ __launch_bounds__(512) HB_OCC void conv_bf16_multi_kernel(const MultiH a) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < HMULTI; ++i)
@@ -620,11 +647,21 @@ void fill_prep(PrepH& t, const stegan_conv_desc* d) {
     t.nb = (long)t.G * (t.K + 1) * t.Mb * t.Cb;
 }
 
+// 16-byte X loads: float4-aligned rows (the forward's upsample included).  Rows that are NOT float4-aligned can take them
+// too (a dwordx4 load needs dword alignment only; the load straddling a row's end has its tail zeroed) -- built, parity
+// green, and measured 1 % SLOWER on the train step (the period discriminators' rows: misaligned 16-byte loads split in
+// the memory pipeline), so it is opt-in: STEGAN_BF16_XVRAG=1.  Experiment switches back to the first version's 4-byte
+// loads: STEGAN_BF16_NO_XV (all), STEGAN_BF16_NO_XVUP (the forward's upsample).
+bool xv_eligible(int Tsrc, const void* src, bool fwd_ups) {
+    if (getenv("STEGAN_BF16_NO_XV") || (fwd_ups && getenv("STEGAN_BF16_NO_XVUP"))) return false;
+    return (Tsrc % 4 == 0 && ((uintptr_t)src % 16) == 0) || getenv("STEGAN_BF16_XVRAG");
+}
+
 struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, NG, ntW, xit, wit, span; size_t lds; bool ok; };
 
 // geometry for one (TM, TN): the largest channel chunk whose tiles fit (cch_max caps it: experiments)
 GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_max, int cs, int U, int U_min, bool xv,
-               int cch_max) {
+               int cch_max, int xgran = 4) {
     GeoH gm;
     gm.ok = false; gm.TM = TM; gm.TN = TN;
     const int BM = 64 * TM, BN = 64 * TN;
@@ -638,14 +675,14 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
         const int span = NCB == 1 ? span_taps + (ntW - ntaps_max) * step_max : span_taps;   // the dead tap reads real rows
         const int UT = U < BN ? U : BN;
         int SEG = (UT - 1) * cs + span + 1;
-        if (xv) SEG = (SEG + 3 + 3) & ~3;                // up to 3 slots of down-rounding, whole groups of 4
+        if (xv) SEG = (SEG + 2 * (xgran - 1)) & ~(xgran - 1);   // up to xgran - 1 slots of down-rounding, whole items
         int NSEG = 1;
         for (int uu = (U_min < 1 ? 1 : U_min); uu <= U; ++uu) {
             const int ns = (uu % BN == 0) ? 1 : ((BN + uu - 2) / uu + 1);
             if (ns > NSEG) NSEG = ns;
         }
         const int XROW = SEG * NSEG;
-        const int NG = xv ? XROW / 4 : XROW;
+        const int NG = xv ? XROW / xgran : XROW;
         const int xit = ceil_div(NCB * NG, 256), wit = ceil_div(ntW * BM * NCB, 256);
         if (xit > (xv ? HXV_MAX : HX_MAX) || wit > HW_MAX) continue;
         const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)XROW * NCB * 16);       // W ring of 2, X ring of 2
@@ -740,9 +777,8 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     }
     if (ntaps_max > MAX_TAPS || phases > MAX_PHASES) return 1;
     const long N = (long)d->B * U;
-    // 16-byte X loads need float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
-    const bool xv = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
-                    !getenv("STEGAN_BF16_NO_XV") && (!mc || mc->xv);
+    const bool xv = mc ? mc->xv : xv_eligible(p.Tsrc, p.src, mode == 0 && p.ups);
+    const int xgran = (mode == 0 && p.ups) ? 8 : 4;               // slots per 16-byte X item
     // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the
     // graph-timed microbenchmark (scripts/bf16_stamps.py, scripts/bf16_microbench.py) on the hot-path layers:
     //   block time   = 5 (index setup + epilogue) + chunks x (0.35 + staged bytes per chunk / 68 KB per us): an iteration is
@@ -768,7 +804,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         if (mc && mc->mh.n > 0 && (tm != mc->TM || tn != mc->TN)) continue;
         if (mc && tm == 2 && tn == 2) continue;                      // (keeps the (2,2) variants out of the multi kernels)
         if (tm == 2 && p.M_g <= 64) continue;
-        const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max);
+        const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max, xgran);
         if (!g2.ok) continue;
         if (mc && mc->mh.n > 0 && g2.logNCB != mc->logNCB) continue;
         const int cch = 8 << g2.logNCB, nch = ceil_div(p.C2_g, cch);
@@ -970,7 +1006,7 @@ extern "C" int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* cons
     MultiCollectH mc;
     mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
     for (int i = 0; i < n; ++i)
-        if (!descs[i] || descs[i]->Tin % 4 != 0 || descs[i]->upsample != 1 || ((uintptr_t)x[i] % 16) != 0) mc.xv = false;
+        if (!descs[i] || descs[i]->upsample != 1 || !xv_eligible(descs[i]->Tin, x[i], false)) mc.xv = false;   // (one granule per launch)
     for (int i = 0; i < n; ++i) {
         const stegan_conv_desc* d = descs[i];
         int rc = check_desc(d);
@@ -1002,7 +1038,7 @@ extern "C" int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc*
     MultiCollectH mc;
     mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
     for (int i = 0; i < n; ++i)
-        if (!descs[i] || descs[i]->Tout % 4 != 0 || ((uintptr_t)dy[i] % 16) != 0) mc.xv = false;
+        if (!descs[i] || !xv_eligible(descs[i]->Tout, dy[i], false)) mc.xv = false;
     for (int i = 0; i < n; ++i) {
         const stegan_conv_desc* d = descs[i];
         int rc = check_desc(d);

@@ -19,7 +19,14 @@ EXTRA = [
     (8, 384, 256, 1, 1, 1, 0, 1, 1, False, 96),      # K = 1, 64-channel chunks
     (4, 136, 200, 5, 1, 1, 2, 1, 1, False, 40),      # ragged channels: 136 = 2 chunks of 64 + 8, 200 rows
     (16, 64, 64, 3, 1, 1, 1, 1, 1, False, 12),       # short rows: a tile spans many batch segments
+    (16, 64, 64, 3, 1, 1, 1, 1, 2, True, 12),        # upsample with 16-byte loads (8 slots per item), many batch segments
+    (6, 72, 48, 5, 1, 3, 6, 1, 2, False, 20),        # upsample, dilated 5 taps, ragged channels, Tq = 40
+    (6, 32, 48, 3, 1, 1, 1, 1, 2, True, 18),         # upsample whose rows are not float4-aligned
+    (10, 32, 128, 5, 3, 1, 2, 1, 1, False, 2731),    # period discriminator rows
+    (6, 128, 256, 3, 1, 1, 1, 1, 1, True, 61),       # ragged rows, a tile spans several batch elements
+    (7, 64, 64, 3, 1, 3, 3, 1, 1, False, 13),        # ... short ragged rows, dilated
 ]
+RAGGED = [c for c in CASES + EXTRA if c[10] % 4 != 0 and c[1] // c[7] >= 8 and c[2] // c[7] >= 8]
 
 
 def bf16r(t):
@@ -87,6 +94,13 @@ def test_conv_bf16_fwd_bwd_data(cfg):
             assert float((got - f32).abs().max()) <= 3e-2 * scale_
         else:                                             # shape left to the exact fp32 kernel
             assert float((got - f32).abs().max()) <= 2e-5 * scale_
+
+
+@pytest.mark.parametrize("cfg", RAGGED, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16_ragged_rows_with_16_byte_loads(cfg, monkeypatch):
+    """The opt-in STEGAN_BF16_XVRAG path (dwordx4 loads at dword alignment, the row's tail zeroed): same parity bar."""
+    monkeypatch.setenv("STEGAN_BF16_XVRAG", "1")
+    test_conv_bf16_fwd_bwd_data(cfg)
 
 
 @pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))

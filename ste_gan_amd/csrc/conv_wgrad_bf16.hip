@@ -72,11 +72,18 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* a0, int d1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TM, int TN, int KT, bool XV>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
+// SIV: staging items per thread and operand with 16-byte loads.  Long rows (T >= 64: one batch element per chunk) need ONE
+// item each; that variant holds 64 staging registers less and is told to fit two blocks per CU (amdgpu_waves_per_eu: a
+// block is one wave per SIMD), where the two-item variant -- short rows, several batch elements and their halos per
+// chunk -- runs one block per CU (its LDS images do not fit twice either).
+#ifndef STEGAN_WGRAD_WAVES
+#define STEGAN_WGRAD_WAVES 2
+#endif
+template <int TM, int TN, int KT, bool XV, int SIV>
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
     constexpr int BM = 64 * TM, BN = 64 * TN;          // co x ci tile of the block
     constexpr int CBA = BM / 8, CBX = BN / 8;          // channel-block planes of the two images
-    constexpr int SI = XV ? WSV_MAX : WS_MAX;
+    constexpr int SI = XV ? SIV : WS_MAX;
     extern __shared__ __align__(16) char smem[];       // dy image 0 | x image 0 | dy image 1 | x image 1
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
                 for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
 
     float ar[XV ? 1 : WS_MAX][8], xr[XV ? 1 : WS_MAX][8];
-    f32x4 av[XV ? WSV_MAX : 1][8], xv[XV ? WSV_MAX : 1][8];
+    f32x4 av[XV ? SIV : 1][8], xv[XV ? SIV : 1][8];
     const int rowb_y = h.Tout * 4, rowb_x = h.Tin * 4;
     const int ylim = h.Cout_g - co0, xlim = h.Cin_g - ci0;       // live channels of the tiles
     int adj_cur = 0, adj_nxt = 0;                                 // down-rounding of the x window start (XV)
@@ -278,6 +285,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
     }
 }
 
+template <int TM, int TN, int KT, bool XV>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
+    conv_wgrad_bf16_body<TM, TN, KT, XV, WSV_MAX>(h);
+}
+
+#if STEGAN_WGRAD_WAVES > 0
+#define WG_OCC __attribute__((amdgpu_waves_per_eu(STEGAN_WGRAD_WAVES, STEGAN_WGRAD_WAVES)))
+#else
+#define WG_OCC
+#endif
+template <int TM, int TN, int KT>
+__global__ __launch_bounds__(256) WG_OCC void conv_wgrad_bf16_one_kernel(const WH h) {
+    conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h);
+}
+
 // dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
 // The bias gradient rides in the same launch: blocks past the first `rb` are bias_grad_body (channel, batch slice) blocks
 // over the fp32 dy (one launch less per layer: 52 a step).
@@ -324,9 +346,13 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h) {
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_one_kernel<TM, TN, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(256), lds, s, h);
+    static const bool no_one = getenv("STEGAN_BF16_WGRAD_NO_ONE") != nullptr;       // experiments
+    if (xv && h.ait <= 1 && h.xit <= 1 && !no_one)
+        hipLaunchKernelGGL((conv_wgrad_bf16_one_kernel<TM, TN, KT>), grid, dim3(256), lds, s, h);
+    else if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(256), lds, s, h);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(256), lds, s, h);
 }
 

@@ -111,7 +111,10 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)h.dy, 0, (int)h.dy_bytes, 0x00020000);
     const bool relu = h.relu != 0;
 
-    // ---- staging items (chunk invariant part): item = (channel block, slot or run of 4 slots), slots fastest
+    // ---- staging items (chunk invariant part): item = (channel block, slot or run of 4 slots), slots fastest.  With the
+    // nearest-x2 upsample one 16-byte load of 4 source positions of x feeds 8 slots (as in conv_bf16.hip)
+    const int xsh = XV ? 2 + h.ups : 0;
+    const int xgm = (1 << xsh) - 1;
     int a_cg[SI], a_seg[SI], a_uu[SI], a_lds[SI];       // dy: plane, batch element within the chunk, position, LDS byte (-1: none)
     int x_cg[SI], x_seg[SI], x_sl[SI], x_lds[SI];
 #pragma unroll
@@ -126,7 +129,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
         }
         {
             const int cg = (int)fd_div((uint32_t)idx, h.fdNGX), grp = idx - cg * h.NGX;
-            const int slot = XV ? grp * 4 : grp;
+            const int slot = XV ? (grp << xsh) : grp;
             const int seg = (int)fd_div((uint32_t)slot, h.fdSEG);
             x_cg[it] = cg; x_seg[it] = seg; x_sl[it] = slot - seg * h.SEG;
             x_lds[it] = (it < h.xit && cg < CBX) ? (cg * h.RSX + slot) * 16 : -1;
@@ -175,7 +178,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
         const int bc_ = (int)fd_div((uint32_t)(c_), h.fdUC), uc_ = (c_) - bc_ * h.u_chunks;                     \
         const int b0_ = b_begin + bc_ * h.NB, u0_ = uc_ * h.RU;                                                 \
         const int q0_ = u0_ * h.stride - h.pad + kk0 * h.dil;                                                   \
-        const int qal_ = XV ? (q0_ & ~3) : q0_;                                                                 \
+        const int qal_ = XV ? (q0_ & ~xgm) : q0_;                                                               \
         adj_out = q0_ - qal_;                                                                                   \
         _Pragma("unroll") for (int it = 0; it < SI; ++it) {                                                     \
             if (it < h.ait) {                                                                                   \
@@ -200,12 +203,17 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
             }                                                                                                   \
         }                                                                                                       \
     }
-#define WG_STORE_ONE(dst_, lds_, r_, v_, relu_)                                                                 \
+#define WG_STORE_ONE(dst_, lds_, r_, v_, relu_, dup_)                                                           \
     if constexpr (XV) {                                                                                         \
         _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                      \
             const u32x4 w_ = {wpack(v_[0][s4], v_[1][s4], relu_), wpack(v_[2][s4], v_[3][s4], relu_),            \
                               wpack(v_[4][s4], v_[5][s4], relu_), wpack(v_[6][s4], v_[7][s4], relu_)};           \
-            *(u32x4*)(dst_ + lds_ + s4 * 16) = w_;                                                              \
+            if (dup_) {                               /* nearest x2: source position s4 -> slots 2 s4, 2 s4 + 1 */ \
+                *(u32x4*)(dst_ + lds_ + s4 * 32) = w_;                                                          \
+                *(u32x4*)(dst_ + lds_ + s4 * 32 + 16) = w_;                                                     \
+            } else {                                                                                            \
+                *(u32x4*)(dst_ + lds_ + s4 * 16) = w_;                                                          \
+            }                                                                                                   \
         }                                                                                                       \
     } else {                                                                                                    \
         const u32x4 w_ = {wpack(r_[0], r_[1], relu_), wpack(r_[2], r_[3], relu_), wpack(r_[4], r_[5], relu_), wpack(r_[6], r_[7], relu_)}; \
@@ -216,8 +224,8 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
         char* A_ = smem + (buf_) * bufsz;                                                                       \
         char* X_ = A_ + abuf;                                                                                   \
         _Pragma("unroll") for (int it = 0; it < SI; ++it) {                                                     \
-            if (it < h.ait && a_lds[it] >= 0) { WG_STORE_ONE(A_, a_lds[it], ar[XV ? 0 : it], av[XV ? it : 0], false) } \
-            if (it < h.xit && x_lds[it] >= 0) { WG_STORE_ONE(X_, x_lds[it], xr[XV ? 0 : it], xv[XV ? it : 0], relu) }  \
+            if (it < h.ait && a_lds[it] >= 0) { WG_STORE_ONE(A_, a_lds[it], ar[XV ? 0 : it], av[XV ? it : 0], false, false) } \
+            if (it < h.xit && x_lds[it] >= 0) { WG_STORE_ONE(X_, x_lds[it], xr[XV ? 0 : it], xv[XV ? it : 0], relu, xsh == 3) }  \
         }                                                                                                       \
     }
 
@@ -388,8 +396,9 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     else { KT = 8; TM = 1; TN = 1; }
     h.NTG = ceil_div(h.K_eff, KT);
     const int BM = 64 * TM, BN = 64 * TN;
-    const bool xv = h.Tin % 4 == 0 && h.Tout % 4 == 0 && h.ups == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
-                    !getenv("STEGAN_BF16_NO_XV");
+    const bool xv = h.Tin % 4 == 0 && h.Tout % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+                    !getenv("STEGAN_BF16_NO_XV") && !(h.ups && getenv("STEGAN_BF16_NO_XVUP"));
+    const int xg = 4 << h.ups;                           // x slots per 16-byte item
     // chunk of the reduction: up to RMAX columns (LDS budget / halo share), whole batch elements when the rows are short
     static const char* env_r = getenv("STEGAN_BF16_WGRAD_R");
     const int RMAX = env_r ? atoi(env_r) : 64;
@@ -402,17 +411,17 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     if (h.NST > NST_MAX) return 1;
     h.u_chunks = ceil_div(h.Tout, h.RU);
     h.SEG = (h.RUp - 1) * h.stride + (KT - 1) * h.dil + 1;
-    if (xv) h.SEG = (h.SEG + 3 + 3) & ~3;
+    if (xv) h.SEG = (h.SEG + 2 * (xg - 1)) & ~(xg - 1);
     // columns of the last k-step past NB * RUp belong to "batch element NB": its slots must exist (they hold zeros)
     const int segs = ceil_div(h.R, h.RUp);
     auto pad4 = [](int v) { int r = v % 16; return v + ((4 - r) + 16) % 16; };     // slots = 4 (mod 16): conflict-free reads
     // staged slots: the R columns of dy; for x the segments plus up to 3 slots of down-rounding and the reach of the last
     // transposed read; the planes are then padded (never staged, never read) to the conflict-free pitch
-    const int xslots = round_up(segs * h.SEG + 4, 4);
+    const int xslots = xv ? round_up(segs * h.SEG + xg, xg) : round_up(segs * h.SEG + 4, 4);
     h.RSA = pad4(h.R);
     h.RSX = pad4(xslots);
     h.NGA = xv ? h.R / 4 : h.R;
-    h.NGX = xv ? xslots / 4 : xslots;
+    h.NGX = xv ? xslots / xg : xslots;
     h.ait = ceil_div((BM / 8) * h.NGA, 256);
     h.xit = ceil_div((BN / 8) * h.NGX, 256);
     if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return 1;

@@ -75,11 +75,11 @@ class WNConv1d(nn.Module):
             self._prep = (stamp, (scale, bufs[0], bufs[1]))
         return self._prep[1]
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, hand=None):
         sink = None
         if self._pack is not None and torch.is_grad_enabled() and self.weight_v.requires_grad:
             sink = (self._pack[4], self.bias.grad)          # raw dw slice, bias-gradient view
-        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared(), sink)
+        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared(), sink, hand)
 
     def extra_repr(self):
         return str(self.cfg)
@@ -125,11 +125,21 @@ class GBlock(nn.Module):
 
     def forward(self, x):
         o = self._o
-        h = self.conv1[1 + o](x)
-        r = self.res1[o](x)
+        if not (ops.HANDOVER and torch.is_grad_enabled() and x.requires_grad):
+            h = self.conv1[1 + o](x)
+            r = self.res1[o](x)
+            y = self.conv1[3 + o](h, residual=r)
+            h = self.conv2[1](y)
+            return self.conv2[3](h, residual=y)
+        # x and y each feed two nodes: their gradients are summed inside the input-gradient kernels (ops.GradHandover)
+        # instead of by two autograd adds per block.  Backward order: conv_d27 (parks d out for y) -> conv_d9 (takes) ->
+        # conv_d3 -> res1 (parks its unfolded dx) -> conv_d1 (takes, folds the upsample once).
+        hx, hy = ops.GradHandover(), ops.GradHandover()
+        h = self.conv1[1 + o](x, hand=(ops.TAKE, hx))
+        r = self.res1[o](x, hand=(ops.PARK_DX, hx))
         y = self.conv1[3 + o](h, residual=r)
-        h = self.conv2[1](y)
-        return self.conv2[3](h, residual=y)
+        h = self.conv2[1](y, hand=(ops.TAKE, hy))
+        return self.conv2[3](h, residual=y, hand=(ops.PARK_RES, hy))
 
 
 class SNConv1d(nn.Module):

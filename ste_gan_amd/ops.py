@@ -458,12 +458,33 @@ def fold_upsample2(dxe: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------
 # autograd: weight-normalised fused conv
 # ---------------------------------------------------------------------------------------------
+# ---- gradient hand-over at a fan-out point inside a block ------------------------------------------------------------
+# In a GBlock the block input feeds two convs (the main path and the 1x1 residual conv) and the middle activation feeds a
+# conv and, as identity residual, the last conv's epilogue.  Autograd would receive two gradients for each of those tensors
+# and add them with a launch of its own (16 a step, on the generator backward's critical path).  Instead the backward
+# node that runs FIRST parks its contribution here and returns None, and the node that runs second passes the parked
+# tensor to its input-gradient kernel as ``add`` (the kernels add it after the ReLU mask -- exactly the sum autograd would
+# form).  Both orders are right: a parker that finds the taker already done returns its gradient the ordinary way.
+HANDOVER = os.environ.get("STEGAN_GRAD_HANDOVER", "1") != "0"
+PARK_DX, PARK_RES, TAKE = 1, 2, 3
+
+
+class GradHandover:
+    __slots__ = ("parked", "taken")
+
+    def __init__(self):
+        self.parked = None
+        self.taken = False
+
+
 class _WNConvFn(torch.autograd.Function):
-    """y = out_act( (g/||v||)[co] * (v (*) in_act(up(x))) + bias + residual ) with hand-written backward."""
+    """y = out_act( (g/||v||)[co] * (v (*) in_act(up(x))) + bias + residual ) with hand-written backward.
+    ``hand`` = (PARK_DX | PARK_RES | TAKE, GradHandover) or None: see the gradient hand-over above."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None):
+    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None):
         ctx.sink = sink
+        ctx.hand = hand
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         if prepared is None:
             scale, wf, wb = wn_scale(v, g), None, None
@@ -492,9 +513,20 @@ class _WNConvFn(torch.autograd.Function):
             dy = act_bwd(dy, y, cfg.out_act, None if cfg.out_btc else _fm_take(y))
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         dx = dv = dg = db = dres = None
+        role, hand = ctx.hand if ctx.hand is not None else (0, None)
         if ctx.needs_input_grad[0]:
-            dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, None, cfg, x.shape[2], ctx.wb)
-            dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
+            add = None
+            if role == TAKE:
+                hand.taken = True
+                add, hand.parked = hand.parked, None
+                if add is not None and (add.shape[0] != x.shape[0] or add.shape[1] != cfg.cin
+                                        or add.shape[2] != x.shape[2] * cfg.upsample or not add.is_contiguous()):
+                    raise RuntimeError("ste_gan_amd: parked gradient does not match the taker's input gradient")
+            dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, add, cfg, x.shape[2], ctx.wb)
+            if role == PARK_DX and not hand.taken:
+                hand.parked = dxe                    # at the upsampled resolution: the taker folds the sum once
+            else:
+                dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
         if ctx.sink is not None and ctx.needs_input_grad[1]:
             # fused mode: accumulate the raw gradients into the network's arenas; (dv, dg) follow in ConvPack.finalize_grads.
             _sink_touch()
@@ -511,8 +543,11 @@ class _WNConvFn(torch.autograd.Function):
             dv = dv.view_as(v)
             dg = dg.view_as(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
-            dres = dy
-        return dx, dv, dg, db, dres, None, None, None
+            if role == PARK_RES and not hand.taken and dy.is_contiguous():
+                hand.parked = dy
+            else:
+                dres = dy
+        return dx, dv, dg, db, dres, None, None, None, None
 
 
 def _ptr_array(items):
@@ -643,10 +678,11 @@ def wn_conv1d_multi(xs, convs):
     return list(_WNConvMultiFn.apply(layers, len(xs), *xs, *params))
 
 
-def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None) -> Tensor:
+def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None) -> Tensor:
     """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None;
-    sink = (raw dw arena slice, bias-gradient view) switches the backward to fused accumulation (optim.ConvPack)."""
-    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink)
+    sink = (raw dw arena slice, bias-gradient view) switches the backward to fused accumulation (optim.ConvPack);
+    hand = (role, GradHandover): this conv's part in a gradient hand-over (GBlock)."""
+    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink, hand)
 
 
 def act_bwd(dy: Tensor, y: Tensor, act: int, add: Optional[Tensor] = None) -> Tensor:

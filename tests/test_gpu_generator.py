@@ -71,3 +71,38 @@ def test_whole_utterance_generation_at_batch_one(T_su, ch):
     solo = g.generate_from_data_dict(item, torch.device("cuda"))
     assert solo.device.type == "cpu" and solo.shape == (16 * T_su, 8)
     torch.testing.assert_close(solo, out[0].cpu(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("up", [1, 2])
+def test_gblock_gradient_handover_equals_autograd_accumulation(up, dtype, monkeypatch):
+    """GBlock backward with the two fan-out sums formed inside the input-gradient kernels (ops.GradHandover) against the
+    same block with autograd adding the two gradients of x and of y: same operands, same fp32 additions."""
+    from ste_gan_amd import ops
+    from ste_gan_amd.layers.conv import GBlock
+    torch.manual_seed(3)
+    blk = GBlock(48, 32 if up == 2 else 48, upsample=up).cuda()
+    x0 = torch.randn(5, 48, 24, device="cuda")
+    dy = torch.randn(5, 32 if up == 2 else 48, 24 * up, device="cuda")
+    ops.set_compute_dtype(dtype)
+    try:
+        res = {}
+        for on in (True, False):
+            monkeypatch.setattr(ops, "HANDOVER", on)
+            x = x0.clone().requires_grad_(True)
+            blk.zero_grad(set_to_none=True)
+            y = blk(x)
+            y.backward(dy)
+            res[on] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+    finally:
+        ops.set_compute_dtype("f32")
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-9
+    # second backward through a retained graph: the hand-over objects are spent, the parkers return their gradients
+    monkeypatch.setattr(ops, "HANDOVER", True)
+    x = x0.clone().requires_grad_(True)
+    y = blk(x)
+    (g1,) = torch.autograd.grad(y, x, dy, retain_graph=True)
+    (g2,) = torch.autograd.grad(y, x, dy)
+    assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())

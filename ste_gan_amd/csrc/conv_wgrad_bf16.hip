@@ -401,32 +401,44 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     const int xg = 4 << h.ups;                           // x slots per 16-byte item
     // chunk of the reduction: up to RMAX columns (LDS budget / halo share), whole batch elements when the rows are short
     static const char* env_r = getenv("STEGAN_BF16_WGRAD_R");
-    const int RMAX = env_r ? atoi(env_r) : 64;
-    h.RU = h.Tout < RMAX ? h.Tout : RMAX;
-    h.RUp = round_up(h.RU, 4);
-    h.NB = h.RUp < RMAX ? RMAX / h.RUp : 1;
-    if (h.NB > h.B) h.NB = h.B;
-    h.R = round_up(h.NB * h.RUp, 16);
-    h.NST = h.R / 16;
-    if (h.NST > NST_MAX) return 1;
-    h.u_chunks = ceil_div(h.Tout, h.RU);
-    h.SEG = (h.RUp - 1) * h.stride + (KT - 1) * h.dil + 1;
-    if (xv) h.SEG = (h.SEG + 2 * (xg - 1)) & ~(xg - 1);
-    // columns of the last k-step past NB * RUp belong to "batch element NB": its slots must exist (they hold zeros)
-    const int segs = ceil_div(h.R, h.RUp);
+    const int RMAX0 = env_r ? atoi(env_r) : 64;
+    size_t lds = 0;
     auto pad4 = [](int v) { int r = v % 16; return v + ((4 - r) + 16) % 16; };     // slots = 4 (mod 16): conflict-free reads
-    // staged slots: the R columns of dy; for x the segments plus up to 3 slots of down-rounding and the reach of the last
-    // transposed read; the planes are then padded (never staged, never read) to the conflict-free pitch
-    const int xslots = xv ? round_up(segs * h.SEG + xg, xg) : round_up(segs * h.SEG + 4, 4);
-    h.RSA = pad4(h.R);
-    h.RSX = pad4(xslots);
-    h.NGA = xv ? h.R / 4 : h.R;
-    h.NGX = xv ? xslots / xg : xslots;
-    h.ait = ceil_div((BM / 8) * h.NGA, 256);
-    h.xit = ceil_div((BN / 8) * h.NGX, 256);
-    if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return 1;
-    const size_t lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
-    if (lds > 160 * 1024) return 1;
+    auto plan = [&](int RMAX) -> bool {
+        h.RU = h.Tout < RMAX ? h.Tout : RMAX;
+        h.RUp = round_up(h.RU, 4);
+        h.NB = h.RUp < RMAX ? RMAX / h.RUp : 1;
+        if (h.NB > h.B) h.NB = h.B;
+        h.R = round_up(h.NB * h.RUp, 16);
+        h.NST = h.R / 16;
+        if (h.NST > NST_MAX) return false;
+        h.u_chunks = ceil_div(h.Tout, h.RU);
+        h.SEG = (h.RUp - 1) * h.stride + (KT - 1) * h.dil + 1;
+        if (xv) h.SEG = (h.SEG + 2 * (xg - 1)) & ~(xg - 1);
+        // columns of the last k-step past NB * RUp belong to "batch element NB": its slots must exist (they hold zeros)
+        const int segs = ceil_div(h.R, h.RUp);
+        // staged slots: the R columns of dy; for x the segments plus the slots of down-rounding and the reach of the last
+        // transposed read; the planes are then padded (never staged, never read) to the conflict-free pitch
+        const int xslots = xv ? round_up(segs * h.SEG + xg, xg) : round_up(segs * h.SEG + 4, 4);
+        h.RSA = pad4(h.R);
+        h.RSX = pad4(xslots);
+        h.NGA = xv ? h.R / 4 : h.R;
+        h.NGX = xv ? xslots / xg : xslots;
+        h.ait = ceil_div((BM / 8) * h.NGA, 256);
+        h.xit = ceil_div((BN / 8) * h.NGX, 256);
+        if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return false;
+        lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
+        return lds <= 160 * 1024;
+    };
+    if (!plan(RMAX0)) return 1;
+    // short rows with wide halos (T = 12, d = 3 | 9: five batch elements and their halos per chunk) need two x items per
+    // thread and 93 KB of LDS: one block per CU.  Half the chunk fits the one-item variant and twice on a CU
+    static const bool no_half = getenv("STEGAN_BF16_WGRAD_NO_HALF") != nullptr;      // experiments
+    if (xv && !no_half && !env_r && (h.ait > 1 || h.xit > 1)) {
+        const WH keep = h;
+        const size_t keep_lds = lds;
+        if (!(plan(RMAX0 / 2) && h.ait <= 1 && h.xit <= 1 && lds <= 80 * 1024)) { h = keep; lds = keep_lds; }
+    }
     h.co_tiles = ceil_div(h.Cout_g, BM); h.ci_tiles = ceil_div(h.Cin_g, BN);
     const long tiles = (long)h.co_tiles * h.ci_tiles * d->groups * h.NTG;
     // slices of the batch: fill the chip (two blocks per CU), bounded by the workspace and by one chunk per slice

@@ -25,6 +25,8 @@ EXTRA = [
     (10, 32, 128, 5, 3, 1, 2, 1, 1, False, 2731),    # period discriminator rows
     (6, 128, 256, 3, 1, 1, 1, 1, 1, True, 61),       # ragged rows, a tile spans several batch elements
     (7, 64, 64, 3, 1, 3, 3, 1, 1, False, 13),        # ... short ragged rows, dilated
+    (16, 64, 64, 3, 1, 9, 9, 1, 1, True, 12),        # short rows, wide halos: the wgrad's half-chunk plan (one-item variant)
+    (10, 128, 128, 3, 1, 3, 3, 1, 1, True, 12),      # ... d = 3, 128-row co tile
 ]
 RAGGED = [c for c in CASES + EXTRA if c[10] % 4 != 0 and c[1] // c[7] >= 8 and c[2] // c[7] >= 8]
 

@@ -12,7 +12,7 @@ def per_kernel(d, counter):
             continue
         n = r["Kernel_Name"]
         fam = ("conv_bf16_kernel" if ("conv_bf16_kernel" in n or "conv_bf16_multi_kernel" in n) else
-               "conv_wgrad_bf16_kernel" if "conv_wgrad_bf16_kernel" in n else
+               "conv_wgrad_bf16_kernel" if ("conv_wgrad_bf16_kernel" in n or "conv_wgrad_bf16_one_kernel" in n) else
                "conv_direct_kernel" if "conv_direct_kernel" in n else "conv_wgrad_kernel" if "conv_wgrad_kernel" in n else
                "conv_igemm_kernel<2>" if "conv_igemm_kernel<2" in n else "conv_splitk_epilogue_kernel" if "splitk_epilogue" in n
                else "conv_cout1_kernels" if "conv_cout1" in n else "assemble_batch_kernel" if "assemble_batch" in n else None)

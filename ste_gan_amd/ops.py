@@ -383,7 +383,7 @@ def wgrad_async(on: bool) -> None:
 
 F32_STREAMS = os.environ.get("STEGAN_F32_STREAMS", "1") == "1"      # the discriminator fork and the generator's weight-gradient
                                                                      # streams in fp32 mode too: 19.2 -> 17.1 ms/step
-WGRAD_BATCH = int(os.environ.get("STEGAN_WGRAD_BATCH", "3"))        # weight gradients launched per fork (8.71 ms/step; 9.01 with 1, 8.80 with 2, 8.78 with 4, 8.82 with 6)
+WGRAD_BATCH = int(os.environ.get("STEGAN_WGRAD_BATCH", "5"))        # weight gradients launched per fork (8.14 ms/step; 8.30 with 1, 8.21 with 2, 8.17 with 3, 8.16 with 4, 8.20 with 8)
 _WG_PENDING: list = []
 
 

@@ -441,11 +441,16 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     }
     h.co_tiles = ceil_div(h.Cout_g, BM); h.ci_tiles = ceil_div(h.Cin_g, BN);
     const long tiles = (long)h.co_tiles * h.ci_tiles * d->groups * h.NTG;
-    // slices of the batch: fill the chip (two blocks per CU), bounded by the workspace and by one chunk per slice
+    // slices of the batch: about 128 blocks per launch, bounded by the workspace and by one chunk per slice.  Every slice
+    // costs a slab written and read back (7 MB for a 768 x 768 x 3 layer) and the weight gradients run beside other streams
+    // (the generator's backward chain, the other discriminators), so HALF a chip of longer blocks beats two blocks per CU:
+    // train step 8.37 / 8.09 / 7.95 / 7.85 / 7.92 ms for a target of 1024 / 512 / 256 / 128 / 64 blocks (10.4 unsliced)
     const int64_t slab = (int64_t)h.K_eff * h.Cout * h.Cin_g;
     if (!workspace || workspace_floats < slab) return 1;
     const int b_chunks = ceil_div(h.B, h.NB);
-    long want = (512 + tiles - 1) / tiles;
+    static const char* env_t = getenv("STEGAN_BF16_WGRAD_TARGET");       // blocks to aim for (experiments)
+    const long target = env_t ? atol(env_t) : 128;
+    long want = (target + tiles - 1) / tiles;
     if (const char* es = getenv("STEGAN_BF16_WGRAD_SLICES")) want = atol(es);
     if (want > b_chunks) want = b_chunks;
     if (want > workspace_floats / slab) want = workspace_floats / slab;

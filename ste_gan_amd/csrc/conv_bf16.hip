@@ -810,7 +810,8 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         const int cch = 8 << g2.logNCB, nch = ceil_div(p.C2_g, cch);
         const long blocks1 = ceil_div(p.M_g, 64 * tm) * (long)d->groups * phases * ((N + 64 * tn - 1) / (64 * tn));
         const double bytes = (double)g2.ntW * 64 * tm * cch * 2 + (double)g2.XROW * cch * 4;
-        const bool pair = g2.lds <= 80 * 1024 && !(tm == 2 && tn == 2);
+        static const char* env_p22 = getenv("STEGAN_BF16_PAIR22");
+        const bool pair = g2.lds <= 80 * 1024 && (!(tm == 2 && tn == 2) || (env_p22 && atoi(env_p22)));
         for (int sp = 1; sp <= (max_splits < nch ? max_splits : nch); ++sp) {
             if (env_spl && sp != atoi(env_spl) && !(atoi(env_spl) > nch && sp == nch)) continue;
             const int per = ceil_div(nch, sp);
@@ -820,7 +821,8 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             const double t_iter = (0.35 + bytes / 68e3) * (cap == 512 ? 1.2 : 1.0);
             const double rounds = (double)((blocks + cap - 1) / cap);
             double t = rounds * (5.0 + per * t_iter);
-            if (sp > 1) t += 6.0 + (sp + 1) * (double)out_elems * 4.0 / 3e6;
+            static const char* env_pen = getenv("STEGAN_BF16_SPLIT_PEN");
+            if (sp > 1) t += (env_pen ? atof(env_pen) : 1.0) * (6.0 + (sp + 1) * (double)out_elems * 4.0 / 3e6);
             if (t < best - 1e-9) { best = t; TM = tm; TN = tn; splits = sp; gm = g2; }
         }
     }

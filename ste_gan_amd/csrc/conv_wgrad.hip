@@ -352,7 +352,9 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
         max_splits = workspace_floats / p.dw_numel;
         p.partial = workspace;
     }
-    if (max_splits > 64) max_splits = 64;
+    static const char* env_cap = getenv("STEGAN_WG_MAX_SPLITS");         // experiments
+    const long cap_splits = env_cap ? atol(env_cap) : 64;
+    if (max_splits > cap_splits) max_splits = cap_splits;
     // cost model in units of one chunk of one block: the blocks on a CU share its matrix pipes, so a launch takes about
     // (blocks on the busiest CU) x (chunks per block + ~3 for prologue / first loads / epilogue), stretched when only
     // one or two blocks share a CU; every extra slice adds a slab of dw_numel floats to the reduction pass
@@ -363,7 +365,8 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
         const long blocks = tiles * ceil_div(p.total_chunks, cps);
         const long load = (blocks + 255) / 256;
         const double eff = load >= 3 ? 1.0 : load == 2 ? 0.8 : 0.55;      // few resident waves hide little latency
-        const double cost = (double)load * (cps + 3.0) / eff + (sp > 1 ? sp * (double)p.dw_numel * 1.3e-6 : 0.0);
+        static const char* env_sc = getenv("STEGAN_WG_SLAB_COST");       // experiments: weight of the slab traffic
+        const double cost = (double)load * (cps + 3.0) / eff + (sp > 1 ? sp * (double)p.dw_numel * 1.3e-6 * (env_sc ? atof(env_sc) : 1.0) : 0.0);
         if (cost < best - 1e-9) { best = cost; want = sp; }
     }
     {

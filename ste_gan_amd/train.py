@@ -194,8 +194,16 @@ class GANTrainStep:
                 D_fake_det, D_real = netD(x_pred_t.detach()), netD(x_t)
                 # both terms are plain summands of the scalar handed to backward(): unit upstream gradient
                 loss_D = lsgan_loss(D_fake_det, 0.0, unit_grad=True) + lsgan_loss(D_real, 1.0, unit_grad=True)
-            loss_D.backward()                      # (weight gradients aside, as in the generator's backward: 8.9-10.0
-            self.optD.finalize_grads()             #  vs 8.8 ms/step -- three streams are already busy here)
+            d_async = os.environ.get("STEGAN_D_WGRAD_ASYNC", "0") == "1"     # experiment, see below
+            if d_async:
+                from . import ops as _ops
+                _ops.wgrad_async(True)
+            try:
+                loss_D.backward()                  # (weight gradients aside, as in the generator's backward: 8.23 vs
+            finally:                               #  7.84 ms/step -- three streams are already busy here)
+                if d_async:
+                    _ops.wgrad_async(False)
+            self.optD.finalize_grads()
             out["discriminator"] = loss_D.detach()
         if side is not None and self.comm is not None:
             # under torch.distributed the phases may be separate hipGraphs (GraphedTrainStep): a graph has to end with

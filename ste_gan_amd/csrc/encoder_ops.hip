@@ -287,6 +287,104 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// ---- the same two operators with one block per BATCH ELEMENT (short rows: the encoder runs them at T = 12) -------------
+// The kernels above give a wave one (b, t) column and walk it with a stride of T floats: every lane of a load touches its
+// own 64-byte segment (17 us for a 2.4 MB tensor).  Here a block owns the contiguous (C, T) slab of one batch element,
+// reads it with unit stride into registers (LN_EPT values per thread) and reduces per t through LDS: the block has T * P
+// threads, so thread i only ever sees t = i % T; the P partials of a column are added by one wave (two barriers).
+constexpr int LN_EPT = 16;
+
+__device__ __forceinline__ float ln_column_sum(float v, float* red, int tid, int T, int P) {
+    // partials of column t sit at red[t + T k], k < P: the waves share the columns, a wave adds one with shuffles
+    float* tot = red + T * P;
+    red[tid] = v;
+    block_sync();
+    const int wave = tid >> 6, lane = tid & 63, nw = (T * P) >> 6;          // whole waves only (wave_sum needs 64 lanes)
+    for (int t = wave; t < T && wave < nw; t += nw) {
+        float a = 0.f;
+        for (int k = lane; k < P; k += 64) a += red[t + T * k];
+        a = wave_sum(a);
+        if (lane == 0) tot[t] = a;
+    }
+    block_sync();
+    return tot[tid % T];          // (red / tot are rewritten only behind the next reduction's first barrier)
+}
+
+__global__ __launch_bounds__(1024) void ln_fwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ y, float* __restrict__ xhat,
+                                                           float* __restrict__ rstd, int Cm, int T, int P, float eps) {
+    extern __shared__ float red[];
+    const int tid = threadIdx.x, nth = T * P, n = Cm * T;
+    const size_t off = (size_t)blockIdx.x * n;
+    float z[LN_EPT];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_EPT; ++e) {
+        const int i = tid + e * nth;
+        z[e] = i < n ? x[off + i] + (r ? r[off + i] : 0.f) : 0.f;
+        s += z[e];
+    }
+    const float mean = ln_column_sum(s, red, tid, T, P) / (float)Cm;
+    float vs = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_EPT; ++e) {
+        const float d = (tid + e * nth < n) ? z[e] - mean : 0.f;
+        vs += d * d;
+    }
+    const float rs = rsqrtf(ln_column_sum(vs, red, tid, T, P) / (float)Cm + eps);
+    const int c0 = tid / T;
+#pragma unroll
+    for (int e = 0; e < LN_EPT; ++e) {
+        const int i = tid + e * nth;
+        if (i < n) {
+            const int c = c0 + e * P;
+            const float xh = (z[e] - mean) * rs;
+            if (xhat) xhat[off + i] = xh;
+            y[off + i] = xh * gamma[c] + beta[c];
+        }
+    }
+    if (tid < T && rstd) rstd[blockIdx.x * T + tid] = rs;
+}
+
+__global__ __launch_bounds__(1024) void ln_bwd_slab_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                           float* __restrict__ dz, int Cm, int T, int P) {
+    extern __shared__ float red[];
+    const int tid = threadIdx.x, nth = T * P, n = Cm * T;
+    const size_t off = (size_t)blockIdx.x * n;
+    const int c0 = tid / T;
+    float g[LN_EPT], xh[LN_EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < LN_EPT; ++e) {
+        const int i = tid + e * nth;
+        g[e] = i < n ? gamma[c0 + e * P] * dy[off + i] : 0.f;
+        xh[e] = i < n ? xhat[off + i] : 0.f;
+        s1 += g[e];
+        s2 += g[e] * xh[e];
+    }
+    s1 = ln_column_sum(s1, red, tid, T, P) / (float)Cm;
+    s2 = ln_column_sum(s2, red, tid, T, P) / (float)Cm;
+    const float rs = rstd[blockIdx.x * T + tid % T];
+#pragma unroll
+    for (int e = 0; e < LN_EPT; ++e) {
+        const int i = tid + e * nth;
+        if (i < n) dz[off + i] = rs * (g[e] - s1 - xh[e] * s2);
+    }
+}
+
+// threads per batch element for the slab kernels: T * P, P the largest power of two with T * P <= 1024 (0: rows too long or
+// the slab does not fit LN_EPT values per thread -- the per-column kernels take it)
+inline int ln_slab_p(int Cm, int T) {
+    static const bool off = getenv("STEGAN_LN_COLUMNS") != nullptr;          // experiments: the first version's kernels
+    if (off || T > 256) return 0;
+    int P = 1;
+    while (T * P * 2 <= 1024) P *= 2;
+    if ((long)Cm * T > (long)LN_EPT * T * P || T * P < 64) return 0;
+    return P;
+}
+
 }  // namespace
 
 extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B,
@@ -326,6 +424,12 @@ extern "C" int stegan_add_layernorm_fwd(const float* x, const float* residual, c
                                         float* y, float* xhat, float* rstd, int32_t B, int32_t C, int32_t T, float eps,
                                         void* stream) {
     STEGAN_CHECK_ARG(x && gamma && beta && y && B > 0 && C > 0 && T > 0);
+    if (const int P = ln_slab_p(C, T)) {
+        hipLaunchKernelGGL(ln_fwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, x,
+                           residual, gamma, beta, y, xhat, rstd, C, T, P, eps);
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
                        beta, y, xhat, rstd, B, C, T, eps);
     STEGAN_LAUNCH_CHECK();
@@ -335,6 +439,12 @@ extern "C" int stegan_add_layernorm_fwd(const float* x, const float* residual, c
 extern "C" int stegan_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                                         float* dz, int32_t B, int32_t C, int32_t T, void* stream) {
     STEGAN_CHECK_ARG(dy && xhat && rstd && gamma && dz && B > 0 && C > 0 && T > 0);
+    if (const int P = ln_slab_p(C, T)) {
+        hipLaunchKernelGGL(ln_bwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, dy,
+                           xhat, rstd, gamma, dz, C, T, P);
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma,
                        dz, B, C, T);
     STEGAN_LAUNCH_CHECK();

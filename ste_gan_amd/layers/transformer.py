@@ -67,11 +67,11 @@ class MultiHeadAttention(nn.Module):
                 self._packed = (key, qkv.contiguous().unsqueeze(-1), wo.contiguous().unsqueeze(-1), emb.contiguous())
         return self._packed[1:]
 
-    def forward(self, x_bct):
+    def forward(self, x_bct, hand=None):
         """x: (B, d_model, T) -> (B, d_model, T) (the reference works on (T,B,d); same numbers)."""
         w_qkv, w_o, emb = self.packed()
         C = self.d_model
-        qkv = ops.frozen_conv1d(x_bct, w_qkv, None, None, None, ops.ConvCfg(C, 3 * C, 1))
+        qkv = ops.frozen_conv1d(x_bct, w_qkv, None, None, None, ops.ConvCfg(C, 3 * C, 1), hand)
         o = ops.relpos_attention(qkv, emb, self.n_head, self.relative_positional.max_relative_pos)
         return ops.frozen_conv1d(o, w_o, None, None, None, ops.ConvCfg(C, C, 1))
 
@@ -92,9 +92,19 @@ class TransformerEncoderLayer(nn.Module):
 
     def forward(self, src_bct):
         d, f = self.d_model, self.dim_feedforward
-        a = self.self_attn(src_bct)
-        src = ops.add_layernorm(src_bct, a, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        # the two residuals: src_bct and src each feed a conv and a LayerNorm.  With gradients flowing, the LayerNorm's
+        # backward (which runs first) parks its gradient for that tensor and the conv's input-gradient kernel adds it
+        # (ops.GradHandover) -- two autograd adds per layer less.  The FFN's ReLU rides on linear2's input staging, so
+        # its mask is applied in linear2's input-gradient epilogue instead of by an activation-backward launch.
+        h1 = h2 = None
+        if ops.HANDOVER and torch.is_grad_enabled() and src_bct.requires_grad:
+            h1, h2 = ops.GradHandover(), ops.GradHandover()
+        a = self.self_attn(src_bct, (ops.TAKE, h1) if h1 is not None else None)
+        src = ops.add_layernorm(src_bct, a, self.norm1.weight, self.norm1.bias, self.norm1.eps,
+                                (ops.PARK_DX, h1) if h1 is not None else None)
         h = ops.frozen_conv1d(src, self.linear1.weight.unsqueeze(-1), None, self.linear1.bias, None,
-                              ops.ConvCfg(d, f, 1, out_act=ACT_RELU))
-        h = ops.frozen_conv1d(h, self.linear2.weight.unsqueeze(-1), None, self.linear2.bias, None, ops.ConvCfg(f, d, 1))
-        return ops.add_layernorm(src, h, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+                              ops.ConvCfg(d, f, 1), (ops.TAKE, h2) if h2 is not None else None)
+        h = ops.frozen_conv1d(h, self.linear2.weight.unsqueeze(-1), None, self.linear2.bias, None,
+                              ops.ConvCfg(f, d, 1, in_act=ACT_RELU))
+        return ops.add_layernorm(src, h, self.norm2.weight, self.norm2.bias, self.norm2.eps,
+                                 (ops.PARK_DX, h2) if h2 is not None else None)

@@ -1205,20 +1205,21 @@ class _FrozenConvFn(torch.autograd.Function):
     """y = out_act(scale * (w (*) x) + bias + residual) with constant w / scale / bias: backward yields dx (+ dres)."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, bias, residual, cfg: ConvCfg, prepared=None):
+    def forward(ctx, x, w, scale, bias, residual, cfg: ConvCfg, prepared=None, hand=None):
         wf, wb = prepared if prepared is not None else (None, None)
         y = conv1d_fwd(x, w, scale, bias, residual, cfg, wf)
         ctx.cfg = cfg
         ctx.wb = wb
         ctx.has_res = residual is not None
         ctx.tin = x.shape[2]
-        ctx.save_for_backward(w, scale, y if cfg.out_act != ACT_NONE else None)
+        ctx.hand = hand
+        ctx.save_for_backward(w, scale, y if cfg.out_act != ACT_NONE else None, x if cfg.in_act == ACT_RELU else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         cfg: ConvCfg = ctx.cfg
-        w, scale, y = ctx.saved_tensors
+        w, scale, y, x_mask = ctx.saved_tensors
         dy = _gpu_f32(dy, "grad_output")
         if cfg.out_btc:
             dy = dy.transpose(1, 2).contiguous()
@@ -1226,9 +1227,20 @@ class _FrozenConvFn(torch.autograd.Function):
                 y = y.transpose(1, 2).contiguous()
         if cfg.out_act != ACT_NONE:
             dy = act_bwd(dy, y, cfg.out_act)
-        dx = conv1d_bwd_data(dy, w, scale, None, None, cfg, ctx.tin, ctx.wb) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            add = None
+            if ctx.hand is not None and ctx.hand[0] == TAKE:            # gradient hand-over (see GradHandover)
+                hand = ctx.hand[1]
+                hand.taken = True
+                add, hand.parked = hand.parked, None
+                if add is not None and (add.shape[0] != dy.shape[0] or add.shape[1] != cfg.cin
+                                        or add.shape[2] != ctx.tin * cfg.upsample or not add.is_contiguous()):
+                    raise RuntimeError("ste_gan_amd: parked gradient does not match the taker's input gradient")
+            dxe = conv1d_bwd_data(dy, w, scale, x_mask, add, cfg, ctx.tin, ctx.wb)
+            dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
         dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
-        return dx, None, None, None, dres, None, None
+        return dx, None, None, None, dres, None, None, None
 
 
 _FROZEN_PREP = {}
@@ -1247,8 +1259,8 @@ def frozen_prepared(w: Tensor, scale: Optional[Tensor], cfg: ConvCfg):
     return ent[1]
 
 
-def frozen_conv1d(x, w, scale, bias, residual, cfg: ConvCfg) -> Tensor:
-    return _FrozenConvFn.apply(x, w, scale, bias, residual, cfg, frozen_prepared(w, scale, cfg))
+def frozen_conv1d(x, w, scale, bias, residual, cfg: ConvCfg, hand=None) -> Tensor:
+    return _FrozenConvFn.apply(x, w, scale, bias, residual, cfg, frozen_prepared(w, scale, cfg), hand)
 
 
 class _RelPosAttnFn(torch.autograd.Function):
@@ -1284,7 +1296,8 @@ def relpos_attention(qkv, rel_emb, H, max_rel):
 
 class _AddLayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps: float):
+    def forward(ctx, x, residual, gamma, beta, eps: float, hand=None):
+        ctx.hand = hand
         x = _gpu_f32(x, "x")
         residual = _gpu_f32(residual, "residual")
         B, Cm, T = x.shape
@@ -1304,8 +1317,14 @@ class _AddLayerNormFn(torch.autograd.Function):
         dz = torch.empty_like(dy)
         check(_lib.lib().stegan_add_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dz), B, Cm, T, _stream()),
               "stegan_add_layernorm_bwd")
-        return dz, dz, None, None, None
+        hand = ctx.hand[1] if ctx.hand is not None and ctx.hand[0] == PARK_DX else None
+        if hand is not None and not hand.taken and ctx.needs_input_grad[0]:
+            hand.parked = dz                       # the conv that also reads x adds it inside its input-gradient kernel
+            return None, dz, None, None, None, None
+        return dz, dz, None, None, None, None
 
 
-def add_layernorm(x, residual, gamma, beta, eps=1e-5):
-    return _AddLayerNormFn.apply(x, residual, gamma, beta, eps)
+def add_layernorm(x, residual, gamma, beta, eps=1e-5, hand=None):
+    """y = LayerNorm_C(x + residual) * gamma + beta on (B, C, T).  hand = (PARK_DX, GradHandover): x also feeds a conv whose
+    backward runs later and takes this node's gradient for x as ``add`` (transformer residuals)."""
+    return _AddLayerNormFn.apply(x, residual, gamma, beta, eps, hand)

@@ -47,3 +47,50 @@ def test_training_mode_raises():
     enc = EMGEncoderTransformer(8, 256, 48, model_size=64, num_transformer_layers=1, dim_feedforward=64).cuda().train()
     with pytest.raises(NotImplementedError):
         enc(torch.zeros(1, 64, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("B,C,T", [(64, 768, 12), (3, 100, 5), (4, 64, 40), (2, 48, 300), (2, 3000, 12), (5, 7, 1)])
+def test_add_layernorm_against_torch(B, C, T):
+    """stegan_add_layernorm_fwd / _bwd on (B, C, T): the one-block-per-batch-element kernels (short rows) and the
+    per-column kernels (T > 256, or a slab too large for the per-thread registers) against torch.layer_norm in fp64."""
+    from ste_gan_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C + T)
+    x, r, dy = (torch.randn(B, C, T, generator=g) for _ in range(3))
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm((xd + rd).transpose(1, 2), (C,), gamma.double(), beta.double(), 1e-5).transpose(1, 2)
+    gx, gr = torch.autograd.grad(ref, (xd, rd), dy.double())
+    xg, rg = x.cuda().requires_grad_(True), r.cuda().requires_grad_(True)
+    y = ops.add_layernorm(xg, rg, gamma.cuda(), beta.cuda(), 1e-5)
+    hx, hr = torch.autograd.grad(y, (xg, rg), dy.cuda())
+    assert float((y.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-5 * float(ref.abs().max())
+    for got, want in ((hx, gx), (hr, gr)):
+        assert float((got.cpu().double() - want).abs().max()) <= 5e-5 * float(want.abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_transformer_layer_gradient_handover(dtype, monkeypatch):
+    """Input gradient of a TransformerEncoderLayer with the residual sums formed inside the convs' input-gradient kernels
+    (ops.GradHandover) against autograd's own accumulation."""
+    from ste_gan_amd import ops
+    from ste_gan_amd.layers.transformer import TransformerEncoderLayer
+    torch.manual_seed(11)
+    layer = TransformerEncoderLayer(64, 4, dim_feedforward=128, relative_positional_distance=20).cuda().eval()
+    for p in layer.parameters():
+        p.requires_grad_(False)
+    x0 = torch.randn(6, 64, 12, device="cuda")
+    dy = torch.randn(6, 64, 12, device="cuda")
+    ops.set_compute_dtype(dtype)
+    try:
+        res = {}
+        for on in (True, False):
+            monkeypatch.setattr(ops, "HANDOVER", on)
+            x = x0.clone().requires_grad_(True)
+            y = layer(x)
+            (gx,) = torch.autograd.grad(y, x, dy)
+            res[on] = (y.detach().clone(), gx.clone())
+    finally:
+        ops.set_compute_dtype("f32")
+    for a, b in zip(res[True], res[False]):
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-9

@@ -69,13 +69,19 @@ class ResBlock(nn.Module):
     def forward(self, x):
         f = self.folded()
         ci, co, s = self.num_ins, self.num_outs, self.stride
-        h = ops.frozen_conv1d(x, self.conv1.weight, f[0][0], f[0][1], None,
-                              ops.ConvCfg(ci, co, 3, stride=s, pad=1, out_act=ACT_RELU))
+        # the first ReLU rides on conv2's input staging (its mask in conv2's input-gradient epilogue: no activation-backward
+        # launch); x feeds conv1 and the residual branch: the branch's backward runs first and parks its gradient for x,
+        # conv1's input-gradient kernel adds it (ops.GradHandover) instead of an autograd add
+        hx = ops.GradHandover() if (ops.HANDOVER and torch.is_grad_enabled() and x.requires_grad) else None
+        h = ops.frozen_conv1d(x, self.conv1.weight, f[0][0], f[0][1], None, ops.ConvCfg(ci, co, 3, stride=s, pad=1),
+                              (ops.TAKE, hx) if hx is not None else None)
+        cfg2 = ops.ConvCfg(co, co, 3, pad=1, in_act=ACT_RELU, out_act=ACT_RELU)
         if self.residual_path is not None:
-            r = ops.frozen_conv1d(x, self.residual_path.weight, f[2][0], f[2][1], None, ops.ConvCfg(ci, co, 1, stride=s))
-        else:
-            r = x
-        return ops.frozen_conv1d(h, self.conv2.weight, f[1][0], f[1][1], r, ops.ConvCfg(co, co, 3, pad=1, out_act=ACT_RELU))
+            r = ops.frozen_conv1d(x, self.residual_path.weight, f[2][0], f[2][1], None, ops.ConvCfg(ci, co, 1, stride=s),
+                                  (ops.PARK_DX, hx) if hx is not None else None)
+            return ops.frozen_conv1d(h, self.conv2.weight, f[1][0], f[1][1], r, cfg2)
+        return ops.frozen_conv1d(h, self.conv2.weight, f[1][0], f[1][1], x, cfg2,
+                                 (ops.PARK_RES, hx) if hx is not None else None)
 
 
 class _LayerStack(nn.Module):

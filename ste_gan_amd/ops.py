@@ -1238,8 +1238,16 @@ class _FrozenConvFn(torch.autograd.Function):
                                         or add.shape[2] != ctx.tin * cfg.upsample or not add.is_contiguous()):
                     raise RuntimeError("ste_gan_amd: parked gradient does not match the taker's input gradient")
             dxe = conv1d_bwd_data(dy, w, scale, x_mask, add, cfg, ctx.tin, ctx.wb)
-            dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
-        dres = dy if (ctx.has_res and ctx.needs_input_grad[4]) else None
+            if ctx.hand is not None and ctx.hand[0] == PARK_DX and not ctx.hand[1].taken:
+                ctx.hand[1].parked = dxe
+            else:
+                dx = fold_upsample2(dxe) if cfg.upsample == 2 else dxe
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            if ctx.hand is not None and ctx.hand[0] == PARK_RES and not ctx.hand[1].taken and dy.is_contiguous():
+                ctx.hand[1].parked = dy
+            else:
+                dres = dy
         return dx, None, None, None, dres, None, None, None
 
 

@@ -11,8 +11,9 @@
 //   * X tile  Xs[cb][slot][8 channels] bf16 (channel-block-major: one 8-channel block of all slots, then the next) --
 //     activations stay fp32 (B, C, T) in HBM; a thread loads the 8 channels of one (8-channel block, run of 4 time slots)
 //     with 8 buffer_load_dwordx4 (lanes along time: whole 128-byte lines; the channel stride is a scalar offset; halo /
-//     padding / out-of-range slots carry an out-of-range offset and read 0 from the buffer unit; rows that are not
-//     float4-aligned, and the nearest-x2 upsample, take 8 buffer_load_dword per slot), applies the input ReLU on the
+//     padding / out-of-range slots carry an out-of-range offset and read 0 from the buffer unit; the forward's nearest-x2
+//     upsample loads 4 SOURCE positions and stores every converted piece twice; rows that are not float4-aligned take 8
+//     buffer_load_dword per slot, or -- opt-in -- the same 16-byte loads with the row's tail zeroed), applies the input ReLU on the
 //     packed halves (v_pk_max_i16 x, 0), converts with v_cvt_pk_bf16_f32 and stores ds_write_b128.  A tap shift is a SLOT
 //     offset, so any dilation / stride is an address offset, never a gather; operand reads of 32 consecutive slots are 32
 //     consecutive 16-byte pieces: bank-conflict free without padding or swizzle.

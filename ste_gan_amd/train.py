@@ -90,7 +90,8 @@ class GANTrainStep:
 
     def _side_stream(self):
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            # (experiment hook: a priority for the encoder branch's stream; captured graphs showed no effect, see DESIGN)
+            self._side = torch.cuda.Stream(priority=int(os.environ.get("STEGAN_SIDE_PRIORITY", "0")))
         return self._side
 
     def _set_d_grad(self, flag: bool):
@@ -331,6 +332,8 @@ class GraphedTrainStep:
         # hipEventQuery at any time; in the default "global" mode such a call from another thread invalidates a capture in
         # progress (hipErrorStreamCaptureInvalidated, then the watchdog aborts the process) -- seen once in three runs.
         mode = dict(capture_error_mode="thread_local")
+        if os.environ.get("STEGAN_MAIN_PRIORITY"):            # experiment hook: capture on a stream with a priority
+            mode["stream"] = torch.cuda.Stream(priority=int(os.environ["STEGAN_MAIN_PRIORITY"]))
         if step.comm is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, **mode):

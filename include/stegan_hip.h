@@ -274,6 +274,16 @@ int stegan_spectral_norm_bwd_acc(const float* w_orig, const float* dw, const flo
 int stegan_mpd_fold_fwd(const float* x_btc, float* out, int32_t B, int32_t T, int32_t C, int32_t period, void* stream);
 int stegan_mpd_fold_bwd(const float* dout, float* dx_btc, int32_t B, int32_t T, int32_t C, int32_t period,
                         int32_t accumulate, void* stream);
+/*
+ * The folds of all n <= 8 period discriminators of a MultiPeriodDiscriminator (discriminator.py:174-183: every
+ * sub-discriminator pads and folds the same x) in ONE launch: outs[k] receives the fold for periods[k].  _bwd_multi
+ * forms dx = sum_k fold_k^T(douts[k]) in one launch -- the sum autograd accumulates over the sub-discriminators'
+ * input gradients.  outs / douts / periods are HOST arrays of n entries.
+ */
+int stegan_mpd_fold_fwd_multi(const float* x_btc, float* const* outs, int32_t B, int32_t T, int32_t C,
+                              const int32_t* periods, int32_t n, void* stream);
+int stegan_mpd_fold_bwd_multi(const float* const* douts, float* dx_btc, int32_t B, int32_t T, int32_t C,
+                              const int32_t* periods, int32_t n, int32_t accumulate, void* stream);
 /* rearrange 'b t c -> b c t' (discriminator.py:145,181) and its transpose (optionally +=). */
 int stegan_btc_to_bct(const float* x, float* y, int32_t B, int32_t T, int32_t C, void* stream);
 int stegan_bct_to_btc(const float* x, float* y, int32_t B, int32_t T, int32_t C, int32_t accumulate, void* stream);

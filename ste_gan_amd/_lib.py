@@ -64,6 +64,8 @@ SIGNATURES = {
     "stegan_spectral_norm_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "stegan_mpd_fold_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stegan_mpd_fold_bwd": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "stegan_mpd_fold_fwd_multi": [_P, _P, _I32, _I32, _I32, _P, _I32, _P],
+    "stegan_mpd_fold_bwd_multi": [_P, _P, _I32, _I32, _I32, _P, _I32, _I32, _P],
     "stegan_btc_to_bct": [_P, _P, _I32, _I32, _I32, _P],
     "stegan_bct_to_btc": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stegan_avgpool421_fwd": [_P, _P, _I64, _I32, _P],

@@ -36,6 +36,63 @@ __global__ __launch_bounds__(256) void mpd_fold_bwd_kernel(const float* __restri
     }
 }
 
+// The folds of ALL period discriminators in one launch, and their backward in one launch that also forms the sum of the
+// discriminators' gradients w.r.t. the signal (autograd added the five dx tensors with four launches of its own).
+constexpr int MPD_MAX = 8;
+struct FoldMulti {
+    int n, B, T, Cc;
+    int p[MPD_MAX], H[MPD_MAX];
+    long first[MPD_MAX + 1];            // first linear output element of each period
+    float* out[MPD_MAX];
+};
+
+__global__ __launch_bounds__(256) void mpd_fold_fwd_multi_kernel(const float* __restrict__ x, const FoldMulti a) {
+    const long total = a.first[a.n];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < MPD_MAX; ++j)
+            if (j < a.n && i >= a.first[j]) k = j;
+        const int p = a.p[k], H = a.H[k];
+        const long li = i - a.first[k];
+        const int h = (int)(li % H);
+        long r = li / H;
+        const int c = (int)(r % a.Cc);
+        r /= a.Cc;
+        const int w = (int)(r % p), b = (int)(r / p);
+        int t = h * p + w;
+        if (t >= a.T) t = 2 * a.T - 2 - t;
+        a.out[k][li] = x[((long)b * a.T + t) * a.Cc + c];
+    }
+}
+
+struct FoldMultiB {
+    int n, B, T, Cc;
+    int p[MPD_MAX], H[MPD_MAX];
+    const float* dout[MPD_MAX];
+};
+
+__global__ __launch_bounds__(256) void mpd_fold_bwd_multi_kernel(const FoldMultiB a, float* __restrict__ dx, int accumulate) {
+    const long total = (long)a.B * a.T * a.Cc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % a.Cc);
+        long r = i / a.Cc;
+        const int t = (int)(r % a.T), b = (int)(r / a.T);
+        const int tr = 2 * a.T - 2 - t;          // padded position that mirrors onto t
+        float g = 0.f;
+#pragma unroll
+        for (int k = 0; k < MPD_MAX; ++k) {
+            if (k >= a.n) break;
+            const int p = a.p[k], H = a.H[k];
+            const float* d = a.dout[k];
+            float gk = d[(((long)b * p + t % p) * a.Cc + c) * H + t / p];          // (per period in the order of the single
+            if (tr >= a.T && tr < H * p) gk += d[(((long)b * p + tr % p) * a.Cc + c) * H + tr / p];   //  kernel, then summed)
+            g += gk;
+        }
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
 // (B,T,C) -> (B,C,T)   (C is tiny: 8)
 __global__ __launch_bounds__(256) void btc_to_bct_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                          int B, int T, int Cc) {
@@ -300,6 +357,41 @@ extern "C" int stegan_mpd_fold_bwd(const float* dout, float* dx_btc, int32_t B, 
     const int H = (T + n_pad) / period;
     hipLaunchKernelGGL(mpd_fold_bwd_kernel, dim3(nblocks((long)B * T * Cc)), dim3(256), 0, (hipStream_t)stream, dout,
                        dx_btc, B, T, Cc, period, H, accumulate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_mpd_fold_fwd_multi(const float* x_btc, float* const* outs, int32_t B, int32_t T, int32_t Cc,
+                                         const int32_t* periods, int32_t n, void* stream) {
+    STEGAN_CHECK_ARG(x_btc && outs && periods && B > 0 && T > 0 && Cc > 0 && n >= 1 && n <= MPD_MAX);
+    FoldMulti a;
+    a.n = n; a.B = B; a.T = T; a.Cc = Cc;
+    a.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        STEGAN_CHECK_ARG(outs[k] && periods[k] > 0);
+        const int n_pad = periods[k] - T % periods[k];
+        STEGAN_CHECK_ARG(n_pad < T);
+        a.p[k] = periods[k]; a.H[k] = (T + n_pad) / periods[k]; a.out[k] = outs[k];
+        a.first[k + 1] = a.first[k] + (long)B * a.p[k] * Cc * a.H[k];
+    }
+    hipLaunchKernelGGL(mpd_fold_fwd_multi_kernel, dim3(nblocks(a.first[n])), dim3(256), 0, (hipStream_t)stream, x_btc, a);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_mpd_fold_bwd_multi(const float* const* douts, float* dx_btc, int32_t B, int32_t T, int32_t Cc,
+                                         const int32_t* periods, int32_t n, int32_t accumulate, void* stream) {
+    STEGAN_CHECK_ARG(douts && dx_btc && periods && B > 0 && T > 0 && Cc > 0 && n >= 1 && n <= MPD_MAX);
+    FoldMultiB a;
+    a.n = n; a.B = B; a.T = T; a.Cc = Cc;
+    for (int k = 0; k < n; ++k) {
+        STEGAN_CHECK_ARG(douts[k] && periods[k] > 0);
+        const int n_pad = periods[k] - T % periods[k];
+        STEGAN_CHECK_ARG(n_pad < T);
+        a.p[k] = periods[k]; a.H[k] = (T + n_pad) / periods[k]; a.dout[k] = douts[k];
+    }
+    hipLaunchKernelGGL(mpd_fold_bwd_multi_kernel, dim3(nblocks((long)B * T * Cc)), dim3(256), 0, (hipStream_t)stream, a,
+                       dx_btc, accumulate);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

@@ -226,7 +226,7 @@ class _MultiDisc(nn.Module):
         (``ops.wn_conv1d_multi``) -- same channel structure, own weights / batch (B * period) / length each."""
         discs = list(self.multi_pooled_disc)
         B = x.shape[0]
-        hs = [ops.mpd_fold(x, d.period) for d in discs]
+        hs = ops.mpd_fold_multi(x, [d.period for d in discs])
         fmaps = [[] for _ in discs]
         depth = len(discs[0].layers) + 1
         for L in range(depth):

@@ -939,6 +939,51 @@ def mpd_fold(x_btc, period):
     return _MPDFoldFn.apply(x_btc, period)
 
 
+class _MPDFoldMultiFn(torch.autograd.Function):
+    """The folds of all period discriminators as ONE node: one launch forward, and one launch backward that also forms
+    the sum of the sub-discriminators' gradients w.r.t. the signal (stegan_mpd_fold_fwd_multi / _bwd_multi)."""
+
+    @staticmethod
+    def forward(ctx, x_btc, periods):
+        x_btc = _gpu_f32(x_btc, "x")
+        B, T, Cc = x_btc.shape
+        outs = []
+        for period in periods:
+            n_pad = period - T % period
+            if n_pad >= T:
+                raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, "
+                                   f"but got: padding (0, {n_pad}) at dimension 2 of input {[B, Cc, T]}")
+            outs.append(torch.empty((B * period, Cc, (T + n_pad) // period), device=x_btc.device, dtype=torch.float32))
+        pa = (C.c_int32 * len(periods))(*periods)
+        check(_lib.lib().stegan_mpd_fold_fwd_multi(_p(x_btc), _ptr_array(outs), B, T, Cc, pa, len(periods), _stream()),
+              "stegan_mpd_fold_fwd_multi")
+        ctx.dims = (B, T, Cc, tuple(periods), [o.shape for o in outs])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        B, T, Cc, periods, shapes = ctx.dims
+        dev = next(d for d in douts if d is not None).device
+        ds = [_gpu_f32(d, "grad") if d is not None else torch.zeros(sh, device=dev, dtype=torch.float32)
+              for d, sh in zip(douts, shapes)]
+        dx = torch.empty((B, T, Cc), device=dev, dtype=torch.float32)
+        pa = (C.c_int32 * len(periods))(*periods)
+        check(_lib.lib().stegan_mpd_fold_bwd_multi(_ptr_array(ds), _p(dx), B, T, Cc, pa, len(periods), 0, _stream()),
+              "stegan_mpd_fold_bwd_multi")
+        return dx, None
+
+
+MPD_FOLD_MULTI = os.environ.get("STEGAN_MPD_FOLD_MULTI", "1") != "0"
+
+
+def mpd_fold_multi(x_btc, periods):
+    """[mpd_fold(x, p) for p in periods] in one launch (and one backward launch); at most 8 periods per launch."""
+    periods = [int(p) for p in periods]
+    if not MPD_FOLD_MULTI or len(periods) < 2 or len(periods) > 8:
+        return [mpd_fold(x_btc, p) for p in periods]
+    return list(_MPDFoldMultiFn.apply(x_btc, periods))
+
+
 def btc_to_bct(x):
     return _BtcToBctFn.apply(x)
 

@@ -118,3 +118,21 @@ def test_reflect_pad_too_large_raises():
     d = DiscriminatorSmall(8).cuda()
     with pytest.raises(RuntimeError):          # T=4: period 11 needs pad 7 >= T (ATen raises too)
         d(torch.zeros(1, 4, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("B,T,Cc,periods", [(3, 192, 8, [2, 3, 5, 7, 11]), (2, 50, 4, [2, 5]), (1, 23, 1, [3, 4, 6, 7, 8, 9, 10, 11])])
+def test_mpd_fold_multi_equals_the_single_folds(B, T, Cc, periods):
+    """stegan_mpd_fold_fwd_multi / _bwd_multi: the folds of all period discriminators in one launch, the backward also
+    summing their gradients -- against one stegan_mpd_fold_fwd / _bwd per period and autograd's accumulation."""
+    from ste_gan_amd import ops
+    g = torch.Generator().manual_seed(T)
+    x0 = torch.randn(B, T, Cc, generator=g).cuda()
+    xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+    multi = ops.mpd_fold_multi(xa, periods)
+    single = [ops.mpd_fold(xb, p) for p in periods]
+    douts = [torch.randn(s.shape, generator=g).cuda() for s in single]
+    for m, s in zip(multi, single):
+        assert torch.equal(m, s)
+    torch.autograd.backward(multi, douts)
+    torch.autograd.backward(single, douts)
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * float(xb.grad.abs().max())

@@ -438,6 +438,14 @@ int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, co
                                   const float* mask_src, const float* add_src, float* dx, void* stream);
 int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                                     void* stream);
+/* The forward / input gradient of n <= 5 single-output-channel convs in ONE launch (the output convs of the period
+ * discriminators, discriminator.py:31: one per sub-discriminator, own batch B * period and length each).  Arrays of n
+ * HOST entries; returns 1 (nothing enqueued) unless stegan_conv1d_fwd_skinny would take every problem. */
+int stegan_conv1d_fwd_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                   const float* const* w, const float* const* scale, const float* const* bias,
+                                   float* const* y, void* stream);
+int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                        const float* const* w, const float* const* scale, float* const* dx, void* stream);
 
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);
 

@@ -45,11 +45,11 @@ __device__ __forceinline__ float sk_act(float v, int act) {
 // FOUR channels are issued before their first use, and short tiles give many channel lanes (few trips each) and many
 // blocks -- the first version (64-step tiles, one load per multiply-add) took 35 us for 1024 channels x 48 steps.
 // Partial sums meet in LDS, in fixed order.
-__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const SkP p) {
+__device__ __forceinline__ void conv_cout1_fwd_body(const SkP& p, int bx, int by) {
     __shared__ float red[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = bx, tid = threadIdx.x;
     const int cl = (int)fd_div((uint32_t)tid, p.fdTT), tl = tid - cl * p.TT;
-    const int t = blockIdx.y * p.TT + tl;
+    const int t = by * p.TT + tl;
     const bool live = cl < p.CL && t < p.Tout;
     int qk[SK_KMAX];
     bool ok[SK_KMAX];
@@ -98,11 +98,26 @@ __global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const SkP p) {
     }
 }
 
+__global__ __launch_bounds__(256) void conv_cout1_fwd_kernel(const SkP p) {
+    conv_cout1_fwd_body(p, blockIdx.x, blockIdx.y);
+}
+
+// Up to SK_MULTI problems in one launch (the output convs of the five period discriminators: same layer, own batch
+// B * period and length each): blockIdx.z picks the problem, blocks outside its extent leave at once.
+constexpr int SK_MULTI = 5;
+struct SkMulti { int n; SkP p[SK_MULTI]; long ne[SK_MULTI]; };
+
+__global__ __launch_bounds__(256) void conv_cout1_fwd_multi_kernel(const SkMulti a) {
+    const SkP& p = a.p[blockIdx.z];
+    if ((int)blockIdx.x >= p.B || (int)blockIdx.y * p.TT >= p.Tout) return;
+    conv_cout1_fwd_body(p, blockIdx.x, blockIdx.y);
+}
+
 // input gradient: one thread per dx element, consecutive threads consecutive addresses; dy (B x Tout floats) and w stay
 // in cache.
-__global__ __launch_bounds__(256) void conv_cout1_bwd_data_kernel(const SkP p, long n) {
+__device__ __forceinline__ void conv_cout1_bwd_data_body(const SkP& p, long n, int bx, int nbx) {
     const float sc = p.scale ? p.scale[0] : 1.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    for (long e = (long)bx * 256 + threadIdx.x; e < n; e += (long)nbx * 256) {
         const uint32_t b = fd_div((uint32_t)e, p.fdCT);
         const uint32_t r = (uint32_t)e - b * (uint32_t)(p.Cin * p.Tin);
         const uint32_t ci = fd_div(r, p.fdTin);
@@ -119,6 +134,14 @@ __global__ __launch_bounds__(256) void conv_cout1_bwd_data_kernel(const SkP p, l
         }
         p.out[e] = s * sc;
     }
+}
+
+__global__ __launch_bounds__(256) void conv_cout1_bwd_data_kernel(const SkP p, long n) {
+    conv_cout1_bwd_data_body(p, n, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void conv_cout1_bwd_data_multi_kernel(const SkMulti a) {
+    conv_cout1_bwd_data_body(a.p[blockIdx.y], a.ne[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // weight gradient: block = (CL channels, slice of `per` batch rows, tile of TT <= 64 input steps); thread = (input step
@@ -212,6 +235,63 @@ extern "C" int stegan_conv1d_fwd_skinny(const stegan_conv_desc* d, const float* 
     p.fdTT = make_fastdiv((uint32_t)p.TT);
     hipLaunchKernelGGL(conv_cout1_fwd_kernel, dim3((unsigned)d->B, (unsigned)ceil_div(d->Tout, p.TT)), dim3(256), 0,
                        (hipStream_t)stream, p);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+// The forward of up to 5 single-output-channel convs in one launch; returns 1 (nothing enqueued) unless every problem is
+// one stegan_conv1d_fwd_skinny takes.
+extern "C" int stegan_conv1d_fwd_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                              const float* const* w, const float* const* scale, const float* const* bias,
+                                              float* const* y, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && descs && x && w && y);
+    if (n > SK_MULTI) return 1;
+    SkMulti a;
+    a.n = n;
+    unsigned gx = 0, gy = 0;
+    for (int i = 0; i < n; ++i) {
+        SkP& p = a.p[i];
+        int rc = fill(descs[i], p);
+        if (rc) return rc;
+        const stegan_conv_desc* d = descs[i];
+        STEGAN_CHECK_ARG(x[i] && w[i] && y[i]);
+        STEGAN_CHECK_ARG(d->out_act >= STEGAN_ACT_NONE && d->out_act <= STEGAN_ACT_TANH);
+        p.x = x[i]; p.w = w[i]; p.scale = scale ? scale[i] : nullptr; p.bias = bias ? bias[i] : nullptr; p.out = y[i];
+        p.TT = d->Tout < 8 ? d->Tout : 8;
+        p.CL = 256 / p.TT;
+        if (p.CL > d->Cin) p.CL = d->Cin;
+        p.fdTT = make_fastdiv((uint32_t)p.TT);
+        a.ne[i] = 0;
+        if ((unsigned)d->B > gx) gx = (unsigned)d->B;
+        if ((unsigned)ceil_div(d->Tout, p.TT) > gy) gy = (unsigned)ceil_div(d->Tout, p.TT);
+    }
+    if (gy > 65535u) return 1;
+    hipLaunchKernelGGL(conv_cout1_fwd_multi_kernel, dim3(gx, gy, (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                                   const float* const* w, const float* const* scale, float* const* dx,
+                                                   void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && descs && dy && w && dx);
+    if (n > SK_MULTI) return 1;
+    SkMulti a;
+    a.n = n;
+    long blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        SkP& p = a.p[i];
+        int rc = fill(descs[i], p);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(dy[i] && w[i] && dx[i]);
+        p.dy = dy[i]; p.w = w[i]; p.scale = scale ? scale[i] : nullptr; p.out = dx[i];
+        a.ne[i] = (long)descs[i]->B * descs[i]->Cin * descs[i]->Tin;
+        const long b = (a.ne[i] + 255) / 256;
+        if (b > blocks) blocks = b;
+    }
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_cout1_bwd_data_multi_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, a);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

@@ -554,9 +554,10 @@ def _ptr_array(items):
     return (C.c_void_p * len(items))(*[C.c_void_p(t.data_ptr()) if t is not None else None for t in items])
 
 
-def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
+def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases, raws=None):
     """Up to five forward convs that share a kernel variant in ONE launch (stegan_conv1d_fwd_multi); None when the
-    library says they cannot share one (the caller then launches them one by one)."""
+    library says they cannot share one (the caller then launches them one by one).  ``raws``: the raw (Cout, Cin/g, K)
+    weights, for the single-output-channel kernels."""
     n = len(xs)
     xs = [_gpu_f32(x, "x") for x in xs]
     ys, descs = [], []
@@ -566,6 +567,12 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
         ys.append(torch.empty((B, cfg.cout, tout), device=x.device, dtype=torch.float32))
         descs.append(_desc(cfg, B, tin, tout))
     dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    if SKINNY and raws is not None and all(c.cout == 1 for c in cfgs):
+        rc = _lib.lib().stegan_conv1d_fwd_skinny_multi(n, dptr, _ptr_array(xs), _ptr_array([_gpu_f32(w, "weight") for w in raws]),
+                                                       _ptr_array(scales), _ptr_array(biases), _ptr_array(ys), _stream())
+        if rc != 1:
+            check(rc, "stegan_conv1d_fwd_skinny_multi")
+            return ys
     whs = [_bf16_of(w) for w in wfs]
     if all(w is not None for w in whs):
         rc = _lib.lib().stegan_conv1d_fwd_multi_h(n, dptr, _ptr_array(xs), _ptr_array(whs), _ptr_array(scales),
@@ -584,7 +591,7 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases):
     return ys
 
 
-def conv1d_bwd_data_multi(dys, cfgs, wbs, tins):
+def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
     n = len(dys)
     dys = [_gpu_f32(t, "dy") for t in dys]
     dxs, descs = [], []
@@ -593,6 +600,14 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins):
         dxs.append(torch.empty((B, cfg.cin, tin), device=dy.device, dtype=torch.float32))
         descs.append(_desc(cfg, B, tin, tout))
     dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    if SKINNY and raws is not None and all(c.cout == 1 for c in cfgs):
+        rc = _lib.lib().stegan_conv1d_bwd_data_skinny_multi(n, dptr, _ptr_array(dys),
+                                                            _ptr_array([_gpu_f32(w, "weight") for w in raws]),
+                                                            _ptr_array(scales) if scales is not None else None,
+                                                            _ptr_array(dxs), _stream())
+        if rc != 1:
+            check(rc, "stegan_conv1d_bwd_data_skinny_multi")
+            return dxs
     whs = [_bf16_of(w) for w in wbs]
     if all(w is not None for w in whs):
         rc = _lib.lib().stegan_conv1d_bwd_data_multi_h(n, dptr, _ptr_array(dys), _ptr_array(whs), None, None, _ptr_array(dxs),
@@ -622,7 +637,8 @@ class _WNConvMultiFn(torch.autograd.Function):
         cfgs = [l[3] for l in layers]
         ys = None
         if PROFILER is None and all(c.upsample == 1 and not c.out_btc for c in cfgs):
-            ys = conv1d_fwd_multi(xs, cfgs, [l[4][1] for l in layers], [l[4][0] for l in layers], [l[2] for l in layers])
+            ys = conv1d_fwd_multi(xs, cfgs, [l[4][1] for l in layers], [l[4][0] for l in layers], [l[2] for l in layers],
+                                  [l[0].reshape(l[0].shape[0], l[0].shape[1], -1) for l in layers])
         if ys is None:
             ys = [conv1d_fwd(x, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], l[2], None, l[3], l[4][1])
                   for x, l in zip(xs, layers)]
@@ -654,7 +670,9 @@ class _WNConvMultiFn(torch.autograd.Function):
             cfgs = [l[3] for l in layers]
             out = None
             if PROFILER is None and all(need):
-                out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs])
+                out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs],
+                                            [l[0].reshape(l[0].shape[0], l[0].shape[1], -1) for l in layers],
+                                            [l[4][0] for l in layers])
             if out is None:
                 out = [conv1d_bwd_data(g, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], None, None, l[3],
                                        x.shape[2], l[4][2]) if nd else None for g, x, l, nd in zip(gs, xs, layers, need)]

@@ -154,3 +154,29 @@ def test_single_output_channel_kernels(cfg):
     assert ops.LAST_CONV_KERNEL != "skinny"
     torch.testing.assert_close(y2.double().cpu(), {0: lambda v: v, 2: lambda v: F.leaky_relu(v, 0.1), 3: torch.tanh}[act](
         pre.detach() + res.double().cpu()), rtol=2e-5, atol=2e-5)
+
+
+def test_single_output_channel_multi_launch_equals_single_launches():
+    """stegan_conv1d_fwd_skinny_multi / _bwd_data_skinny_multi (the period discriminators' output convs in one launch)
+    against one launch per problem: same kernels' bodies, so bit equality."""
+    from ste_gan_amd import ops
+    g = torch.Generator().manual_seed(9)
+    shapes = [(128, 1024, 24), (192, 1024, 16), (320, 1024, 10), (448, 1024, 7), (704, 1024, 5)]       # (B * period, Cin, H)
+    cfgs, xs, ws, scs, bs, dys = [], [], [], [], [], []
+    for B, Cin, T in shapes:
+        cfgs.append(ops.ConvCfg(Cin, 1, 3, 1, 1, 1))
+        xs.append(torch.randn(B, Cin, T, generator=g).cuda())
+        ws.append((torch.randn(1, Cin, 3, generator=g) * 0.05).cuda())
+        scs.append((torch.rand(1, generator=g) + 0.5).cuda())
+        bs.append(torch.randn(1, generator=g).cuda())
+        dys.append(torch.randn(B, 1, T, generator=g).cuda())
+    ys = ops.conv1d_fwd_multi(xs, cfgs, [None] * 5, scs, bs, ws)
+    assert ys is not None
+    dxs = ops.conv1d_bwd_data_multi(dys, cfgs, [None] * 5, [s[2] for s in shapes], ws, scs)
+    assert dxs is not None
+    for x, w, sc, b, dy, c, y, dx in zip(xs, ws, scs, bs, dys, cfgs, ys, dxs):
+        y1 = ops.conv1d_fwd(x, w, sc, b, None, c)
+        assert ops.LAST_CONV_KERNEL == "skinny"
+        assert torch.equal(y, y1)
+        dx1 = ops.conv1d_bwd_data(dy, w, sc, None, None, c, x.shape[2])
+        assert torch.equal(dx, dx1)

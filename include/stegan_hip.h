@@ -460,6 +460,10 @@ int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32
  * add may be NULL (= stegan_act_bwd). */
 int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
                        void* stream);
+/* stegan_act_bwd_add for m <= 8 tensors in one launch (layer L of the period discriminators); HOST arrays of m entries,
+ * add (the array, or single entries) may be NULL. */
+int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
+                             float* const* out, const int64_t* n, int32_t act, void* stream);
 
 #ifdef __cplusplus
 }

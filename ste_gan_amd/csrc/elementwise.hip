@@ -5,8 +5,8 @@ namespace {
 
 // add != nullptr: a second gradient of the same tensor (the feature-matching term of a discriminator feature map, known
 // since the forward pass) is summed in here instead of by a separate elementwise kernel in front of this one
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
-                                                      const float* __restrict__ y, float* __restrict__ out, long n, int act) {
+__device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const float* __restrict__ add,
+                                             const float* __restrict__ y, float* __restrict__ out, long n, int act) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 1024;
     for (; i < n; i += stride) {
@@ -36,6 +36,20 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
+                                                      const float* __restrict__ y, float* __restrict__ out, long n, int act) {
+    act_bwd_body(dy, add, y, out, n, act);
+}
+
+// the same for up to ACT_MULTI tensors in one launch (layer L of the five period discriminators): blockIdx.y = tensor
+constexpr int ACT_MULTI = 8;
+struct ActMulti { const float* dy[ACT_MULTI]; const float* add[ACT_MULTI]; const float* y[ACT_MULTI]; float* out[ACT_MULTI]; long n[ACT_MULTI]; };
+
+__global__ __launch_bounds__(256) void act_bwd_multi_kernel(const ActMulti a, int act) {
+    const int k = blockIdx.y;
+    act_bwd_body(a.dy[k], a.add[k], a.y[k], a.out[k], a.n[k], act);
+}
+
 }  // namespace
 
 extern "C" int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
@@ -46,6 +60,25 @@ extern "C" int stegan_act_bwd_add(const float* dy, const float* add, const float
     long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, add, y, out, (long)n, act);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
+                                        float* const* out, const int64_t* n, int32_t act, void* stream) {
+    STEGAN_CHECK_ARG(m >= 1 && m <= ACT_MULTI && dy && y && out && n);
+    STEGAN_CHECK_ARG(act == STEGAN_ACT_RELU || act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH);
+    ActMulti a;
+    long blocks = 1;
+    for (int k = 0; k < m; ++k) {
+        STEGAN_CHECK_ARG(dy[k] && y[k] && out[k] && n[k] > 0);
+        a.dy[k] = dy[k]; a.add[k] = add ? add[k] : nullptr; a.y[k] = y[k]; a.out[k] = out[k]; a.n[k] = (long)n[k];
+        STEGAN_CHECK_ARG(((uintptr_t)a.dy[k] | (uintptr_t)a.add[k] | (uintptr_t)a.y[k] | (uintptr_t)a.out[k]) % 16 == 0);
+        const long b = ((long)n[k] + 1023) / 1024;
+        if (b > blocks) blocks = b;
+    }
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(act_bwd_multi_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, (hipStream_t)stream, a, act);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

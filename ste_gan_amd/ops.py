@@ -655,10 +655,22 @@ class _WNConvMultiFn(torch.autograd.Function):
         n, layers = ctx.n, ctx.layers
         saved = ctx.saved_tensors
         xs, ys = saved[:n], saved[n:]
-        gs = []
-        for dy, y, l in zip(dys, ys, layers):
-            g = _gpu_f32(dy, "grad_output")
-            gs.append(act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g)
+        gs = [_gpu_f32(dy, "grad_output") for dy in dys]
+        acts = {l[3].out_act for l in layers}
+        if ACT_MULTI and len(acts) == 1 and ACT_NONE not in acts and n <= 8 and not any(l[3].out_btc for l in layers) \
+                and all(g.is_contiguous() for g in gs):
+            # the activation backward of all problems (folded feature-matching gradients included) in one launch
+            adds = [_fm_take(y) for y in ys]
+            if any(a is not None and a.numel() != g.numel() for a, g in zip(adds, gs)):
+                raise RuntimeError("ste_gan_amd.act_bwd: folded gradient does not match the activation gradient")
+            outs = [torch.empty_like(g) for g in gs]
+            numels = (C.c_int64 * n)(*[g.numel() for g in gs])
+            check(_lib.lib().stegan_act_bwd_add_multi(n, _ptr_array(gs), _ptr_array(adds), _ptr_array(ys), _ptr_array(outs),
+                                                      numels, acts.pop(), _stream()), "stegan_act_bwd_add_multi")
+            gs = outs
+        else:
+            gs = [act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g
+                  for g, y, l in zip(gs, ys, layers)]
         if ctx.wgrad:
             _sink_touch()
             for x, g, l in zip(xs, gs, layers):
@@ -992,6 +1004,7 @@ class _MPDFoldMultiFn(torch.autograd.Function):
 
 
 MPD_FOLD_MULTI = os.environ.get("STEGAN_MPD_FOLD_MULTI", "1") != "0"
+ACT_MULTI = os.environ.get("STEGAN_ACT_MULTI", "1") != "0"          # one activation-backward launch per period-discriminator layer
 
 
 def mpd_fold_multi(x_btc, periods):

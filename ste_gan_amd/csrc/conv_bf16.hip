@@ -565,12 +565,19 @@ __device__ __forceinline__ unsigned short to_bf16(float f) {
 // gathered element by element with a K-float stride, twice per weight: 146 us for the generator's 24 M weights.  The
 // buffers are zero-filled when they are allocated and only live elements are ever written: the zero tap plane k = K and
 // the padding rows / channels stay zero.
-constexpr int PREP_LDS_FLOATS = 12288;                         // 48 KiB
+// 25 KiB of LDS per block (six blocks per CU; the first version's 48 KiB allowed three): this kernel only moves memory
+#ifndef STEGAN_PREP_LDS_FLOATS
+#define STEGAN_PREP_LDS_FLOATS 6400
+#endif
+constexpr int PREP_LDS_FLOATS = STEGAN_PREP_LDS_FLOATS;
 __host__ __device__ inline int prep_cit(int K) {               // input channels per tile: CIT K <= ~192 floats per row
     int c = (192 / K) & ~7;
     return c < 8 ? 8 : (c > 64 ? 64 : c);
 }
-__host__ __device__ inline int prep_rows(int K) { return 64 * (prep_cit(K) * K + 1) <= PREP_LDS_FLOATS ? 64 : 32; }
+__host__ __device__ inline int prep_rows(int K) {              // output rows per tile: the most that fit
+    const int P = prep_cit(K) * K + 1;
+    return 64 * P <= PREP_LDS_FLOATS ? 64 : (32 * P <= PREP_LDS_FLOATS ? 32 : 16);
+}
 __host__ __device__ inline long prep_tiles(int G, int Cout_g, int Cin_g, int K) {
     return (long)G * ((Cout_g + prep_rows(K) - 1) / prep_rows(K)) * ((Cin_g + prep_cit(K) - 1) / prep_cit(K));
 }

@@ -576,7 +576,7 @@ __host__ __device__ inline int prep_cit(int K) {               // input channels
 }
 __host__ __device__ inline int prep_rows(int K) {              // output rows per tile: the most that fit
     const int P = prep_cit(K) * K + 1;
-    return 64 * P <= PREP_LDS_FLOATS ? 64 : (32 * P <= PREP_LDS_FLOATS ? 32 : 16);
+    return 64 * P <= PREP_LDS_FLOATS ? 64 : (32 * P <= PREP_LDS_FLOATS ? 32 : (16 * P <= PREP_LDS_FLOATS ? 16 : 8));
 }
 __host__ __device__ inline long prep_tiles(int G, int Cout_g, int Cin_g, int K) {
     return (long)G * ((Cout_g + prep_rows(K) - 1) / prep_rows(K)) * ((Cin_g + prep_cit(K) - 1) / prep_cit(K));

@@ -319,7 +319,7 @@ inline int bwd_weight_splits(ConvK& p, int groups) {
     const int chunks = ceil_div(p.R, KC);
     const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * groups;
     static const char* env_tgt = getenv("STEGAN_WGRAD_TARGET");          // blocks to aim for (experiments)
-    const long target = env_tgt ? atol(env_tgt) : 1024;
+    const long target = env_tgt ? atol(env_tgt) : 256;        // (1024 at first: 7.49 vs 7.46 ms/step -- these run beside other streams)
     int splits = (int)((target + tiles - 1) / tiles);
     // every split ends in one atomic per output element, and same-address atomics serialise in L2 (~13 ns each): beyond a
     // few hundred splits a tiny dw (8 -> 32 channels: ONE tile, 880 splits of one 16-deep chunk each) is atomics-bound

@@ -446,6 +446,9 @@ int stegan_conv1d_fwd_skinny_multi(int32_t n, const stegan_conv_desc* const* des
                                    float* const* y, void* stream);
 int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
                                         const float* const* w, const float* const* scale, float* const* dx, void* stream);
+/* ... and their weight gradients: dw[i] += raw direction gradient, db[i] (array or entries may be NULL) += sum of dy[i]. */
+int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                          const float* const* dy, float* const* dw, float* const* db, void* stream);
 
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);
 

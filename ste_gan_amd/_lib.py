@@ -91,6 +91,7 @@ SIGNATURES = {
     "stegan_conv1d_bwd_weight_skinny": [_P, _P, _P, _P, _P, _P],
     "stegan_conv1d_fwd_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_weight_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add_multi": [_I32, _P, _P, _P, _P, _P, _I32, _P],

@@ -150,13 +150,13 @@ __global__ __launch_bounds__(256) void conv_cout1_bwd_data_multi_kernel(const Sk
 // and one thread per (channel, tap) adds the block's sum into dw with an fp32 atomic (as the split-K sums of the general
 // weight-gradient kernels do).  (A lane-per-channel version read x with a row stride between lanes: 64 cache lines per
 // load instruction, 32 us.)
-__global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
+__device__ __forceinline__ void conv_cout1_wgrad_body(const SkP& p, int bx, int by, int bz) {
     __shared__ float red[SK_KMAX][256];
     const int tid = threadIdx.x;
     const int cl = (int)fd_div((uint32_t)tid, p.fdTT), tl = tid - cl * p.TT;
-    const int c = blockIdx.x * p.CL + cl, q = blockIdx.z * p.TT + tl;
+    const int c = bx * p.CL + cl, q = bz * p.TT + tl;
     const bool live = cl < p.CL && c < p.Cin && q < p.Tin;
-    const int b0 = blockIdx.y * p.per, b1 = min(p.B, b0 + p.per);
+    const int b0 = by * p.per, b1 = min(p.B, b0 + p.per);
     int tk[SK_KMAX];
     bool ok[SK_KMAX];
 #pragma unroll
@@ -187,13 +187,48 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
     // thread (k, channel lane): sum of the channel's TT steps
     if (tid < p.CL * p.K) {
         const int k = (int)fd_div((uint32_t)tid, p.fdCL), cj = tid - k * p.CL;
-        const int cc = blockIdx.x * p.CL + cj;
+        const int cc = bx * p.CL + cj;
         if (cc < p.Cin) {
             float s = 0.f;
             for (int j = 0; j < p.TT; ++j) s += red[k][cj * p.TT + j];
             atomicAdd(&p.out[(size_t)cc * p.K + k], s);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
+    conv_cout1_wgrad_body(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// the weight gradients of up to SK_MULTI problems in one launch; blockIdx.x runs over the problems' channel blocks
+// (first[]); the first channel block / first time tile of a problem also sums dy of its batch slice into the bias
+// gradient (one output channel: db is ONE number per problem)
+struct SkMultiW { int n; int first[SK_MULTI + 1]; SkP p[SK_MULTI]; float* db[SK_MULTI]; };
+
+__global__ __launch_bounds__(256) void conv_cout1_wgrad_multi_kernel(const SkMultiW a) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < SK_MULTI; ++j)
+        if (j < a.n && (int)blockIdx.x >= a.first[j]) k = j;
+    const SkP& p = a.p[k];
+    const int bx = blockIdx.x - a.first[k];
+    if ((int)blockIdx.y * p.per >= p.B || (int)blockIdx.z * p.TT >= p.Tin) return;
+    if (bx == 0 && blockIdx.z == 0 && a.db[k]) {
+        __shared__ float bred[4];
+        const int b0 = blockIdx.y * p.per, b1 = min(p.B, b0 + p.per);
+        const int n = (b1 - b0) * p.Tout;
+        const float* dyb = p.dy + (size_t)b0 * p.Tout;
+        float s0 = 0.f, s1 = 0.f;
+        int i = threadIdx.x;
+        for (; i + 256 < n; i += 512) { s0 += dyb[i]; s1 += dyb[i + 256]; }
+        if (i < n) s0 += dyb[i];
+        float s = wave_sum(s0 + s1);
+        if ((threadIdx.x & 63) == 0) bred[threadIdx.x >> 6] = s;
+        block_sync();
+        if (threadIdx.x == 0) atomicAdd(a.db[k], (bred[0] + bred[1]) + (bred[2] + bred[3]));
+        block_sync();
+    }
+    conv_cout1_wgrad_body(p, bx, blockIdx.y, blockIdx.z);
 }
 
 // Cout == 1, ungrouped, no upsample / input activation / residual / (B, T, C) output: everything else returns 1
@@ -312,6 +347,51 @@ extern "C" int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const fl
     return STEGAN_OK;
 }
 
+// wgrad geometry of one problem (shared by the single and the multi launch)
+static void sk_wgrad_geometry(const stegan_conv_desc* d, SkP& p, int& cblocks, int& slices, int& qtiles) {
+    p.TT = d->Tin < 64 ? d->Tin : 64;
+    p.CL = 256 / p.TT;
+    if (p.CL > d->Cin) p.CL = d->Cin;
+    if (p.CL * d->K > 256) p.CL = 256 / d->K;
+    p.fdTT = make_fastdiv((uint32_t)p.TT); p.fdCL = make_fastdiv((uint32_t)p.CL);
+    cblocks = ceil_div(d->Cin, p.CL); qtiles = ceil_div(d->Tin, p.TT);
+    slices = ceil_div(512, cblocks * qtiles);             // ~2 blocks per CU; every slice ends in Cin x K atomics
+    if (slices > d->B) slices = d->B;
+    if (slices > 64) slices = 64;
+    p.per = ceil_div(d->B, slices);
+    slices = ceil_div(d->B, p.per);
+}
+
+// dw[i] (+ db[i], may be NULL) of n <= 5 single-output-channel convs in one launch; returns 1 (nothing enqueued) unless
+// stegan_conv1d_bwd_weight_skinny would take every problem
+extern "C" int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                                     const float* const* dy, float* const* dw, float* const* db,
+                                                     void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && descs && x && dy && dw);
+    if (n > SK_MULTI) return 1;
+    SkMultiW a;
+    a.n = n; a.first[0] = 0;
+    int gy = 1, gz = 1;
+    for (int i = 0; i < n; ++i) {
+        SkP& p = a.p[i];
+        int rc = fill(descs[i], p);
+        if (rc) return rc;
+        STEGAN_CHECK_ARG(x[i] && dy[i] && dw[i]);
+        p.x = x[i]; p.dy = dy[i]; p.out = dw[i];
+        a.db[i] = db ? db[i] : nullptr;
+        int cb, sl, qt;
+        sk_wgrad_geometry(descs[i], p, cb, sl, qt);
+        a.first[i + 1] = a.first[i] + cb;
+        if (sl > gy) gy = sl;
+        if (qt > gz) gz = qt;
+    }
+    for (int i = n; i < SK_MULTI; ++i) a.db[i] = nullptr;
+    hipLaunchKernelGGL(conv_cout1_wgrad_multi_kernel, dim3((unsigned)a.first[n], (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
 extern "C" int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
                                                float* db, void* stream) {
     SkP p;
@@ -319,17 +399,9 @@ extern "C" int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const 
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
     p.x = x; p.dy = dy; p.out = dw;
-    p.TT = d->Tin < 64 ? d->Tin : 64;
-    p.CL = 256 / p.TT;
-    if (p.CL > d->Cin) p.CL = d->Cin;
-    if (p.CL * d->K > 256) p.CL = 256 / d->K;
-    p.fdTT = make_fastdiv((uint32_t)p.TT); p.fdCL = make_fastdiv((uint32_t)p.CL);
-    const int cblocks = ceil_div(d->Cin, p.CL), qtiles = ceil_div(d->Tin, p.TT);
-    int slices = ceil_div(512, cblocks * qtiles);             // ~2 blocks per CU; every slice ends in Cin x K atomics
-    if (slices > d->B) slices = d->B;
-    if (slices > 64) slices = 64;
-    p.per = ceil_div(d->B, slices);
-    hipLaunchKernelGGL(conv_cout1_wgrad_kernel, dim3((unsigned)cblocks, (unsigned)ceil_div(d->B, p.per), (unsigned)qtiles),
+    int cblocks, slices, qtiles;
+    sk_wgrad_geometry(d, p, cblocks, slices, qtiles);
+    hipLaunchKernelGGL(conv_cout1_wgrad_kernel, dim3((unsigned)cblocks, (unsigned)slices, (unsigned)qtiles),
                        dim3(256), 0, (hipStream_t)stream, p);
     STEGAN_LAUNCH_CHECK();
     if (db) return stegan_bias_grad(dy, db, d->B, 1, d->Tout, stream);

@@ -673,9 +673,21 @@ class _WNConvMultiFn(torch.autograd.Function):
                   for g, y, l in zip(gs, ys, layers)]
         if ctx.wgrad:
             _sink_touch()
-            for x, g, l in zip(xs, gs, layers):
-                if l[5] is not None:
-                    conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None)
+            done = False
+            if SKINNY and PROFILER is None and n <= 5 and all(l[5] is not None and l[3].cout == 1 for l in layers):
+                # the single-output-channel output convs: all problems' weight (and bias) gradients in one launch
+                descs = [_desc(l[3], x.shape[0], x.shape[2], g.shape[2]) for x, g, l in zip(xs, gs, layers)]
+                dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+                rc = _lib.lib().stegan_conv1d_bwd_weight_skinny_multi(
+                    n, dptr, _ptr_array(xs), _ptr_array(gs), _ptr_array([l[5][0] for l in layers]),
+                    _ptr_array([l[5][1] if l[2] is not None else None for l in layers]), _stream())
+                if rc != 1:
+                    check(rc, "stegan_conv1d_bwd_weight_skinny_multi")
+                    done = True
+            if not done:
+                for x, g, l in zip(xs, gs, layers):
+                    if l[5] is not None:
+                        conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None)
         dxs = [None] * n
         need = [ctx.needs_input_grad[2 + i] for i in range(n)]
         if any(need):

@@ -180,3 +180,21 @@ def test_single_output_channel_multi_launch_equals_single_launches():
         assert torch.equal(y, y1)
         dx1 = ops.conv1d_bwd_data(dy, w, sc, None, None, c, x.shape[2])
         assert torch.equal(dx, dx1)
+    # weight + bias gradients of all five in one launch (fp32 atomics: equal to rounding)
+    from ste_gan_amd import _lib
+    import ctypes as C
+    n = len(shapes)
+    dws = [torch.full((1, s[1], 3), 0.5, device="cuda") for s in shapes]
+    dbs = [torch.full((1,), -2.0, device="cuda") for _ in shapes]
+    descs = [ops._desc(c, x.shape[0], x.shape[2], dy.shape[2]) for c, x, dy in zip(cfgs, xs, dys)]
+    dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    rc = _lib.lib().stegan_conv1d_bwd_weight_skinny_multi(n, dptr, ops._ptr_array(xs), ops._ptr_array(dys), ops._ptr_array(dws),
+                                                          ops._ptr_array(dbs), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    for x, dy, c, dw, db in zip(xs, dys, cfgs, dws, dbs):
+        dw1 = torch.full_like(dw, 0.5)
+        db1 = torch.full_like(db, -2.0)
+        ops.conv1d_bwd_weight(x, dy, c, dw1, db1)
+        assert float((dw - dw1).abs().max()) <= 1e-5 * float(dw1.abs().max())
+        assert float((db - db1).abs().max()) <= 1e-5 * float(db1.abs().max()) + 1e-6

@@ -129,6 +129,49 @@ __device__ __forceinline__ void att_stage(float* dst, const float* src, int n) {
     for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
+// the live rows of the relative-position table, 8 loads in flight per thread (same reason as att_stage_many)
+__device__ __forceinline__ void att_stage_emb(float* es, const float* __restrict__ emb, int h, int A, int T, int R, int EP) {
+    const int n = (2 * T - 1) * A;
+    for (int base = 0; base < n; base += 2048) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            const int r = i / A, a = i - r * A, rel = r - (T - 1);
+            v[u] = (i < n && rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + threadIdx.x;
+            const int r = i / A, a = i - r * A;
+            if (i < n) es[r * EP + a] = v[u];
+        }
+    }
+}
+
+// NA equally long arrays at once, all loads of a round of 4 x 256 elements per array issued before the first LDS store (the
+// loop above is load, wait, store, load, ...: staging q, k, v took 14 memory round trips in sequence, most of the kernel)
+template <int NA>
+__device__ __forceinline__ void att_stage_many(float* const (&dst)[NA], const float* const (&src)[NA], int n) {
+    for (int base = 0; base < n; base += 1024) {
+        float r[NA][4];
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                r[k][u] = i < n ? src[k][i] : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < NA; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = base + u * 256 + threadIdx.x;
+                if (i < n) dst[k][i] = r[k][u];
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
                                                              float* __restrict__ P, float* __restrict__ O, int H, int A,
                                                              int T, int R, float inv_sqrt_d) {
@@ -138,14 +181,13 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __rest
     const int EP = A + 1;
     float* qs = sm; float* ks = qs + AT; float* vs = ks + AT; float* es = vs + AT; float* Ps = es + (2 * T - 1) * EP;
     const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
-    att_stage(qs, qkv + base, AT);
-    att_stage(ks, qkv + base + (size_t)Cm * T, AT);
-    att_stage(vs, qkv + base + (size_t)2 * Cm * T, AT);
-    // table row for rel = r - (T - 1): zero when |rel| > R - 1 (masked below)
-    for (int i = threadIdx.x; i < (2 * T - 1) * A; i += 256) {
-        const int r = i / A, a = i - r * A, rel = r - (T - 1);
-        es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
+    {
+        float* const d3[3] = {qs, ks, vs};
+        const float* const s3[3] = {qkv + base, qkv + base + (size_t)Cm * T, qkv + base + (size_t)2 * Cm * T};
+        att_stage_many<3>(d3, s3, AT);
     }
+    // table row for rel = r - (T - 1): zero when |rel| > R - 1 (masked below)
+    att_stage_emb(es, emb, h, A, T, R, EP);
     block_sync();
     for (int ij = threadIdx.x; ij < T * T; ij += 256) {
         const int i = ij / T, j = ij - i * T, rel = j - i;
@@ -192,15 +234,14 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
     float* qs = sm; float* ks = qs + AT; float* vs = ks + AT; float* ds = vs + AT; float* es = ds + AT;
     float* Ps = es + (2 * T - 1) * EP; float* Ss = Ps + T * T;
     const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
-    att_stage(qs, qkv + base, AT);
-    att_stage(ks, qkv + base + (size_t)Cm * T, AT);
-    att_stage(vs, qkv + base + (size_t)2 * Cm * T, AT);
-    att_stage(ds, dO + ((size_t)b * Cm + h * A) * T, AT);
-    att_stage(Ps, P + (size_t)blockIdx.x * T * T, T * T);
-    for (int i = threadIdx.x; i < (2 * T - 1) * A; i += 256) {
-        const int r = i / A, a = i - r * A, rel = r - (T - 1);
-        es[r * EP + a] = (rel <= R - 1 && rel >= -(R - 1)) ? emb[((size_t)h * (2 * R - 1) + rel + R - 1) * A + a] : 0.f;
+    {
+        float* const d4[4] = {qs, ks, vs, ds};
+        const float* const s4[4] = {qkv + base, qkv + base + (size_t)Cm * T, qkv + base + (size_t)2 * Cm * T,
+                                    dO + ((size_t)b * Cm + h * A) * T};
+        att_stage_many<4>(d4, s4, AT);
     }
+    att_stage(Ps, P + (size_t)blockIdx.x * T * T, T * T);
+    att_stage_emb(es, emb, h, A, T, R, EP);
     block_sync();
     // dP[i][j] = sum_a dO[a][i] v[a][j]
     for (int ij = threadIdx.x; ij < T * T; ij += 256) {

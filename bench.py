@@ -157,6 +157,34 @@ def gen_infer(args, cfg, device, quiet=False):
     return line
 
 
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` outside a launcher: start N ranks (one per GPU) as FRESH child processes under
+    ``torch.distributed.run`` with the same arguments and relay rank 0's JSON line.  This process never touches the GPU
+    (nothing before this point initialises HIP; ``torch.cuda.device_count()`` does not on this image), and the ranks are
+    children, not an exec of this process."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not os.environ.get("STEGAN_BENCH_ONE_GPU"):
+        raise SystemExit(f"bench.py: --gpus {n} but this node shows {have} GPU(s) "
+                         "(STEGAN_BENCH_ONE_GPU=1 + STEGAN_BENCH_BACKEND=gloo rehearses N ranks on one card)")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    for l in r.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if r.returncode != 0 or len(lines) != 1:
+        raise SystemExit(f"bench.py: the {n}-rank run failed (exit {r.returncode}, {len(lines)} result lines)")
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,7 +201,11 @@ def main():
                     help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -361,13 +393,13 @@ def main():
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)
     if world > 1:
-        # every rank is done (rank 0 has printed): leave without running destructors.  Tearing down captured graphs, the
-        # RCCL communicator and the process group at interpreter exit aborted intermittently on this stack (SIGABRT after
-        # the result line, exit code 134), which a launcher reads as a failed run.
+        # ordered teardown (ste_gan_amd.parallel.shutdown): every rank is done, drain the device, release the captured graphs
+        # and the communication stream, then destroy the process group.  (Round 2 left through os._exit here: the abort it
+        # dodged came from graph captures in the default "global" error mode racing the RCCL watchdog's event queries --
+        # fixed by capture_error_mode="thread_local" in GraphedTrainStep; scripts/teardown_probe.py reproduces both.)
+        from ste_gan_amd.parallel import shutdown
         dist.barrier()
-        torch.cuda.synchronize()
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        shutdown(step, eager_step)
 
 
 if __name__ == "__main__":

@@ -345,12 +345,33 @@ int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, 
  * sum rect^2, mean rect], L1 mean against the real signal's features; summed over n_scales (<= 3).
  * x_* are (B,T,C).  *loss_slot += weight*loss; per_scale[n_scales] (nullable) = unweighted losses;
  * dx_gen (nullable) = d(weight*loss)/dx_gen.  workspace: stegan_multi_td_workspace_floats(B,C) floats.
- * T is limited by the 160 KiB LDS of a CU (9*T floats per row must fit in 150 KiB).
+ * stegan_multi_td_fwd_bwd is the reference's default configuration (9-tap filter, padded windowing) with rows short
+ * enough for LDS (9*T floats per row in 150 KiB); stegan_multi_td_fwd_bwd_ex takes every option of
+ * TimeDomainFeatureLoss.__init__ (time_domain_loss.py:20-33): avg_window = average_filter_window_size (odd),
+ * pad_windowing = apply_padding_windowing, and rows of any length -- when stegan_multi_td_scratch_floats() returns
+ * n > 0 the row buffers do not fit LDS and the caller passes a scratch of n floats (whole-utterance validation,
+ * train.py:329-336).
  */
 int64_t stegan_multi_td_workspace_floats(int32_t B, int32_t C);
 int stegan_multi_td_fwd_bwd(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
                             int32_t n_scales, const int32_t* win_host, const int32_t* shift_host, float weight,
                             float* loss_slot, float* per_scale, float* dx_gen, float* workspace, void* stream);
+int64_t stegan_multi_td_scratch_floats(int32_t B, int32_t T, int32_t C, int32_t n_scales, const int32_t* win_host,
+                                       const int32_t* shift_host, int32_t pad_windowing);
+int stegan_multi_td_fwd_bwd_ex(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
+                               int32_t n_scales, const int32_t* win_host, const int32_t* shift_host, int32_t avg_window,
+                               int32_t pad_windowing, float weight, float* loss_slot, float* per_scale, float* dx_gen,
+                               float* workspace, float* scratch, int64_t scratch_floats, void* stream);
+/* TimeDomainFeatureLoss.calculate_time_domain_features (time_domain_loss.py:58-69): x (B,T,C) -> feats (B,F,C,4),
+ * F = (T + 2*(pad_windowing ? win/2 : 0) - win) / shift + 1.  scratch: 3*B*C*T floats. */
+int stegan_td_features(const float* x, int32_t B, int32_t T, int32_t C, int32_t win, int32_t shift, int32_t avg_window,
+                       int32_t pad_windowing, float* feats, float* scratch, void* stream);
+/* AverageFilter.forward (layers/average_filter.py:22-28) on `rows` rows of length T: reflect pad by window/2 when
+ * pad_signal, AvgPool1d(window, stride 1); y has T (padded) or T - window + 1 columns.  _bwd: dx (rows,T) from dy. */
+int stegan_average_filter_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t window, int32_t pad_signal,
+                              void* stream);
+int stegan_average_filter_bwd(const float* dy, float* dx, int64_t rows, int32_t T, int32_t window, int32_t pad_signal,
+                              void* stream);
 /* weight * mean_rows ||target - pred + 1e-6||_2 (F.pairwise_distance, losses/emg_encoder_loss.py:63-67).
  * workspace: rows floats. */
 int stegan_su_loss_fwd_bwd(const float* target, const float* pred, int32_t rows, int32_t D, float weight,

@@ -75,6 +75,10 @@ SIGNATURES = {
     "stegan_pair_loss_fwd_bwd": [_P, _P, C.c_float, _I64, _I32, C.c_float, _P, _P, _P],
     "stegan_scale_by_scalar": [_P, _P, _P, _I64, _P],
     "stegan_multi_td_fwd_bwd": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, C.c_float, _P, _P, _P, _P, _P],
+    "stegan_multi_td_fwd_bwd_ex": [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _I64, _P],
+    "stegan_td_features": [_P, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _P, _P, _P],
+    "stegan_average_filter_fwd": [_P, _P, _I64, _I32, _I32, _I32, _P],
+    "stegan_average_filter_bwd": [_P, _P, _I64, _I32, _I32, _I32, _P],
     "stegan_su_loss_fwd_bwd": [_P, _P, _I32, _I32, C.c_float, _P, _P, _P, _P],
     "stegan_phoneme_ce_fwd_bwd": [_P, _P, _I32, _I32, _I32, C.c_float, _P, _P, _P, _P, _P, _P],
     "stegan_relpos_attention_fwd": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
@@ -101,6 +105,7 @@ SIGNATURES = {
 # symbols whose return value is not a status code
 INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_multi_td_workspace_floats": [_I32, _I32],
+                "stegan_multi_td_scratch_floats": [_I32, _I32, _I32, _I32, _P, _P, _I32],
                 "stegan_conv_prep_floats": [_D, _I32],
                 "stegan_conv_prep_bf16_elems": [_D, _I32],
                 "stegan_conv_prep_bf16_tiles": [_D],

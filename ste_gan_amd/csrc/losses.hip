@@ -99,29 +99,40 @@ __device__ __forceinline__ int refl(int t, int T) {        // reflect without ed
     return t;
 }
 
-// dst[t] = (1/9) sum_{j=-4..4} src[refl(t+j)]
-__device__ __forceinline__ void box9(const float* src, float* dst, int T) {
+// barrier of the time-domain kernels: their row buffers may live in global memory (long rows), so the wave's outstanding
+// stores AND loads are drained, not only its LDS operations
+__device__ __forceinline__ void td_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// dst[t] = (1/AW) sum_{j=-H..H} src[refl(t+j)],  H = AW / 2  (AverageFilter: reflect pad + AvgPool1d(AW, stride 1))
+__device__ __forceinline__ void boxN(const float* src, float* dst, int T, int AW) {
+    const int H = AW >> 1;
+    const float inv = 1.f / (float)AW;
     for (int t = threadIdx.x; t < T; t += 256) {
         float s = 0.f;
-#pragma unroll
-        for (int j = -4; j <= 4; ++j) s += src[refl(t + j, T)];
-        dst[t] = s * (1.f / 9.f);
+        for (int j = -H; j <= H; ++j) s += src[refl(t + j, T)];
+        dst[t] = s * inv;
     }
 }
 
-// adjoint of box9: dsrc[s] = sum over padded taps that read src[s]
-__device__ __forceinline__ float box9_pad_adj(const float* dy, int tau, int T) {   // d/dxpad[tau], tau in [0,T+8)
-    if (tau < 0 || tau >= T + 8) return 0.f;
+// adjoint of boxN: dsrc[s] = sum over padded taps that read src[s]
+__device__ __forceinline__ float boxN_pad_adj(const float* dy, int tau, int T, int AW) {   // d/dxpad[tau], tau in [0,T+AW-1)
+    if (tau < 0 || tau >= T + AW - 1) return 0.f;
     float s = 0.f;
-    const int lo = max(0, tau - 8), hi = min(T - 1, tau);
+    const int lo = max(0, tau - (AW - 1)), hi = min(T - 1, tau);
     for (int t = lo; t <= hi; ++t) s += dy[t];
-    return s * (1.f / 9.f);
+    return s / (float)AW;
 }
-__device__ __forceinline__ void box9_adjoint(const float* dy, float* dsrc, int T) {
+__device__ __forceinline__ void boxN_adjoint(const float* dy, float* dsrc, int T, int AW) {
+    const int H = AW >> 1;
     for (int s = threadIdx.x; s < T; s += 256) {
-        float g = box9_pad_adj(dy, s + 4, T);
-        if (s >= 1 && s <= 4) g += box9_pad_adj(dy, 4 - s, T);
-        if (s >= T - 5 && s <= T - 2) g += box9_pad_adj(dy, 4 + 2 * (T - 1) - s, T);
+        float g = boxN_pad_adj(dy, s + H, T, AW);
+        if (s >= 1 && s <= H) g += boxN_pad_adj(dy, H - s, T, AW);
+        if (s >= T - 1 - H && s <= T - 2) g += boxN_pad_adj(dy, H + 2 * (T - 1) - s, T, AW);
         dsrc[s] = g;
     }
 }
@@ -129,9 +140,12 @@ __device__ __forceinline__ void box9_adjoint(const float* dy, float* dsrc, int T
 __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__ x_real, const float* __restrict__ x_gen,
                                                        int T, int Cc, TDScale s0, TDScale s1, TDScale s2, float weight,
                                                        float* __restrict__ partial, float* __restrict__ dx_gen,
-                                                       int maxF) {
-    extern __shared__ float sm[];
-    // layout: xr, xg, low_r, low_g, rect_r, rect_g, tmp, dlow, drect  (9*T) + frame coefs 4*maxF
+                                                       int maxF, int AW, float* __restrict__ scratch) {
+    extern __shared__ float sm_dyn[];
+    // layout: xr, xg, low_r, low_g, rect_r, rect_g, tmp, dlow, drect  (9*T) + frame coefs 4*maxF -- in LDS, or, for rows too
+    // long for it (whole-utterance validation), in a global scratch row of the same layout (block-private: the barriers
+    // below order its stores and loads within the block)
+    float* sm = scratch ? scratch + (size_t)blockIdx.x * ((size_t)9 * T + 4 * maxF) : sm_dyn;
     float* xr = sm;            float* xg = xr + T;
     float* low_r = xg + T;     float* low_g = low_r + T;
     float* rect_r = low_g + T; float* rect_g = rect_r + T;
@@ -146,16 +160,16 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
         dlow[t] = 0.f;
         drect[t] = 0.f;
     }
-    block_sync();
-    box9(xr, tmp, T);   block_sync();
-    box9(tmp, low_r, T); block_sync();
-    box9(xg, tmp, T);   block_sync();
-    box9(tmp, low_g, T); block_sync();
+    td_sync();
+    boxN(xr, tmp, T, AW);   td_sync();
+    boxN(tmp, low_r, T, AW); td_sync();
+    boxN(xg, tmp, T, AW);   td_sync();
+    boxN(tmp, low_g, T, AW); td_sync();
     for (int t = threadIdx.x; t < T; t += 256) {
         rect_r[t] = fabsf(xr[t] - low_r[t]);
         rect_g[t] = fabsf(xg[t] - low_g[t]);
     }
-    block_sync();
+    td_sync();
 
     const TDScale sc[3] = {s0, s1, s2};
     float loss_acc[3] = {0.f, 0.f, 0.f};
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
             cf[3 * maxF + f] = sgn(d3) * k * invW;
         }
         loss_acc[si] = l * S.inv_n;
-        block_sync();
+        td_sync();
         if (dx_gen) {
             // gather form of the frame/reflect adjoint: position t receives from padded taus t+P and its mirrors
             for (int t = threadIdx.x; t < T; t += 256) {
@@ -208,7 +222,7 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
                 drect[t] += gr;
             }
         }
-        block_sync();
+        td_sync();
     }
     // loss partials: [row][3]
     for (int si = 0; si < 3; ++si) {
@@ -217,17 +231,75 @@ __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__
     }
     if (!dx_gen) return;
     // rect = |x - low|:  dh = sign(x-low)*drect ; dx = dh + A^T A^T (dlow - dh)
-    block_sync();
+    td_sync();
     for (int t = threadIdx.x; t < T; t += 256) {
         const float h = xg[t] - low_g[t];
         const float dh = (h > 0.f ? 1.f : (h < 0.f ? -1.f : 0.f)) * drect[t];
         rect_g[t] = dh;                  // reuse as dh
         dlow[t] -= dh;
     }
-    block_sync();
-    box9_adjoint(dlow, tmp, T);  block_sync();
-    box9_adjoint(tmp, low_g, T); block_sync();
+    td_sync();
+    boxN_adjoint(dlow, tmp, T, AW);  td_sync();
+    boxN_adjoint(tmp, low_g, T, AW); td_sync();
     for (int t = threadIdx.x; t < T; t += 256) dx_gen[((size_t)b * T + t) * Cc + c] = rect_g[t] + low_g[t];
+}
+
+// calculate_time_domain_features of ONE signal: one block per (b, c) row; row buffers (x, low / tmp, rect) in global scratch
+__global__ __launch_bounds__(256) void td_features_kernel(const float* __restrict__ x, int T, int Cc, int W, int S, int P, int F,
+                                                          int AW, float* __restrict__ feats, float* __restrict__ scratch) {
+    float* xr = scratch + (size_t)blockIdx.x * 3 * T;
+    float* low = xr + T;
+    float* tmp = low + T;
+    const int row = blockIdx.x, b = row / Cc, c = row % Cc;
+    for (int t = threadIdx.x; t < T; t += 256) xr[t] = x[((size_t)b * T + t) * Cc + c];
+    td_sync();
+    boxN(xr, tmp, T, AW); td_sync();
+    boxN(tmp, low, T, AW); td_sync();
+    for (int t = threadIdx.x; t < T; t += 256) tmp[t] = fabsf(xr[t] - low[t]);       // rectified high-frequency part
+    td_sync();
+    for (int f = threadIdx.x; f < F; f += 256) {
+        float ml = 0.f, pl = 0.f, pr = 0.f, mr = 0.f;
+        for (int j = 0; j < W; ++j) {
+            const int t = refl(f * S + j - P, T);
+            const float a = low[t], r = tmp[t];
+            ml += a; pl += a * a; pr += r * r; mr += r;
+        }
+        float* o = feats + (((size_t)b * F + f) * Cc + c) * 4;
+        o[0] = ml / (float)W; o[1] = pl; o[2] = pr; o[3] = mr / (float)W;
+    }
+}
+
+// AverageFilter forward (adjoint == 0): y[r][t] = (1/AW) sum_j xpad[r][t + j], xpad = reflect pad by P (or x itself);
+// adjoint: dx[r][s] = sum over the padded positions that mirror to s of (1/AW) sum_{t : t <= tau < t + AW} dy[r][t]
+__global__ __launch_bounds__(256) void avg_filter_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int T,
+                                                         int To, int AW, int P, int adjoint) {
+    const float inv = 1.f / (float)AW;
+    if (!adjoint) {
+        const long n = rows * To;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            const long r = i / To;
+            const int t = (int)(i - r * To);
+            float s = 0.f;
+            for (int j = 0; j < AW; ++j) s += src[r * T + refl(t + j - P, T)];
+            dst[i] = s * inv;
+        }
+        return;
+    }
+    const long n = rows * T;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / T;
+        const int s_ = (int)(i - r * T);
+        const float* dy = src + r * To;
+        int taus[3] = {s_ + P, (s_ >= 1 && s_ <= P) ? P - s_ : -1, (s_ >= T - 1 - P && s_ <= T - 2) ? P + 2 * (T - 1) - s_ : -1};
+        float g = 0.f;
+        for (int q = 0; q < 3; ++q) {
+            const int tau = taus[q];
+            if (tau < 0) continue;
+            const int lo = max(0, tau - (AW - 1)), hi = min(To - 1, tau);
+            for (int t = lo; t <= hi; ++t) g += dy[t];
+        }
+        dst[i] = g * inv;
+    }
 }
 
 // out[slot_base + s] += sum_rows partial[row][s]   (fixed order -> deterministic)
@@ -382,34 +454,113 @@ extern "C" int stegan_scale_by_scalar(const float* x, const float* scalar_dev, f
 
 extern "C" int64_t stegan_multi_td_workspace_floats(int32_t B, int32_t C) { return (int64_t)B * C * 3; }
 
-extern "C" int stegan_multi_td_fwd_bwd(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
-                                       int32_t n_scales, const int32_t* win_host, const int32_t* shift_host,
-                                       float weight, float* loss_slot, float* per_scale, float* dx_gen,
-                                       float* workspace, void* stream) {
+namespace {
+constexpr size_t TD_LDS_MAX = 150 * 1024;
+inline int td_frames(int T, int W, int S, int pad) { return (T + 2 * (pad ? W / 2 : 0) - W) / S + 1; }
+}
+
+// row buffer of the time-domain kernels in floats (9 T + 4 maxF); rows that exceed the LDS budget need a global scratch
+// of B * C such rows (stegan_multi_td_fwd_bwd_ex)
+extern "C" int64_t stegan_multi_td_scratch_floats(int32_t B, int32_t T, int32_t C, int32_t n_scales, const int32_t* win_host,
+                                                  const int32_t* shift_host, int32_t pad_windowing) {
+    if (B <= 0 || T <= 0 || C <= 0 || n_scales < 1 || n_scales > 3 || !win_host || !shift_host) return -1;
+    int maxF = 1;
+    for (int i = 0; i < n_scales; ++i) {
+        if (win_host[i] < 1 || shift_host[i] < 1) return -1;
+        const int F = td_frames(T, win_host[i], shift_host[i], pad_windowing);
+        if (F > maxF) maxF = F;
+    }
+    const size_t row = (size_t)9 * T + 4 * maxF;
+    return row * sizeof(float) <= TD_LDS_MAX ? 0 : (int64_t)row * B * C;
+}
+
+// ste_gan/losses/time_domain_loss.py:20-41 in full: any odd average-filter width, with or without the reflect-padded
+// windowing.  scratch (stegan_multi_td_scratch_floats; may be null when that returns 0) holds the row buffers of rows
+// too long for LDS (whole-utterance validation).
+extern "C" int stegan_multi_td_fwd_bwd_ex(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
+                                          int32_t n_scales, const int32_t* win_host, const int32_t* shift_host,
+                                          int32_t avg_window, int32_t pad_windowing, float weight, float* loss_slot,
+                                          float* per_scale, float* dx_gen, float* workspace, float* scratch,
+                                          int64_t scratch_floats, void* stream) {
     STEGAN_CHECK_ARG(x_real && x_gen && workspace && B > 0 && T > 0 && C > 0);
     STEGAN_CHECK_ARG(n_scales >= 1 && n_scales <= 3 && win_host && shift_host);
+    STEGAN_CHECK_ARG(avg_window >= 1 && (avg_window & 1) && avg_window / 2 < T);      // reflect padding needs pad < length
     TDScale sc[3] = {TDScale{1, 1, 0, 0, 0.f}, TDScale{1, 1, 0, 0, 0.f}, TDScale{1, 1, 0, 0, 0.f}};
     int maxF = 1;
     for (int i = 0; i < n_scales; ++i) {
-        const int W = win_host[i], S = shift_host[i], P = W / 2;
+        const int W = win_host[i], S = shift_host[i], P = pad_windowing ? W / 2 : 0;
         STEGAN_CHECK_ARG(W >= 1 && S >= 1);
-        STEGAN_CHECK_ARG(P < T && T > 4);          // reflect padding needs pad < length (ATen raises likewise)
-        const int F = (T + 2 * P - W) / S + 1;
+        STEGAN_CHECK_ARG(P < T && W <= T + 2 * P);          // (ATen raises likewise: pad >= length, window > signal)
+        const int F = td_frames(T, W, S, pad_windowing);
         STEGAN_CHECK_ARG(F >= 1);
         sc[i] = TDScale{W, S, P, F, 1.f / ((float)B * F * C * 4.f)};
         if (F > maxF) maxF = F;
     }
-    const size_t lds = ((size_t)9 * T + 4 * maxF) * sizeof(float);
-    STEGAN_CHECK_ARG(lds <= 150 * 1024);
+    const size_t row = (size_t)9 * T + 4 * maxF;
+    size_t lds = row * sizeof(float);
+    float* scr = nullptr;
+    if (lds > TD_LDS_MAX) {
+        STEGAN_CHECK_ARG(scratch && scratch_floats >= (int64_t)row * B * C);
+        scr = scratch; lds = 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)multi_td_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)multi_td_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TD_LDS_MAX);
         attr_set = true;
     }
     hipLaunchKernelGGL(multi_td_kernel, dim3(B * C), dim3(256), lds, s, x_real, x_gen, T, C, sc[0], sc[1], sc[2], weight,
-                       workspace, dx_gen, maxF);
+                       workspace, dx_gen, maxF, avg_window, scr);
     hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(256), 0, s, workspace, B * C, weight, loss_slot, per_scale);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_multi_td_fwd_bwd(const float* x_real, const float* x_gen, int32_t B, int32_t T, int32_t C,
+                                       int32_t n_scales, const int32_t* win_host, const int32_t* shift_host,
+                                       float weight, float* loss_slot, float* per_scale, float* dx_gen,
+                                       float* workspace, void* stream) {
+    return stegan_multi_td_fwd_bwd_ex(x_real, x_gen, B, T, C, n_scales, win_host, shift_host, 9, 1, weight, loss_slot,
+                                      per_scale, dx_gen, workspace, nullptr, 0, stream);
+}
+
+// TimeDomainFeatureLoss.calculate_time_domain_features (time_domain_loss.py:58-69): x (B, T, C) -> (B, F, C, 4) =
+// [mean(low), sum(low^2), sum(rect^2), mean(rect)] per frame; scratch: B * C rows of 3 T floats.
+extern "C" int stegan_td_features(const float* x, int32_t B, int32_t T, int32_t C, int32_t win, int32_t shift,
+                                  int32_t avg_window, int32_t pad_windowing, float* feats, float* scratch, void* stream) {
+    STEGAN_CHECK_ARG(x && feats && scratch && B > 0 && T > 0 && C > 0 && win >= 1 && shift >= 1);
+    STEGAN_CHECK_ARG(avg_window >= 1 && (avg_window & 1) && avg_window / 2 < T);
+    const int P = pad_windowing ? win / 2 : 0;
+    STEGAN_CHECK_ARG(P < T && win <= T + 2 * P);
+    const int F = td_frames(T, win, shift, pad_windowing);
+    hipLaunchKernelGGL(td_features_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)stream, x, T, C, win, shift, P, F,
+                       avg_window, feats, scratch);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+// AverageFilter (layers/average_filter.py:10-28) on rows of length T: reflect pad by window / 2 (pad_signal) + AvgPool1d
+// (window, stride 1).  Output length T (padded) or T - window + 1.  The backward is the adjoint (dx from dy).
+extern "C" int stegan_average_filter_fwd(const float* x, float* y, int64_t rows, int32_t T, int32_t window, int32_t pad_signal,
+                                         void* stream) {
+    STEGAN_CHECK_ARG(x && y && rows > 0 && T > 0 && window >= 1);
+    STEGAN_CHECK_ARG(pad_signal ? (window / 2 < T) : (window <= T));
+    const int To = pad_signal ? T + 2 * (window / 2) - window + 1 : T - window + 1;
+    const long n = rows * To;
+    hipLaunchKernelGGL(avg_filter_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, y, rows, T, To, window,
+                       pad_signal ? window / 2 : 0, 0);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_average_filter_bwd(const float* dy, float* dx, int64_t rows, int32_t T, int32_t window, int32_t pad_signal,
+                                         void* stream) {
+    STEGAN_CHECK_ARG(dy && dx && rows > 0 && T > 0 && window >= 1);
+    STEGAN_CHECK_ARG(pad_signal ? (window / 2 < T) : (window <= T));
+    const int To = pad_signal ? T + 2 * (window / 2) - window + 1 : T - window + 1;
+    const long n = rows * T;
+    hipLaunchKernelGGL(avg_filter_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, dx, rows, T, To, window,
+                       pad_signal ? window / 2 : 0, 1);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

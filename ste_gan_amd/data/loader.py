@@ -124,8 +124,12 @@ def _utt_mode(utt_id: str) -> str:
     return utt_id.split("__")[-1]                                          # emg_dataset.py:191-193
 
 
-def _file_id(stem: str, prefix: str = "emg_synth__") -> str:
-    return stem.split(prefix)[1] if stem.startswith(prefix) else stem      # emg_dataset.py:195-200
+def _file_id(emg_path: Path, emg_synth_prefix: str = "emg_synth__") -> str:
+    """emg_dataset.py:195-200: utterances of a SYNTHETIC-EMG directory (one whose name carries the prefix) share the
+    units / phonemes / transcription files of the recording they were generated from, named by the 2nd id field."""
+    if emg_synth_prefix in emg_path.parent.name:
+        return emg_path.stem.split("__")[1]
+    return emg_path.stem
 
 
 def read_partition(root_dir: Path, partition: str, session_id_to_idx: Optional[Dict] = None,
@@ -152,7 +156,7 @@ def read_partition(root_dir: Path, partition: str, session_id_to_idx: Optional[D
                 or (only_include_silent and not silent):
             n_filtered += 1
             continue
-        fid = _file_id(utt_id)
+        fid = _file_id(emg_path)
         units = torch.load(split / DataDir.SPEECH_UNITS / f"{fid}.pt")
         phonemes = torch.load(split / DataDir.PHONEMES / f"{fid}.pt")
         mfcc_path = split / DataDir.MFCCS / f"{utt_id}.pt"

@@ -1,10 +1,12 @@
 """Time-domain feature losses, host side -- mirrors ``ste_gan/losses/time_domain_loss.py``.
 
 ``TimeDomainFeatureLoss`` (:13-73) and ``MultiTimeDomainFeatureLoss`` (:76-107) keep their
-constructor arguments and ``forward`` / ``time_domain_loss`` results; the whole chain (two reflect
-padded 9-tap average filters, rectification, reflect padded framing, the four frame features for
-both signals, the L1 means of up to three scales and d loss / d x_generated) is ONE kernel launch
-with every intermediate in LDS (ste_gan_amd/csrc/losses.hip).
+constructor arguments (every option: window / shift, ``apply_padding_windowing``, any odd
+``average_filter_window_size``) and ``forward`` / ``time_domain_loss`` / ``calculate_time_domain_features`` results;
+the whole loss chain (two reflect padded average filters, rectification, optionally reflect padded framing, the four
+frame features for both signals, the L1 means of up to three scales and d loss / d x_generated) is ONE kernel launch
+with every intermediate in LDS -- or, for rows too long for LDS (whole utterances in validation), in a global scratch
+(ste_gan_amd/csrc/losses.hip).
 """
 from __future__ import annotations
 
@@ -15,23 +17,35 @@ import torch.nn as nn
 from torch import Tensor
 
 from .. import ops
+from ..layers.average_filter import AverageFilter
 
 
 class TimeDomainFeatureLoss(nn.Module):
     def __init__(self, num_channels, win_size_samples: int = 21, win_shift_samples: int = 8,
                  apply_padding_windowing: bool = True, average_filter_window_size: int = 9):
         super().__init__()
-        if not apply_padding_windowing or average_filter_window_size != 9:
-            raise ValueError("ste_gan_amd.TimeDomainFeatureLoss supports the configuration the reference uses: "
-                             "padded windowing and a 9-tap average filter")
+        if average_filter_window_size < 1 or average_filter_window_size % 2 == 0:
+            raise ValueError("average_filter_window_size must be odd (average_filter.py:14: the filter keeps the length)")
         self.num_channels = num_channels
+        self.average_filter = AverageFilter(num_channels, average_filter_window_size)
         self.win_size_samples = win_size_samples
         self.win_shift_samples = win_shift_samples
         self.apply_padding_windowing = apply_padding_windowing
         self.avg_filter_window_size = average_filter_window_size
 
+    def double_average(self, x: Tensor) -> Tensor:
+        """(B, T, C) -> (B, T, C): the average filter applied twice along time (time_domain_loss.py:52-56)."""
+        y = self.average_filter(self.average_filter(ops.btc_to_bct(x)))
+        return y.transpose(1, 2).contiguous()
+
+    def calculate_time_domain_features(self, raw_x: Tensor) -> Tensor:
+        """(B, T, C) -> (B, frames, C, 4): [mean(low), sum(low^2), sum(rect^2), mean(rect)] (time_domain_loss.py:58-69)."""
+        return ops.td_features(raw_x, self.win_size_samples, self.win_shift_samples, self.avg_filter_window_size,
+                               self.apply_padding_windowing)
+
     def time_domain_loss(self, x_real: Tensor, x_generated: Tensor):
-        loss, _ = ops.multi_td_loss(x_real, x_generated, (self.win_size_samples,), (self.win_shift_samples,))
+        loss, _ = ops.multi_td_loss(x_real, x_generated, (self.win_size_samples,), (self.win_shift_samples,),
+                                    self.avg_filter_window_size, self.apply_padding_windowing)
         return loss
 
     forward = time_domain_loss

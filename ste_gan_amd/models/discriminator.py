@@ -158,6 +158,7 @@ class _MultiDisc(nn.Module):
         scale = [None] * len(self.multi_scale_disc)
         run = lambda i: self.multi_scale_disc[i](xs[i], sn_pre[i] if sn_pre is not None else None)
         if side is not None:
+            self._handoff(side, [x] + xs[len(scale) - n_side:])
             with torch.cuda.stream(side):
                 results = self._pooled_forward(x)
                 for i in range(len(scale) - n_side, len(scale)):       # balance: the period branch is the shorter one
@@ -169,6 +170,16 @@ class _MultiDisc(nn.Module):
         if side is not None:
             main.wait_stream(side)
         return results + scale
+
+    @staticmethod
+    def _handoff(side, tensors):
+        """Tensors allocated on the calling stream and consumed on ``side`` (forward AND, as saved tensors, by the side
+        branch's backward: the first conv's weight gradient reads xs[i] there).  Without this the caching allocator may
+        hand such a block back to the calling stream's pool as soon as autograd drops the saved tensor, while the side
+        stream's kernel is still queued -- inside a capture the reuse would be baked into the replayed graph."""
+        for t in tensors:
+            if t.is_cuda:
+                t.record_stream(side)
 
     def _scales_on_side(self):
         """How many of the LAST scale discriminators run on the period branch's stream (STEGAN_D_SIDE_SCALES)."""
@@ -279,6 +290,7 @@ class _MultiDisc(nn.Module):
             return ("both", disc(xs[i]), n)
 
         if side is not None:
+            self._handoff(side, [both] + xs[ns - n_side:])
             with torch.cuda.stream(side):
                 pooled = self._pooled_forward(both)
                 for i in range(ns - n_side, ns):

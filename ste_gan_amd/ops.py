@@ -385,6 +385,8 @@ F32_STREAMS = os.environ.get("STEGAN_F32_STREAMS", "1") == "1"      # the discri
                                                                      # streams in fp32 mode too: 19.2 -> 17.1 ms/step
 WGRAD_BATCH = int(os.environ.get("STEGAN_WGRAD_BATCH", "5"))        # weight gradients launched per fork (8.14 ms/step; 8.30 with 1, 8.21 with 2, 8.17 with 3, 8.16 with 4, 8.20 with 8)
 _WG_PENDING: list = []
+_WG_USED: dict = {}            # side streams forked since the last wgrad_join() (only those are joined: waiting on a
+                               # stream that took no part in the current capture would be a capture-isolation error)
 
 
 def _wgrad_flush() -> None:
@@ -394,6 +396,7 @@ def _wgrad_flush() -> None:
         _WG_SIDE.append(torch.cuda.Stream())
     side = _WG_SIDE[_WG_NEXT[0] % WGRAD_STREAMS]
     _WG_NEXT[0] += 1
+    _WG_USED[side.cuda_stream] = side
     side.wait_stream(torch.cuda.current_stream())       # ONE cross-queue edge for the whole batch (11 us each inside a
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
         for x, dy, cfg, dw, db in _WG_PENDING:
@@ -429,10 +432,10 @@ def wgrad_join() -> None:
     (_wgrad_sink) and the backward nodes that ran on other streams (_sink_touch)."""
     _wgrad_flush()
     cur = torch.cuda.current_stream()
-    if _WG_KEEP:
-        for s_ in _WG_SIDE:
-            cur.wait_stream(s_)
-        _WG_KEEP.clear()
+    for s_ in _WG_USED.values():
+        cur.wait_stream(s_)
+    _WG_USED.clear()
+    _WG_KEEP.clear()
     for key, s_ in list(_SINK_STREAMS.items()):
         if key != cur.cuda_stream:
             cur.wait_stream(s_)
@@ -1196,7 +1199,7 @@ def mse_to_const(a, target: float):
 
 class _MultiTDFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_real, x_gen, wins, shifts):
+    def forward(ctx, x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True):
         x_real = _gpu_f32(x_real, "x_real")
         x_gen = _gpu_f32(x_gen, "x_generated")
         if x_real.shape != x_gen.shape:
@@ -1211,8 +1214,14 @@ class _MultiTDFn(torch.autograd.Function):
         dx = torch.empty_like(x_gen) if ctx.needs_input_grad[1] else None
         wa = (C.c_int32 * n)(*wins)
         sa = (C.c_int32 * n)(*shifts)
-        check(L.stegan_multi_td_fwd_bwd(_p(x_real), _p(x_gen), B, T, Cc, n, wa, sa, 1.0, _p(loss), _p(per), _p(dx), _p(ws),
-                                        _stream()), "stegan_multi_td_fwd_bwd")
+        # rows too long for LDS (whole utterances in validation) keep their row buffers in a global scratch
+        ns = int(L.stegan_multi_td_scratch_floats(B, T, Cc, n, wa, sa, int(pad_windowing)))
+        if ns < 0:
+            raise RuntimeError("stegan_multi_td_scratch_floats: invalid argument or unsupported shape")
+        scratch = torch.empty(ns, device=x_gen.device, dtype=torch.float32) if ns > 0 else None
+        check(L.stegan_multi_td_fwd_bwd_ex(_p(x_real), _p(x_gen), B, T, Cc, n, wa, sa, int(avg_window), int(pad_windowing),
+                                           1.0, _p(loss), _p(per), _p(dx), _p(ws), _p(scratch), ns, _stream()),
+              "stegan_multi_td_fwd_bwd_ex")
         ctx.save_for_backward(dx)
         ctx.mark_non_differentiable(per)
         return loss, per
@@ -1220,11 +1229,57 @@ class _MultiTDFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gper):
         (dx,) = ctx.saved_tensors
-        return None, (_chain(dx, g) if dx is not None else None), None, None
+        return None, (_chain(dx, g) if dx is not None else None), None, None, None, None
 
 
-def multi_td_loss(x_real, x_gen, wins, shifts):
-    return _MultiTDFn.apply(x_real.detach(), x_gen, tuple(wins), tuple(shifts))
+def multi_td_loss(x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True):
+    return _MultiTDFn.apply(x_real.detach(), x_gen, tuple(wins), tuple(shifts), int(avg_window), bool(pad_windowing))
+
+
+def td_features(x: Tensor, win: int, shift: int, avg_window: int = 9, pad_windowing: bool = True) -> Tensor:
+    """TimeDomainFeatureLoss.calculate_time_domain_features (time_domain_loss.py:58-69): (B, T, C) -> (B, F, C, 4), no
+    gradient (the loss kernel carries its own backward)."""
+    x = _gpu_f32(x.detach(), "raw_x")
+    B, T, Cc = x.shape
+    P = win // 2 if pad_windowing else 0
+    if win > T + 2 * P or P >= T:
+        raise RuntimeError(f"maximum size for tensor at dimension 1 is {T + 2 * P} but size is {win}")
+    F = (T + 2 * P - win) // shift + 1
+    feats = torch.empty((B, F, Cc, 4), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(3 * B * Cc * T, device=x.device, dtype=torch.float32)
+    check(_lib.lib().stegan_td_features(_p(x), B, T, Cc, int(win), int(shift), int(avg_window), int(pad_windowing), _p(feats),
+                                        _p(scratch), _stream()), "stegan_td_features")
+    return feats
+
+
+class _AverageFilterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, window: int, pad_signal: bool):
+        x = _gpu_f32(x, "x")
+        T = x.shape[-1]
+        rows = x.numel() // T
+        To = T if pad_signal else T - window + 1
+        if (pad_signal and window // 2 >= T) or To < 1:
+            raise RuntimeError(f"Argument #4: Padding size should be less than the corresponding input dimension, but got: "
+                               f"padding ({window // 2}, {window // 2}) at dimension {x.dim() - 1} of input {list(x.shape)}")
+        y = torch.empty(x.shape[:-1] + (To,), device=x.device, dtype=torch.float32)
+        check(_lib.lib().stegan_average_filter_fwd(_p(x), _p(y), rows, T, window, int(pad_signal), _stream()),
+              "stegan_average_filter_fwd")
+        ctx.dims = (rows, T, window, pad_signal, x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, T, window, pad_signal, shape = ctx.dims
+        dy = _gpu_f32(dy, "grad_output")
+        dx = torch.empty(shape, device=dy.device, dtype=torch.float32)
+        check(_lib.lib().stegan_average_filter_bwd(_p(dy), _p(dx), rows, T, window, int(pad_signal), _stream()),
+              "stegan_average_filter_bwd")
+        return dx, None, None
+
+
+def average_filter(x: Tensor, window: int = 9, pad_signal: bool = True) -> Tensor:
+    return _AverageFilterFn.apply(x, int(window), bool(pad_signal))
 
 
 class _SULossFn(torch.autograd.Function):

@@ -48,6 +48,30 @@ class FlatGradAllReduce:
         if handle is not None:
             torch.cuda.current_stream().wait_event(handle)
 
+    def close(self) -> None:
+        """Drain and drop the communication stream (part of the ordered shutdown, :func:`shutdown`)."""
+        if self._stream is not None:
+            self._stream.synchronize()
+            self._stream = None
+
+
+def shutdown(*steps) -> None:
+    """Ordered end of a torch.distributed job: drain the device, release what the captured steps hold (graphs + their
+    memory pool, static batches, the communication stream: ``close()`` of GraphedTrainStep / GANTrainStep), drain again,
+    and only then destroy the process group.  destroy_process_group() tears down the RCCL communicator and its
+    watchdog; nothing of this package may still be in flight on, or hold events of, the streams RCCL used."""
+    import gc
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+    for st in steps:
+        if st is not None and hasattr(st, "close"):
+            st.close()
+    gc.collect()
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.synchronize()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
 
 def shard_batch(batch: dict, rank: int, world_size: int) -> dict:
     """Contiguous batch-dimension shard of a DataType-keyed batch dict for this rank."""

@@ -283,6 +283,15 @@ class GANTrainStep:
         self.last = out
         return out
 
+    def close(self) -> None:
+        """Release what the step holds on the device side of the data-parallel exchange (ordered shutdown,
+        ``parallel.shutdown``)."""
+        self._st = None
+        self.last = {}
+        self._d_handle = self._g_handle = None
+        if self.comm is not None:
+            self.comm.close()
+
     @staticmethod
     def read_stats(out: Dict[str, torch.Tensor]) -> Dict[str, float]:
         """Single synchronising readback of the step's scalars (the reference pays ~10 .item() syncs)."""
@@ -331,7 +340,8 @@ class GraphedTrainStep:
         # capture_error_mode "thread_local": with a process group alive, the RCCL watchdog THREAD polls its work events with
         # hipEventQuery at any time; in the default "global" mode such a call from another thread invalidates a capture in
         # progress (hipErrorStreamCaptureInvalidated, then the watchdog aborts the process) -- seen once in three runs.
-        mode = dict(capture_error_mode="thread_local")
+        # (STEGAN_CAPTURE_ERROR_MODE=global: diagnostic hook of scripts/teardown_probe.py, which reproduces that abort)
+        mode = dict(capture_error_mode=os.environ.get("STEGAN_CAPTURE_ERROR_MODE", "thread_local"))
         if os.environ.get("STEGAN_MAIN_PRIORITY"):            # experiment hook: capture on a stream with a priority
             mode["stream"] = torch.cuda.Stream(priority=int(os.environ["STEGAN_MAIN_PRIORITY"]))
         if step.comm is None:
@@ -396,6 +406,17 @@ class GraphedTrainStep:
         g3.replay()
         self._after_replay()
         return self.out
+
+    def close(self) -> None:
+        """Ordered teardown: drain the device, destroy the captured graphs (and with them the shared memory pool), drop the
+        static batch and the step's communication stream.  Called by ``parallel.shutdown`` before the process group goes."""
+        torch.cuda.synchronize()
+        self.graph = None
+        self.graphs = None
+        self.out = self.last = None
+        self.static = {}
+        self.step.close()
+        torch.cuda.synchronize()
 
     def _after_replay(self):
         """The replayed optimiser kernels changed the weights behind the host's back: mark every prepared weight copy stale
@@ -473,7 +494,15 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
     try:
         return _train(cfg, model_directory, checkpoint, torch_device, debug, emg_enc_ckpt, loaders)
     finally:
+        # ordered release of what the run captured (graphs + their pool, static batches, the communication stream): the
+        # caller may destroy the process group next (main(), parallel.shutdown)
+        for st in reversed(_LIVE_STEPS):
+            st.close()
+        _LIVE_STEPS.clear()
         ops.set_compute_dtype(previous)
+
+
+_LIVE_STEPS: list = []          # the (graphed) steps of the run in progress, closed by train() on the way out
 
 
 def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug: bool, emg_enc_ckpt: Path = None,
@@ -526,6 +555,7 @@ def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debu
         train_loader.save_session_and_speaking_mode_mapping_json(model_directory)          # train.py:121-122
 
     step_fn = GANTrainStep(cfg, netG, netD, emg_encoder_loss, multi_td_loss, optG, optD)
+    _LIVE_STEPS.append(step_fn)
     # hipGraph replay per batch SHAPE: an eager step is ~800 launches and bound by the host (22.7 ms against 8.8 ms of GPU
     # time at B = 64).  The first batch of a shape runs eagerly -- that IS its training step, and it warms every lazy
     # allocation -- then the step is captured (capture executes nothing) and later batches of that shape replay it.
@@ -556,6 +586,7 @@ def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debu
                 stats = step_fn.read_stats(out)                        # (read before a capture runs the Python side again)
                 if len(graphed) < 4:                                   # more distinct shapes than that: the rest stay eager
                     graphed[key] = GraphedTrainStep(step_fn, batch, warmup=0)
+                    _LIVE_STEPS.append(graphed[key])
             if stats is None:
                 stats = step_fn.read_stats(out)
             for tag in tags:
@@ -683,7 +714,8 @@ def main(cfg, continue_run: bool, debug: bool, emg_enc_ckpt: Path, **kwargs):
         train(cfg, output_directory, checkpoint, device, debug, emg_enc_ckpt)
     finally:
         if ddp_device is not None:
-            dist.destroy_process_group()
+            from .parallel import shutdown
+            shutdown()                         # train() has released its graphs / comm stream: drain, THEN destroy the group
 
 
 def _plain(d):

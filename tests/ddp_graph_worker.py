@@ -1,4 +1,6 @@
-"""Child process of test_gpu_train_step.py::test_three_graph_replay_with_process_group_matches_golden."""
+"""The three-graph replay under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
+(``parallel.shutdown``); run in-process by test_gpu_train_step.py::test_three_graph_replay_with_process_group_matches_golden
+and usable as a script."""
 import os
 import sys
 
@@ -39,8 +41,9 @@ def main():
         close(norms(netG.state_dict().values()), g[f"s{s}.g_param_norm"], 2e-5, f"s{s}.g_param_norm")
         close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
     torch.cuda.synchronize()
+    from ste_gan_amd.parallel import shutdown
+    shutdown(gs, step)                 # ordered teardown: graphs + comm stream released, then destroy_process_group
     print("RESULT OK", flush=True)
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,52 @@
+"""Child process (one per rank) of test_gpu_ddp_step.py: two ranks share the one card of a GPU box and exchange gradients
+through the host (gloo).  Each rank runs GANTrainStep -- eagerly or as three replayed hipGraphs (argv[2]) -- on ITS shard
+of a detfill batch for two optimiser steps and writes its parameters; the parent compares the replicas with each other
+and with the single-process step on the whole batch.  Leaves through ``parallel.shutdown`` (ordered teardown), not os._exit."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+
+def main():
+    out_dir, mode = sys.argv[1], sys.argv[2]
+    from test_gpu_ddp_step import STEPS, build_nets, full_batch, to_device_batch
+    from ste_gan_amd import ops
+    from ste_gan_amd.parallel import shard_batch, shutdown
+    from ste_gan_amd.train import GraphedTrainStep
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ops.set_compute_dtype(os.environ.get("DDP_STEP_DTYPE", "f32"))
+    netG, netD, optG, optD, step = build_nets()
+    assert step.comm is not None and step.comm.world_size == world
+    shards = [to_device_batch(shard_batch(full_batch(s), rank, world)) for s in range(STEPS)]
+    runner = step
+    if mode == "graph":
+        sdG = {k: v.clone() for k, v in netG.state_dict().items()}
+        sdD = {k: v.clone() for k, v in netD.state_dict().items()}
+        runner = GraphedTrainStep(step, shards[0], warmup=2)
+        assert runner.graphs is not None and len(runner.graphs) == 3
+        netG.load_state_dict(sdG); netD.load_state_dict(sdD)
+        for opt in (optG, optD):
+            opt.reset_state()
+    losses = []
+    for s in range(STEPS):
+        st = runner.read_stats(runner(shards[s]))
+        losses.append([st["discriminator"], st["generator"]])
+    torch.cuda.synchronize()
+    torch.save({"g": {k: v.cpu() for k, v in netG.state_dict().items()}, "d": {k: v.cpu() for k, v in netD.state_dict().items()},
+                "losses": losses}, os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
+    dist.barrier()
+    shutdown(runner, step)
+    print(f"RANK {rank} DONE", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -26,8 +26,9 @@ def main():
     dist.barrier()
     train(_cfg(tmp, max_steps=4), out, None, "cuda:0", debug=False, emg_enc_ckpt=tmp / "enc.pt")
     dist.barrier()
+    from ste_gan_amd.parallel import shutdown
+    shutdown()                         # train() released its graphs on the way out
     print(f"RANK {rank} DONE", flush=True)
-    os._exit(0)
 
 
 if __name__ == "__main__":

@@ -57,6 +57,58 @@ COLLATE_CASES = {
 }
 
 
+# ---- TimeDomainFeatureLoss with non-default options: name -> (B, T, win, shift, apply_padding_windowing, filter width);
+#      td_long: the default multi-scale loss on a row too long for LDS (whole-utterance validation)
+TDOPT_CASES = {"tdopt_nopad_w5": (2, 160, 21, 8, False, 5), "tdopt_pad_w3": (1, 96, 30, 7, True, 3),
+               "tdopt_nopad_w9": (2, 200, 51, 13, False, 9)}
+TD_LONG = ("td_long_t6000", 1, 6000)
+# ---- AverageFilter: name -> (B, C, T, window, pad_signal)
+AVG_CASES = {"avg_w9_pad": (2, 8, 50, 9, True), "avg_w5_nopad": (2, 3, 40, 5, False), "avg_w9_short": (1, 8, 6, 9, True)}
+
+# ---- validation pass (train.py:292-378): name -> (gen channels, enc (model_size, layers, ff), [(B, T_su), ...])
+VALID_CASES = {"valid_c48": (48, (64, 2, 128), [(2, 32), (2, 20), (1, 300)])}
+
+# ---- dataset selection (data/emg_dataset.py:50-151,220-262): partition -> [(utterance id, frames, extra EMG samples)];
+#      ids are {session}__{utterance}__{speaking mode}
+CORPUS = {
+    "train": [("s3__u01__normal", 40, 0), ("s1__u02__normal", 12, 0), ("s2__u03__silent", 50, 0), ("s1__u04__normal", 13, 0),
+              ("s2__u05__normal", 20, 8), ("s10__u06__normal", 33, 0), ("s1__u07__whisper", 25, 0)],
+    "valid": [("s2__v01__normal", 30, 0), ("s1__v02__silent", 30, 0), ("s3__v03__normal", 5, 0)],
+    "test": [("s1__t01__normal", 6, 0), ("s10__t02__normal", 44, 0), ("s2__t03__silent", 9, 0)],
+}
+CORPUS_EMG_LENGTH = 200
+
+
+def write_corpus(root, strict_ok: bool = True):
+    """The synthetic on-disk corpus in the reference's layout (<root>/<partition>/{emg,units,phonemes,mfccs,emg_feats,
+    transcriptions}/<id>.{pt,txt}); deterministic content.  ``strict_ok=False`` adds the 8 extra samples of "u05"."""
+    import torch
+    from pathlib import Path
+    root = Path(root)
+    for part, lst in CORPUS.items():
+        for sub in ("emg", "units", "phonemes", "mfccs", "emg_feats", "transcriptions"):
+            (root / part / sub).mkdir(parents=True, exist_ok=True)
+        for uid, f, extra in lst:
+            extra = 0 if strict_ok else extra
+            torch.save(det_input(uid + ".emg", (16 * f + extra, 8), "tanh"), root / part / "emg" / f"{uid}.pt")
+            torch.save(det_input(uid + ".su", (f, 256)), root / part / "units" / f"{uid}.pt")
+            torch.save(det_ints(uid + ".ph", (f,), 48), root / part / "phonemes" / f"{uid}.pt")
+            torch.save(det_input(uid + ".mf", (2 * f, 25)), root / part / "mfccs" / f"{uid}.pt")
+            torch.save(det_input(uid + ".ef", (f, 112)), root / part / "emg_feats" / f"{uid}.pt")
+            (root / part / "transcriptions" / f"{uid}.txt").write_text(f"Utterance {uid}\n")
+
+
+def valid_batches(name):
+    ch, enc, shapes = VALID_CASES[name]
+    out = []
+    for i, (B, T) in enumerate(shapes):
+        tag = f"{name}.b{i}"
+        su = det_input(tag + ".su", (B, T, 256))
+        out.append({"su": su, "feats": su, "x_real": det_input(tag + ".x", (B, 16 * T, 8), "tanh"),
+                    "sess": det_ints(tag + ".sess", (B,), 17), "phonemes": det_ints(tag + ".ph", (B, T), 48)})
+    return out
+
+
 def poscheck(t):
     """Checksum that moves when any element changes or shifts: float64 [sum, sum(x*w), sum(x*x)], w = 1 + (i mod 8191)/8191."""
     import numpy as np

@@ -153,6 +153,118 @@ def td_cases():
              dx=xg.grad.numpy(), feats0=feats0.detach().numpy())
 
 
+def tdopt_cases():
+    """TimeDomainFeatureLoss with non-default options, the default loss on a very long row, and AverageFilter alone."""
+    from ste_gan.layers.average_filter import AverageFilter
+    from ste_gan.losses.time_domain_loss import TimeDomainFeatureLoss
+    for name, (B, T, win, shift, pad, aw) in cases.TDOPT_CASES.items():
+        m = TimeDomainFeatureLoss(8, win, shift, apply_padding_windowing=pad, average_filter_window_size=aw)
+        xr, xg = det_input(name + ".real", (B, T, 8), "tanh"), det_input(name + ".gen", (B, T, 8), "tanh").requires_grad_(True)
+        loss = m.time_domain_loss(xr, xg)
+        loss.backward()
+        save(name, loss=np.float64(loss.item()), dx=xg.grad.numpy(),
+             feats=m.calculate_time_domain_features(xr).detach().numpy(),
+             low=m.double_average(xr).detach().numpy())
+    name, B, T = cases.TD_LONG
+    m = MultiTimeDomainFeatureLoss(8)
+    xr, xg = det_input(name + ".real", (B, T, 8), "tanh"), det_input(name + ".gen", (B, T, 8), "tanh").requires_grad_(True)
+    loss, vals = m.time_domain_loss(xr, xg)
+    loss.backward()
+    save(name, loss=np.float64(loss.item()), scale_losses=np.array([v.item() for v in vals], np.float64),
+         dx=xg.grad.numpy())
+    for name, (B, Cc, T, w, pad) in cases.AVG_CASES.items():
+        x = det_input(name + ".x", (B, Cc, T)).requires_grad_(True)
+        y = AverageFilter(Cc, w, pad)(x)
+        gy = det_input(name + ".gy", tuple(y.shape))
+        y.backward(gy)
+        save(name, y=y.detach().numpy(), dx=x.grad.numpy())
+
+
+def valid_cases():
+    """Restatement of the validation pass, ste_gan/train.py:292-350, over the reference modules (CPU: the fp16 autocast
+    around it disables itself) on a list of synthetic batches standing in for valid_loader."""
+    from ste_gan.train_utils import mean_error, phoneme_accuracy, phoneme_accuracy_no_silence
+    for name, (ch, (ms, nl, ff), _) in cases.VALID_CASES.items():
+        netG = load_det(EMGGeneratorGanTTS("SPEECH_UNITS", 256, 17, 8, channels=ch),
+                        oshapes.generator_shapes("SPEECH_UNITS", ch))
+        enc = make_encoder(ms, nl, ff)
+        multi_td = MultiTimeDomainFeatureLoss(8)
+        enc_loss = EMGEncoderLoss(enc)
+        with torch.no_grad():
+            netG.eval()
+            td_errors, su_errors, phoneme_errors, wave_errors = [], [], [], []
+            n = ok = sil = ok_ns = 0
+            for b in cases.valid_batches(name):
+                x_t = b["x_real"]
+                x_pred_t = netG(b["feats"], b["sess"], torch.zeros_like(b["sess"]))
+                wave_errors.append(F.mse_loss(x_pred_t, x_t).item())
+                td_errors.append(multi_td(x_t, x_pred_t).item())
+                eo = enc_loss(x_pred_t, b["su"], b["phonemes"])
+                su_errors.append(eo.speech_unit_loss.item())
+                phoneme_errors.append(eo.phoneme_loss.item())
+                n += eo.num_phones; ok += eo.num_correct_phones
+                sil += eo.num_silence_phones; ok_ns += eo.num_correct_phones_no_silence
+        save(name, speech_unit=np.float64(mean_error(su_errors)), multi_td=np.float64(mean_error(td_errors)),
+             phoneme=np.float64(mean_error(phoneme_errors)), waveform=np.float64(mean_error(wave_errors)),
+             phoneme_accuracy_avg=np.float64(phoneme_accuracy(n, ok)),
+             phoneme_accuracy_avg_no_sil=np.float64(phoneme_accuracy_no_silence(n, ok_ns, sil)),
+             counters=np.array([n, sil, ok, ok_ns], np.int64),
+             per_batch=np.array([wave_errors, td_errors, su_errors, phoneme_errors], np.float64))
+
+
+def dataset_cases():
+    """The reference's EMGDataset (data/emg_dataset.py) over the synthetic on-disk corpus of cases.write_corpus, built with
+    the flags data/loader.py:28-48 passes: which utterances each partition keeps (and in what order), the id -> index
+    maps, the per-item indices and lengths, the strict length check and the overlap check."""
+    import json
+    from pathlib import Path
+    from ste_gan.data.emg_dataset import EMGDataset
+    rec = {}
+    with tempfile.TemporaryDirectory() as td:
+        root = Path(td)
+        cases.write_corpus(root, strict_ok=True)
+        L = cases.CORPUS_EMG_LENGTH
+        tr = EMGDataset(root, "train", strict=True, filter_by_length=True, only_include_voiced=True, train_emg_length=L)
+        va = EMGDataset(root, "valid", session_id_to_idx=tr.session_id_to_idx, speaking_mode_id_to_idx=tr.speaking_mode_id_to_idx,
+                        only_include_voiced=True, filter_by_length=True, train_emg_length=L, strict=True)
+        te = EMGDataset(root, "test", session_id_to_idx=tr.session_id_to_idx, speaking_mode_id_to_idx=tr.speaking_mode_id_to_idx,
+                        only_include_voiced=True, filter_by_length=False, train_emg_length=L, strict=True)
+        EMGDataset.check_no_data_overlap([tr, va, te])
+        allm = EMGDataset(root, "train", strict=False, filter_by_length=False, only_include_voiced=False, train_emg_length=L)
+        sil = EMGDataset(root, "train", strict=False, filter_by_length=True, only_include_voiced=False,
+                         only_include_silent=True, train_emg_length=L)
+        for tag, ds in (("train", tr), ("valid", va), ("test", te), ("train_all", allm), ("train_silent", sil)):
+            items = [ds[i] for i in range(len(ds))]
+            rec[tag] = dict(utt_ids=list(ds.utt_ids), num_filtered=int(ds.num_filtered), emg_lengths=list(ds.emg_lengths),
+                            session_id_to_idx=dict(ds.session_id_to_idx), speaking_mode_id_to_idx=dict(ds.speaking_mode_id_to_idx),
+                            session_index=[int(it["SESSION_INDEX"]) for it in items],
+                            speaking_mode_index=[int(it["SPEAKING_MODE_IDX"]) for it in items],
+                            unit_frames=[int(it["SPEECH_UNITS"].shape[0]) for it in items],
+                            mfcc_frames=[int(it["MFCCS"].shape[0]) for it in items],
+                            emg_checksum=[float(it["REAL_EMG"].double().sum()) for it in items],
+                            num_sessions=ds.num_sessions, num_speaking_modes=ds.num_speaking_modes,
+                            num_emg_channels=ds.num_emg_channels)
+        # strict mode on a corpus whose EMG is 8 samples longer than 16 x frames (utterance u05): __getitem__ asserts
+        root2 = root / "nonstrict"
+        cases.write_corpus(root2, strict_ok=False)
+        ds = EMGDataset(root2, "train", strict=True, filter_by_length=True, only_include_voiced=True, train_emg_length=L)
+        bad = []
+        for i in range(len(ds)):
+            try:
+                ds[i]
+            except AssertionError:
+                bad.append(ds.utt_ids[i])
+        rec["strict_violations"] = bad
+        try:
+            EMGDataset.check_no_data_overlap([tr, tr])
+            rec["overlap_raises"] = False
+        except ValueError:
+            rec["overlap_raises"] = True
+    with open(os.path.join(HERE, "dataset_corpus.json"), "w") as fp:
+        json.dump(rec, fp, indent=1, sort_keys=True)
+    print(f"  dataset_corpus.json: {sorted(rec)}")
+
+
 def enc_cases():
     for name, (ms, nl, ff, B, T) in cases.ENC_CASES.items():
         enc = make_encoder(ms, nl, ff)
@@ -256,9 +368,9 @@ def collate_cases():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen", "disc", "td", "enc", "step", "collate"]
+    which = sys.argv[1:] or ["gen", "disc", "td", "tdopt", "enc", "step", "valid", "collate", "dataset"]
     for w in which:
-        {"gen": gen_cases, "disc": disc_cases, "td": td_cases, "enc": enc_cases, "step": step_cases,
-         "collate": collate_cases}[w]()
+        {"gen": gen_cases, "disc": disc_cases, "td": td_cases, "tdopt": tdopt_cases, "enc": enc_cases, "step": step_cases,
+         "valid": valid_cases, "collate": collate_cases, "dataset": dataset_cases}[w]()
     leaked = [os.path.join(dp, d) for dp, dn, _ in os.walk("/root/reference") for d in dn if d == "__pycache__"]
     assert not leaked, f"__pycache__ written into the reference tree: {leaked}"

@@ -182,3 +182,69 @@ def test_discriminator_loss_on_the_unsliced_batch():
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", list(cases.TD_CASES))
+def test_time_domain_features_vs_golden(name, golden):
+    """TimeDomainFeatureLoss.calculate_time_domain_features (time_domain_loss.py:58-69) against the reference's feature
+    tensor of the (20, 8) scale stored beside the loss fixtures."""
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    g = golden(name)
+    xr, _ = cases.td_inputs(name)
+    feats = MultiTimeDomainFeatureLoss(8).time_domain_losses[0].calculate_time_domain_features(xr.cuda())
+    assert feats.shape == g["feats0"].shape
+    close(feats.cpu().numpy(), g["feats0"], 2e-5, "feats0")
+
+
+@pytest.mark.parametrize("name", list(cases.TDOPT_CASES))
+def test_time_domain_loss_options_vs_golden(name, golden):
+    """apply_padding_windowing=False and other average-filter widths (time_domain_loss.py:20-41): loss, gradient, feature
+    tensor and the double average against fixtures from the reference module."""
+    from ste_gan_amd.losses.time_domain_loss import TimeDomainFeatureLoss
+    B, T, win, shift, pad, aw = cases.TDOPT_CASES[name]
+    g = golden(name)
+    m = TimeDomainFeatureLoss(8, win, shift, apply_padding_windowing=pad, average_filter_window_size=aw)
+    xr = det_input(name + ".real", (B, T, 8), "tanh").cuda()
+    xg = det_input(name + ".gen", (B, T, 8), "tanh").cuda().requires_grad_(True)
+    loss = m.time_domain_loss(xr, xg)
+    close(float(loss), g["loss"], 2e-5, "loss")
+    loss.backward()
+    close(xg.grad.cpu().numpy(), g["dx"], 1e-4, "dx")
+    close(m.calculate_time_domain_features(xr).cpu().numpy(), g["feats"], 2e-5, "feats")
+    close(m.double_average(xr).cpu().numpy(), g["low"], 2e-5, "double_average")
+
+
+def test_multi_td_on_a_row_longer_than_lds(golden):
+    """T = 6000 (a whole utterance in validation): 9 T floats per row do not fit LDS, the row buffers go to a global scratch."""
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    name, B, T = cases.TD_LONG
+    g = golden(name)
+    xr = det_input(name + ".real", (B, T, 8), "tanh").cuda()
+    xg = det_input(name + ".gen", (B, T, 8), "tanh").cuda().requires_grad_(True)
+    loss, vals = MultiTimeDomainFeatureLoss(8).time_domain_loss(xr, xg)
+    close(float(loss), g["loss"], 2e-5, "loss")
+    close([float(v) for v in vals], g["scale_losses"], 2e-5, "scale_losses")
+    loss.backward()
+    close(xg.grad.cpu().numpy(), g["dx"], 1e-4, "dx")
+
+
+@pytest.mark.parametrize("name", list(cases.AVG_CASES))
+def test_average_filter_vs_golden(name, golden):
+    """AverageFilter (layers/average_filter.py:10-28), padded and unpadded, forward and backward."""
+    from ste_gan_amd.layers.average_filter import AverageFilter
+    B, Cc, T, w, pad = cases.AVG_CASES[name]
+    g = golden(name)
+    x = det_input(name + ".x", (B, Cc, T)).cuda().requires_grad_(True)
+    y = AverageFilter(Cc, w, pad)(x)
+    assert tuple(y.shape) == g["y"].shape
+    close(y.detach().cpu().numpy(), g["y"], 2e-6, "y")
+    y.backward(det_input(name + ".gy", tuple(y.shape)).cuda())
+    close(x.grad.cpu().numpy(), g["dx"], 2e-6, "dx")
+
+
+def test_average_filter_errors():
+    from ste_gan_amd.layers.average_filter import AverageFilter
+    with pytest.raises(RuntimeError):                       # reflect padding 4 >= length 4: ATen raises as well
+        AverageFilter(8, 9)(torch.zeros(1, 8, 4, device="cuda"))
+    with pytest.raises(RuntimeError):
+        AverageFilter(8, 9, pad_signal=False)(torch.zeros(1, 8, 5, device="cuda"))

@@ -151,3 +151,36 @@ def test_train_loop_two_ranks_with_graph_replay(tmp_path):
     assert {".done", "netG-final.pt", "netD-final.pt", "checkpoint-final.pt"} <= names
     sd = torch.load(out / "netG-final.pt")
     assert all(torch.isfinite(v).all() for v in sd.values())
+
+
+def test_validation_pass_vs_reference_fixture(golden):
+    """``train.validate`` (ste_gan/train.py:292-350) over a list of batches standing in for valid_loader, against the
+    fixture make_golden.py::valid_cases recorded from the reference's modules: the four mean errors within 1e-4, the
+    phoneme counters -- hence both accuracies -- exact.  The third batch is a 4 800-sample utterance (multi-TD row
+    buffers in the global scratch)."""
+    import numpy as np
+    import cases
+    from oracle import shapes as oshapes
+    from oracle.detfill import fill_state_dict
+    from ste_gan_amd.constants import DataType
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.train import validate
+    from test_gpu_train_step import make_cfg
+    name = "valid_c48"
+    g = golden(name)
+    ch, (ms, nl, ff), _ = cases.VALID_CASES[name]
+    netG = init_emg_generator(make_cfg(ch)); netG.load_state_dict(fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", ch)))
+    enc = EMGEncoderTransformer(8, 256, 48, model_size=ms, num_transformer_layers=nl, dim_feedforward=ff)
+    enc.load_state_dict(fill_state_dict(oshapes.encoder_shapes(ms, 3, nl, dim_feedforward=ff)))
+    netG, enc = netG.cuda(), enc.cuda().eval()
+    loader = [{DataType.REAL_EMG: b["x_real"], DataType.SPEECH_UNITS: b["su"], DataType.SESSION_INDEX: b["sess"],
+               DataType.SPEAKING_MODE_INDEX: torch.zeros_like(b["sess"]), DataType.PHONEMES: b["phonemes"]}
+              for b in cases.valid_batches(name)]
+    val = validate(netG, MultiTimeDomainFeatureLoss(8), EMGEncoderLoss(enc), loader, DataType.SPEECH_UNITS, torch.device("cuda"))
+    for k in ("speech_unit", "multi_td", "phoneme", "waveform"):
+        assert abs(val[k] - float(g[k])) <= 1e-4 * abs(float(g[k])), (k, val[k], float(g[k]))
+    assert val["phoneme_accuracy_avg"] == float(g["phoneme_accuracy_avg"])
+    assert val["phoneme_accuracy_avg_no_sil"] == float(g["phoneme_accuracy_avg_no_sil"])

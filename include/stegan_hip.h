@@ -180,6 +180,27 @@ int stegan_conv1d_fwd_h(const stegan_conv_desc* d, const float* x, const uint16_
 int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* dy, const uint16_t* wbh, const float* scale,
                              const float* mask_src, const float* add_src, float* dx, float* workspace,
                              int64_t workspace_floats, void* stream);
+/*
+ * Round 3: bf16 ACTIVATION IMAGES.  A conv kernel can write, beside its fp32 output (B, C, T), the same values rounded to
+ * bf16 in the channel-block-major layout its consumers stage by LDS-DMA: image[b][c / 8][t][c % 8], i.e. (B, ceil(C/8), T, 8)
+ * uint16 (whole 8-channel blocks per group only; otherwise the request is ignored), and can take its input as such an
+ * image instead of converting the fp32 tensor while it is staged.  xh / dyh and yh / dxh are nullable; every other
+ * argument is as for stegan_conv1d_fwd_h / _bwd_data_h / _fwd_multi_h / _bwd_data_multi_h (which are these with null
+ * images).  Reference: the same layers/conv.py convolutions; the images carry no values of their own.
+ */
+int stegan_conv1d_fwd_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const uint16_t* wfh,
+                         const float* scale, const float* bias, const float* residual, float* y, uint16_t* yh,
+                         float* workspace, int64_t workspace_floats, void* stream);
+int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float* dy, const uint16_t* dyh, const uint16_t* wbh,
+                              const float* scale, const float* mask_src, const float* add_src, float* dx, uint16_t* dxh,
+                              float* workspace, int64_t workspace_floats, void* stream);
+int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                               const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
+                               const float* const* bias, const float* const* residual, float* const* y,
+                               uint16_t* const* yh, void* stream);
+int stegan_conv1d_bwd_data_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                    const uint16_t* const* dyh, const uint16_t* const* wbh, const float* const* mask_src,
+                                    const float* const* add_src, float* const* dx, uint16_t* const* dxh, void* stream);
 /* bf16 forms of stegan_conv1d_fwd_multi / stegan_conv1d_bwd_data_multi (same contract: up to 5 problems, return 1 when they
  * cannot share one kernel variant or one of them is left to the fp32 kernels). */
 int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,

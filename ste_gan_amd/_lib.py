@@ -51,6 +51,10 @@ SIGNATURES = {
     "stegan_conv1d_bwd_data_h": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_bwd_weight_h": [_D, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_fwd_multi_h": [_I32, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_fwd_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "stegan_conv1d_bwd_data_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
+    "stegan_conv1d_fwd_multi_hx": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_data_multi_hx": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_multi_h": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_bias_grad": [_P, _P, _I32, _I32, _I32, _P],
     "stegan_conv1d_plan": [_D, _I32, _P, _P, _P],

@@ -61,7 +61,16 @@ struct HP {
     int vec_out;                  // 16-byte epilogue accesses: unit output stride, columns and rows multiples of 4, aligned
     int dbg;                      // diagnostic ablations (STEGAN_BF16_DBG bits: 1 no X loads, 2 no W DMA, 4 no MFMA loop, 8 no
                                   // X LDS stores); results are wrong when set
+    // round 3: the source as a bf16 activation image [B][xh_cb][Tsrc][8 channels] (written by the producing kernel's
+    // epilogue, DirP::out_h): the X tile is then staged by LDS-DMA like the weights -- no loads into registers, no
+    // conversion, no LDS stores; null: the fp32 source is converted while it is staged (kernel template parameter XH)
+    const unsigned short* xh = nullptr;
+    int xh_cb = 0;                // channel blocks per batch element of the image = ceil(Csrc / 8)
+    unsigned xh_bytes = 0;
+    int xnit = 0;                   // X DMA wave-instructions per producer wave and chunk = ceil(NCB * XROW / 256)
 };
+
+constexpr int HXD_MAX = 8;     // X DMA wave-instructions per producer wave and chunk (8 x 256 pieces of 16 bytes = 32 KiB)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
     const f32x2 f = {a, b};
@@ -81,8 +90,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
 #define HB_DBG(bit_) false
 #endif
 
-template <int TM, int TN, int LOGNCB, bool XV>
+template <int TM, int TN, int LOGNCB, bool XV, bool XH = false>
 __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
+    static_assert(!(XV && XH), "the image path has no use for the 16-byte fp32 loads");
     const DirP& p = h.d;
     constexpr int NCB = 1 << LOGNCB;
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -173,6 +183,86 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // (each role computes only its own per-lane state inside its branch: register demand is the maximum of the two
     // roles, not their sum)
     if (producer) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece; piece = (tap * NCB + cb) * BM + m.  The bf16 weights
+    // are stored [g][k][cb][m][8 channels], so the 64 lanes of a wave-instruction copy 1 KiB of CONTIGUOUS global memory
+    const int CB = h.Cpad >> 3;
+    int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
+#pragma unroll
+    for (int it = 0; it < HW_MAX; ++it) {
+        const int piece = it * 256 + tid;
+        const int m = piece & (BM - 1), r = piece / BM;
+        const int cb = r & (NCB - 1), tap = r >> LOGNCB;
+        const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;            // dead tap of an odd pair: the zero plane
+        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
+    }
+#define HB_DMA_W(c_, buf_)                                                                                      \
+    {                                                                                                           \
+        const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
+        char* Wd_ = smem + (buf_) * wbuf;                                                                       \
+        _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                 \
+            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !HB_DBG(2)) {                     \
+                const char* src_ = wc_ + w_off[it];                                                             \
+                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (it * 256 + wave * 64) * 16), 16, 0, 0); \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    if constexpr (XH) {
+        // ---- the source is a bf16 image [B][xh_cb][Tsrc][8]: piece (cb, slot) of the LDS image [cb][slot] IS 16 contiguous
+        // bytes of it, so the whole X tile is staged by LDS-DMA through a buffer descriptor -- piece = it * 256 + tid lands
+        // at LDS byte 16 * piece (wave-uniform base + 16 * lane); per-lane offset = (batch row, channel block of the
+        // chunk, time); the chunk's first channel block is a SCALAR offset; halo / padding / slots past the tile and
+        // channel blocks past the group carry an out-of-range offset: the buffer unit writes zeros for them
+        // (scripts/micro/bufload_lds_oob.hip); lanes past the image (piece >= NCB * XROW) are switched off.  No
+        // alignment rule: any tap offset, stride or dilation is a slot address, as before; the nearest-x2 upsample
+        // reads source position q >> 1.
+        const auto rsrc_h = __builtin_amdgcn_make_buffer_rsrc((void*)h.xh, 0, (int)h.xh_bytes, 0x00020000);
+        const int npieces = NCB * p.XROW;
+        const int cbg0 = g * (p.C2_g >> 3);                       // first channel block of the group inside the image
+        unsigned xd_voff[HXD_MAX];
+        int xd_cb[HXD_MAX];
+#pragma unroll
+        for (int it = 0; it < HXD_MAX; ++it) {
+            const int piece = it * 256 + tid;
+            const int cb = (int)fd_div((uint32_t)piece, p.fdXROW), slot = piece - cb * p.XROW;
+            const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
+            const int b = b_lo + sg;
+            const int q = (sg == 0 ? qbase0 : qbaseN) + sl;
+            const int qs = p.mode == 0 ? (q >> p.ups) : q;
+            xd_cb[it] = piece < npieces ? cb : -1;                // -1: lane switched off
+            xd_voff[it] = OOB;
+            if (it < h.xnit && piece < npieces && sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
+                xd_voff[it] = (unsigned)(((b * h.xh_cb + cbg0 + cb) * p.Tsrc + qs) * 16);
+        }
+        const int chunk_x = NCB * p.Tsrc * 16;                    // bytes between the image planes of neighbouring chunks
+#define HB_DMA_X(c_, buf_)                                                                                      \
+        {                                                                                                       \
+            const int live_ = (p.C2_g - (c_) * CCH + 7) >> 3;   /* channel blocks of the group left for this chunk */ \
+            char* Xd_ = Xbufs + (buf_) * xbuf;                                                                  \
+            _Pragma("unroll") for (int it = 0; it < HXD_MAX; ++it) {                                            \
+                if (it < h.xnit && xd_cb[it] >= 0 && !HB_DBG(1)) {                                            \
+                    const int vo_ = xd_cb[it] < live_ ? (int)xd_voff[it] : (int)OOB;                            \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h, (lds_ptr_t)(Xd_ + (it * 256 + wave * 64) * 16), 16, \
+                                                             vo_, (c_) * chunk_x, 0, 0);                        \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        if (c_begin < c_end) {
+            HB_DMA_X(c_begin, 0)
+            HB_DMA_W(c_begin, 0)
+        }
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cur = (c - c_begin) & 1;
+            block_sync();                // all 8 waves: chunk c has landed (the barrier's vmcnt(0)); buffer cur ^ 1 is free
+            if (c + 1 < c_end) {
+                HB_DMA_X(c + 1, cur ^ 1)
+                HB_DMA_W(c + 1, cur ^ 1)
+            }
+        }
+        return;
+#undef HB_DMA_X
+    } else {
     constexpr int XI = XV ? HXV_MAX : HX_MAX;
     unsigned x_voff[XI];
     int x_lds[XI], x_c8[XI];             // LDS byte offset of the item's first slot (-1: no item); 8 * cg
@@ -195,19 +285,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             if constexpr (XV) x_nv[it] = p.Tsrc - qs;
         }
     }
-    // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece; piece = (tap * NCB + cb) * BM + m.  The bf16 weights
-    // are stored [g][k][cb][m][8 channels], so the 64 lanes of a wave-instruction copy 1 KiB of CONTIGUOUS global memory
-    const int CB = h.Cpad >> 3;
-    int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
-#pragma unroll
-    for (int it = 0; it < HW_MAX; ++it) {
-        const int piece = it * 256 + tid;
-        const int m = piece & (BM - 1), r = piece / BM;
-        const int cb = r & (NCB - 1), tap = r >> LOGNCB;
-        const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;            // dead tap of an odd pair: the zero plane
-        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
-    }
-
     // staged X values of the chunk in flight: scalar form xAr[it][j] = channel j of the item's slot; vector form
     // xAv[it][j] = 4 slots of channel j
     float xAr[XV ? 1 : HX_MAX][8];
@@ -257,19 +334,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             }                                                                                                   \
         }                                                                                                       \
     }
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-#define HB_DMA_W(c_, buf_)                                                                                      \
-    {                                                                                                           \
-        const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
-        char* Wd_ = smem + (buf_) * wbuf;                                                                       \
-        _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                 \
-            if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !HB_DBG(2)) {                     \
-                const char* src_ = wc_ + w_off[it];                                                             \
-                __builtin_amdgcn_global_load_lds((gptr_t)src_, (lds_ptr_t)(Wd_ + (it * 256 + wave * 64) * 16), 16, 0, 0); \
-            }                                                                                                   \
-        }                                                                                                       \
-    }
     // Pipeline, one chunk ahead, two LDS buffers per operand, ONE barrier per chunk:
     //   iteration c: [barrier] issue W(c+1) LDS-DMA + X(c+1) loads -> MFMAs of chunk c -> convert + store X(c+1)
     // Two blocks share a CU where the grid allows, so one block's global round trip hides under the other's MFMAs.  (A
@@ -295,6 +359,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             }
         }
         return;                             // the accumulators live in the consumer waves
+    }   // !XH
     }
 #undef HB_LOAD_X
 #undef HB_STORE_X
@@ -338,10 +403,19 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[i] = HB_LDS(wa_ + a_byte[i]);                         \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) b_[j] = HB_LDS(xb_ + b_byte[j]);                         \
     }
+    // image path: the input ReLU cannot ride on the staging (LDS-DMA moves bytes), so it is applied to the X fragment at
+    // its point of use -- max with 0 on the packed halves (sign bit set <=> negative int16), or with -32768 (identity)
+    // when the layer has no input activation: one wave-uniform operand, no branch
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const short relu_floor = (XH && relu) ? (short)0 : (short)-32768;
+    const s16x8_t relu_fl = {relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor, relu_floor};
+#define HB_XFRAG(b_) (XH ? __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, b_), relu_fl)) : (b_))
 #define HB_MFMA(a_, b_)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                              \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_[j], a_[i], acc[i][j], 0, 0, 0);
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                            \
+        const bf16x8 bj_ = HB_XFRAG(b_[j]);                                                                     \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bj_, a_[i], acc[i][j], 0, 0, 0);                \
+    }
     // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
 #define HB_COMPUTE(c_)                                                                                          \
     if (!HB_DBG(4)) {                                                                                           \
@@ -378,6 +452,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     }
 #undef HB_COMPUTE
 #undef HB_MFMA
+#undef HB_XFRAG
 #undef HB_LOAD
 #undef HB_LDS
 
@@ -410,6 +485,35 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
     else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = fmaxf(v_[e], 0.f); }      \
     else if (act == STEGAN_ACT_TANH) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = tanhf(v_[e]); }
+    // ---- bf16 image of the output (DirP::out_h), for the kernel that consumes it next: [B][out_cb][Tdst][8 channels].
+    // A 16-byte piece needs 8 CHANNELS of one column -- 8 lanes of this layout -- so each 32 x 32 tile goes through a
+    // 2 KiB LDS scratch: 16 two-byte stores per lane into [column][channel], two 16-byte reads per lane of (column, 8-channel
+    // block) pieces, consecutive lanes on consecutive columns: 512 contiguous bytes of the image per store instruction.
+    // The scratch reuses the W ring: the producers have left, the consumer waves meet at one more barrier (a wave that has
+    // ended is not waited for) so that no wave overwrites operands another one still reads.
+    unsigned short* const outh = raw ? nullptr : p.out_h;
+    char* const scr = smem + wave * 2048;
+    if (outh) block_sync();
+#define HB_IMAGE_TILE(v_, i_, j_, m_ok_)                                                                        \
+    if (outh) {                                                                                                 \
+        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                        \
+            const int nl_ = 8 * (e >> 2) + 4 * hl + (e & 3);                                                    \
+            *(unsigned short*)(scr + nl_ * 64 + l31 * 2) = (m_ok_) ? f32_to_bf16_bits(v_[e]) : (unsigned short)0; \
+        }                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                                                      \
+            const int cbq_ = hl + 2 * h2, nl_ = l31;                                                            \
+            const u32x4 pc_ = *(const u32x4*)(scr + nl_ * 64 + cbq_ * 16);                                      \
+            const int mb_ = m0 + (wm * TM + (i_)) * 32 + cbq_ * 8;                                              \
+            const int n_ = n0 + (wn * TN + (j_)) * 32 + nl_;                                                    \
+            if (mb_ < M_g && n_ < N) {                                                                          \
+                const int b_ = (int)fd_div((uint32_t)n_, fdU), u_ = n_ - b_ * U;                                \
+                const int to_ = mode == 0 ? u_ : phase + u_ * os;                                               \
+                *(u32x4*)(outh + (((size_t)b_ * p.out_cb + ((g * M_g + mb_) >> 3)) * Tdst + to_) * 8) = pc_;    \
+            }                                                                                                   \
+        }                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the reads are done before the next tile's stores */ \
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 32 + l31;
@@ -462,6 +566,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (ok[q]) *(f32x4*)(outp + oidx[q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                HB_IMAGE_TILE(v, i, j, m_ok)
             } else {
                 int oi[16];
                 bool okk[16];
@@ -489,10 +594,12 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (okk[e]) outp[oi[e]] = v[e];
+                HB_IMAGE_TILE(v, i, j, m_ok)
             }
         }
     }
 #undef HB_ACT16
+#undef HB_IMAGE_TILE
 #ifndef STEGAN_STAMPS_ITER
     HSTAMP(6)
 #endif
@@ -516,9 +623,9 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #define HB_OCC
 #endif
 
-template <int TM, int TN, int LOGNCB, bool XV>
+template <int TM, int TN, int LOGNCB, bool XV, bool XH = false>
 __global__ __launch_bounds__(512) HB_OCC void conv_bf16_kernel(const HP h) {
-    conv_bf16_body<TM, TN, LOGNCB, XV>(h, blockIdx.x, gridDim.x, 0);
+    conv_bf16_body<TM, TN, LOGNCB, XV, XH>(h, blockIdx.x, gridDim.x, 0);
 }
 
 // Multi-problem launch: up to HMULTI independent convolutions that share a kernel variant (the same layer of the five
@@ -531,13 +638,13 @@ struct MultiH {
 };
 static_assert(sizeof(MultiH) <= 4096, "kernel argument segment limit");
 
-template <int TM, int TN, int LOGNCB, bool XV>
+template <int TM, int TN, int LOGNCB, bool XV, bool XH = false>
 __global__ __launch_bounds__(512) HB_OCC void conv_bf16_multi_kernel(const MultiH a) {
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < HMULTI; ++i)
         if (i < a.n && (int)blockIdx.x >= a.first[i]) pi = i;
-    conv_bf16_body<TM, TN, LOGNCB, XV>(a.p[pi], blockIdx.x - a.first[pi], a.first[pi + 1] - a.first[pi], 0);
+    conv_bf16_body<TM, TN, LOGNCB, XV, XH>(a.p[pi], blockIdx.x - a.first[pi], a.first[pi + 1] - a.first[pi], 0);
 }
 
 // ---- bf16 weight copies: v (Cout, Cin_g, K) fp32 -> wf[g][k][ci/8][co][ci%8], wb[g][k][co/8][ci][co%8] (x scale[co]);
@@ -669,7 +776,7 @@ struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, NG, ntW, xit, wit, span; size
 
 // geometry for one (TM, TN): the largest channel chunk whose tiles fit (cch_max caps it: experiments)
 GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_max, int cs, int U, int U_min, bool xv,
-               int cch_max, int xgran = 4) {
+               int cch_max, int xgran = 4, bool dma_x = false) {
     GeoH gm;
     gm.ok = false; gm.TM = TM; gm.TN = TN;
     const int BM = 64 * TM, BN = 64 * TN;
@@ -692,7 +799,8 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
         const int XROW = SEG * NSEG;
         const int NG = xv ? XROW / xgran : XROW;
         const int xit = ceil_div(NCB * NG, 256), wit = ceil_div(ntW * BM * NCB, 256);
-        if (xit > (xv ? HXV_MAX : HX_MAX) || wit > HW_MAX) continue;
+        // image source: the X tile is DMA pieces, not register items -- bounded by HXD_MAX wave-instructions per wave
+        if ((dma_x ? xit > HXD_MAX : xit > (xv ? HXV_MAX : HX_MAX)) || wit > HW_MAX) continue;
         const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)XROW * NCB * 16);       // W ring of 2, X ring of 2
         if (lds > 160 * 1024) continue;
         GeoH c = gm;
@@ -705,39 +813,40 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
     return fallback;
 }
 
-template <int TM, int TN, bool XV>
+template <int TM, int TN, bool XV, bool XH = false>
 void launch_variant(int logNCB, dim3 grid, size_t lds, hipStream_t s, const HP& h) {
     switch (logNCB) {
-        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV>), grid, dim3(512), lds, s, h); break;
-        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV>), grid, dim3(512), lds, s, h); break;
-        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV>), grid, dim3(512), lds, s, h); break;
-        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV>), grid, dim3(512), lds, s, h); break;
+        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV, XH>), grid, dim3(512), lds, s, h); break;
+        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV, XH>), grid, dim3(512), lds, s, h); break;
+        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV, XH>), grid, dim3(512), lds, s, h); break;
+        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV, XH>), grid, dim3(512), lds, s, h); break;
     }
 }
 
-template <int TM, int TN, bool XV>
+template <int TM, int TN, bool XV, bool XH = false>
 void set_lds_attr() {
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 0, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 1, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 2, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 3, XV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 0, XV, XH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 1, XV, XH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 2, XV, XH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<TM, TN, 3, XV, XH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 struct MultiCollectH {              // host side of a multi-problem launch being assembled
     MultiH mh;
     int TM, TN, logNCB;             // variant of the first problem, forced on the others (0 / -1: not chosen yet)
     bool xv;                        // 16-byte X loads only when every problem's rows are float4 aligned
+    bool xh = false;                // every problem's source comes as a bf16 image (LDS-DMA staging)
     size_t lds;
     long blocks;
 };
 
-template <int TM, int TN, bool XV>
+template <int TM, int TN, bool XV, bool XH = false>
 void launch_variant_multi(int logNCB, dim3 grid, size_t lds, hipStream_t s, const MultiH& a) {
     switch (logNCB) {
-        case 0: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 0, XV>), grid, dim3(512), lds, s, a); break;
-        case 1: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 1, XV>), grid, dim3(512), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 2, XV>), grid, dim3(512), lds, s, a); break;
-        default: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 3, XV>), grid, dim3(512), lds, s, a); break;
+        case 0: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 0, XV, XH>), grid, dim3(512), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 1, XV, XH>), grid, dim3(512), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 2, XV, XH>), grid, dim3(512), lds, s, a); break;
+        default: hipLaunchKernelGGL((conv_bf16_multi_kernel<TM, TN, 3, XV, XH>), grid, dim3(512), lds, s, a); break;
     }
 }
 
@@ -785,7 +894,15 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     }
     if (ntaps_max > MAX_TAPS || phases > MAX_PHASES) return 1;
     const long N = (long)d->B * U;
-    const bool xv = mc ? mc->xv : xv_eligible(p.Tsrc, p.src, mode == 0 && p.ups);
+    // the source as a bf16 image (staged by LDS-DMA): whole 8-channel blocks per group, an image within the buffer
+    // descriptor's 2 GiB; a multi launch takes it when EVERY problem has one
+    static const bool no_xh = getenv("STEGAN_BF16_NO_XH") != nullptr;
+    const int64_t img_bytes = (int64_t)d->B * ceil_div(p.Csrc, 8) * p.Tsrc * 16;
+    const bool xh = (mc ? mc->xh : (h.xh != nullptr)) && h.xh && !no_xh && p.C2_g % 8 == 0 && img_bytes < (int64_t)OOB;
+    if (mc && mc->xh && !xh) return 1;
+    if (!xh) h.xh = nullptr;
+    h.xh_cb = ceil_div(p.Csrc, 8); h.xh_bytes = (unsigned)img_bytes;
+    const bool xv = xh ? false : (mc ? mc->xv : xv_eligible(p.Tsrc, p.src, mode == 0 && p.ups));
     const int xgran = (mode == 0 && p.ups) ? 8 : 4;               // slots per 16-byte X item
     // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the
     // graph-timed microbenchmark (scripts/bf16_stamps.py, scripts/bf16_microbench.py) on the hot-path layers:
@@ -812,12 +929,16 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         if (mc && mc->mh.n > 0 && (tm != mc->TM || tn != mc->TN)) continue;
         if (mc && tm == 2 && tn == 2) continue;                      // (keeps the (2,2) variants out of the multi kernels)
         if (tm == 2 && p.M_g <= 64) continue;
-        const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max, xgran);
+        const GeoH g2 = plan_bf16(tm, tn, p.C2_g, ntaps_max, span_off, step_max, cs, U, U_min, xv, cch_max, xgran, xh);
         if (!g2.ok) continue;
         if (mc && mc->mh.n > 0 && g2.logNCB != mc->logNCB) continue;
         const int cch = 8 << g2.logNCB, nch = ceil_div(p.C2_g, cch);
         const long blocks1 = ceil_div(p.M_g, 64 * tm) * (long)d->groups * phases * ((N + 64 * tn - 1) / (64 * tn));
-        const double bytes = (double)g2.ntW * 64 * tm * cch * 2 + (double)g2.XROW * cch * 4;
+        // bytes the producers move per chunk; an image source is half the bytes and needs no conversion / LDS stores:
+        // DMA pieces cost the producers about half of what register-staged bytes do (STEGAN_BF16_XH_RATE: experiments)
+        static const char* env_xr = getenv("STEGAN_BF16_XH_RATE");
+        const double xcost = xh ? (env_xr ? atof(env_xr) : 0.5) * 2.0 : 4.0;
+        const double bytes = (double)g2.ntW * 64 * tm * cch * 2 + (double)g2.XROW * cch * xcost;
         static const char* env_p22 = getenv("STEGAN_BF16_PAIR22");
         const bool pair = g2.lds <= 80 * 1024 && (!(tm == 2 && tn == 2) || (env_p22 && atoi(env_p22)));
         for (int sp = 1; sp <= (max_splits < nch ? max_splits : nch); ++sp) {
@@ -841,6 +962,10 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     p.fdXROW = make_fastdiv((uint32_t)gm.XROW); p.fdSEG = make_fastdiv((uint32_t)gm.SEG);
     p.fdU0 = make_fastdiv((uint32_t)U); p.fdU1 = make_fastdiv((uint32_t)(U > 1 ? U - 1 : 1));
     h.NG = gm.NG; h.fdNG = make_fastdiv((uint32_t)gm.NG); h.ntapsW = gm.ntW; h.xit = gm.xit; h.wit = gm.wit;
+    h.xnit = xh ? ceil_div(NCB * gm.XROW, 256) : 0;
+    if (p.out_h && (p.out_btc || p.Cdst % 8 != 0 || p.M_g % 8 != 0)) p.out_h = nullptr;      // whole 8-channel blocks only
+    p.out_cb = p.Cdst / 8;
+    if (p.out_h && gm.lds < 8192) gm.lds = 8192;                  // the image epilogue's scratch (4 waves x 2 KiB)
     { const char* ed = getenv("STEGAN_BF16_DBG"); h.dbg = ed ? atoi(ed) : 0; }
     {
         const bool al = ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
@@ -880,7 +1005,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     if (mc) {
         MultiH& mh = mc->mh;
         if (mh.n >= HMULTI) return 1;
-        if (mh.n == 0) { mc->TM = TM; mc->TN = TN; mc->logNCB = gm.logNCB; mc->lds = gm.lds; mc->blocks = 0; mh.first[0] = 0; }
+        if (mh.n == 0) { mc->TM = TM; mc->TN = TN; mc->logNCB = gm.logNCB; mc->lds = gm.lds; mc->blocks = 0; mh.first[0] = 0; mc->xh = xh; }
         if (gm.lds > mc->lds) mc->lds = gm.lds;
         mh.p[mh.n] = h;
         mc->blocks += nb * p.m_tiles * d->groups * phases;
@@ -891,10 +1016,11 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     if (!attr_done) {
         set_lds_attr<1, 1, false>(); set_lds_attr<1, 2, false>(); set_lds_attr<2, 1, false>(); set_lds_attr<2, 2, false>();
         set_lds_attr<1, 1, true>(); set_lds_attr<1, 2, true>(); set_lds_attr<2, 1, true>(); set_lds_attr<2, 2, true>();
+        set_lds_attr<1, 1, false, true>(); set_lds_attr<1, 2, false, true>(); set_lds_attr<2, 1, false, true>(); set_lds_attr<2, 2, false, true>();
         attr_done = true;
     }
     dim3 grid((unsigned)(nb * p.m_tiles * d->groups * phases * p.splits));
-#define HB_GO(TM_, TN_) { if (xv) launch_variant<TM_, TN_, true>(gm.logNCB, grid, gm.lds, s, h); else launch_variant<TM_, TN_, false>(gm.logNCB, grid, gm.lds, s, h); }
+#define HB_GO(TM_, TN_) { if (xh) launch_variant<TM_, TN_, false, true>(gm.logNCB, grid, gm.lds, s, h); else if (xv) launch_variant<TM_, TN_, true>(gm.logNCB, grid, gm.lds, s, h); else launch_variant<TM_, TN_, false>(gm.logNCB, grid, gm.lds, s, h); }
     if (TM == 2 && TN == 2) HB_GO(2, 2)
     else if (TM == 2) HB_GO(2, 1)
     else if (TN == 2) HB_GO(1, 2)
@@ -913,14 +1039,16 @@ template <int TM, int TN>
 void multi_go(MultiCollectH& mc, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-#define HB_ATTR(L_, V_) (void)hipFuncSetAttribute((const void*)conv_bf16_multi_kernel<TM, TN, L_, V_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        HB_ATTR(0, true) HB_ATTR(1, true) HB_ATTR(2, true) HB_ATTR(3, true)
-        HB_ATTR(0, false) HB_ATTR(1, false) HB_ATTR(2, false) HB_ATTR(3, false)
+#define HB_ATTR(L_, V_, H_) (void)hipFuncSetAttribute((const void*)conv_bf16_multi_kernel<TM, TN, L_, V_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        HB_ATTR(0, true, false) HB_ATTR(1, true, false) HB_ATTR(2, true, false) HB_ATTR(3, true, false)
+        HB_ATTR(0, false, false) HB_ATTR(1, false, false) HB_ATTR(2, false, false) HB_ATTR(3, false, false)
+        HB_ATTR(0, false, true) HB_ATTR(1, false, true) HB_ATTR(2, false, true) HB_ATTR(3, false, true)
 #undef HB_ATTR
         attr = true;
     }
     dim3 grid((unsigned)mc.blocks);
-    if (mc.xv) launch_variant_multi<TM, TN, true>(mc.logNCB, grid, mc.lds, s, mc.mh);
+    if (mc.xh) launch_variant_multi<TM, TN, false, true>(mc.logNCB, grid, mc.lds, s, mc.mh);
+    else if (mc.xv) launch_variant_multi<TM, TN, true>(mc.logNCB, grid, mc.lds, s, mc.mh);
     else launch_variant_multi<TM, TN, false>(mc.logNCB, grid, mc.lds, s, mc.mh);
 }
 
@@ -968,9 +1096,13 @@ extern "C" int stegan_conv_prep_bf16_multi(int32_t n, const void* table_dev, int
     return STEGAN_OK;
 }
 
-extern "C" int stegan_conv1d_fwd_h(const stegan_conv_desc* d, const float* x, const uint16_t* wfh, const float* scale,
-                                   const float* bias, const float* residual, float* y, float* workspace,
-                                   int64_t workspace_floats, void* stream) {
+// Forward / input-gradient conv with bf16 activation images (round 3): ``xh`` (nullable) = the source as an image
+// [B][ceil(Cin / 8)][Tin][8] written by the kernel that produced it -- staged by LDS-DMA instead of being converted from
+// fp32; ``yh`` (nullable) = where to write the image of the output beside the fp32 tensor (whole 8-channel blocks only:
+// ignored otherwise).  The fp32 arguments are as for stegan_conv1d_fwd_h / stegan_conv1d_bwd_data_h.
+extern "C" int stegan_conv1d_fwd_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const uint16_t* wfh,
+                                    const float* scale, const float* bias, const float* residual, float* y, uint16_t* yh,
+                                    float* workspace, int64_t workspace_floats, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && wfh && y);
@@ -985,12 +1117,13 @@ extern "C" int stegan_conv1d_fwd_h(const stegan_conv_desc* d, const float* x, co
     p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = 0; p.zero_off = 0;
     p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
     h.wh = wfh; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+    h.xh = xh; p.out_h = yh;
     return launch_bf16(d, 0, h, workspace, workspace_floats, (hipStream_t)stream);
 }
 
-extern "C" int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* dy, const uint16_t* wbh, const float* scale,
-                                        const float* mask_src, const float* add_src, float* dx, float* workspace,
-                                        int64_t workspace_floats, void* stream) {
+extern "C" int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float* dy, const uint16_t* dyh, const uint16_t* wbh,
+                                         const float* scale, const float* mask_src, const float* add_src, float* dx,
+                                         uint16_t* dxh, float* workspace, int64_t workspace_floats, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(dy && wbh && dx);
@@ -1004,19 +1137,36 @@ extern "C" int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* 
     p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = 0; p.zero_off = 0;
     p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
     h.wh = wbh; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+    h.xh = dyh; p.out_h = dxh;
     return launch_bf16(d, 1, h, workspace, workspace_floats, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_fwd_h(const stegan_conv_desc* d, const float* x, const uint16_t* wfh, const float* scale,
+                                   const float* bias, const float* residual, float* y, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
+    return stegan_conv1d_fwd_hx(d, x, nullptr, wfh, scale, bias, residual, y, nullptr, workspace, workspace_floats, stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data_h(const stegan_conv_desc* d, const float* dy, const uint16_t* wbh, const float* scale,
+                                        const float* mask_src, const float* add_src, float* dx, float* workspace,
+                                        int64_t workspace_floats, void* stream) {
+    return stegan_conv1d_bwd_data_hx(d, dy, nullptr, wbh, scale, mask_src, add_src, dx, nullptr, workspace, workspace_floats,
+                                     stream);
 }
 
 // Up to 5 independent convolutions in ONE launch (the same layer of the period discriminators), bf16 operands: see
 // stegan_conv1d_fwd_multi.  Returns 1 when the problems cannot share a kernel variant (the caller launches them one by one).
-extern "C" int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
-                                         const uint16_t* const* wfh, const float* const* scale, const float* const* bias,
-                                         const float* const* residual, float* const* y, void* stream) {
+extern "C" int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                          const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
+                                          const float* const* bias, const float* const* residual, float* const* y,
+                                          uint16_t* const* yh, void* stream) {
     STEGAN_CHECK_ARG(n >= 1 && n <= HMULTI && descs && x && wfh && y);
     MultiCollectH mc;
-    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
-    for (int i = 0; i < n; ++i)
+    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true; mc.xh = xh != nullptr;
+    for (int i = 0; i < n; ++i) {
         if (!descs[i] || descs[i]->upsample != 1 || !xv_eligible(descs[i]->Tin, x[i], false)) mc.xv = false;   // (one granule per launch)
+        if (xh && (!xh[i] || !descs[i] || (descs[i]->Cin / descs[i]->groups) % 8 != 0)) mc.xh = false;
+    }
     for (int i = 0; i < n; ++i) {
         const stegan_conv_desc* d = descs[i];
         int rc = check_desc(d);
@@ -1035,20 +1185,30 @@ extern "C" int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* cons
         p.C2_g = d->Cin / d->groups; p.M_g = d->Cout / d->groups; p.LD = 0; p.zero_off = 0;
         p.in_relu = d->in_act == STEGAN_ACT_RELU; p.out_act = d->out_act; p.out_btc = d->out_btc;
         h.wh = wfh[i]; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+        h.xh = mc.xh ? xh[i] : nullptr; p.out_h = yh ? yh[i] : nullptr;
         rc = launch_bf16(d, 0, h, nullptr, 0, (hipStream_t)stream, &mc);
         if (rc) return rc;
     }
     return launch_multi_h(mc, (hipStream_t)stream);
 }
 
-extern "C" int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
-                                              const uint16_t* const* wbh, const float* const* mask_src,
-                                              const float* const* add_src, float* const* dx, void* stream) {
+extern "C" int stegan_conv1d_fwd_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                         const uint16_t* const* wfh, const float* const* scale, const float* const* bias,
+                                         const float* const* residual, float* const* y, void* stream) {
+    return stegan_conv1d_fwd_multi_hx(n, descs, x, nullptr, wfh, scale, bias, residual, y, nullptr, stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                               const uint16_t* const* dyh, const uint16_t* const* wbh,
+                                               const float* const* mask_src, const float* const* add_src, float* const* dx,
+                                               uint16_t* const* dxh, void* stream) {
     STEGAN_CHECK_ARG(n >= 1 && n <= HMULTI && descs && dy && wbh && dx);
     MultiCollectH mc;
-    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true;
-    for (int i = 0; i < n; ++i)
+    mc.mh.n = 0; mc.TM = 0; mc.TN = 0; mc.logNCB = -1; mc.xv = true; mc.xh = dyh != nullptr;
+    for (int i = 0; i < n; ++i) {
         if (!descs[i] || !xv_eligible(descs[i]->Tout, dy[i], false)) mc.xv = false;
+        if (dyh && (!dyh[i] || !descs[i] || (descs[i]->Cout / descs[i]->groups) % 8 != 0)) mc.xh = false;
+    }
     for (int i = 0; i < n; ++i) {
         const stegan_conv_desc* d = descs[i];
         int rc = check_desc(d);
@@ -1065,8 +1225,15 @@ extern "C" int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc*
         p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = 0; p.zero_off = 0;
         p.in_relu = 0; p.out_act = 0; p.out_btc = 0;
         h.wh = wbh[i]; h.Mpad = round_up(p.M_g, 128); h.Cpad = round_up(p.C2_g, 64);
+        h.xh = mc.xh ? dyh[i] : nullptr; p.out_h = dxh ? dxh[i] : nullptr;
         rc = launch_bf16(d, 1, h, nullptr, 0, (hipStream_t)stream, &mc);
         if (rc) return rc;
     }
     return launch_multi_h(mc, (hipStream_t)stream);
+}
+
+extern "C" int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
+                                              const uint16_t* const* wbh, const float* const* mask_src,
+                                              const float* const* add_src, float* const* dx, void* stream) {
+    return stegan_conv1d_bwd_data_multi_hx(n, descs, dy, nullptr, wbh, mask_src, add_src, dx, nullptr, stream);
 }

@@ -54,7 +54,15 @@ struct DirP {
                                              // chains, ~35 scalar instructions each, in front of the first DMA)
     int ph_ntaps[MAX_PHASES], ph_kbase[MAX_PHASES], ph_kstep[MAX_PHASES], ph_offmin[MAX_PHASES], ph_step[MAX_PHASES];
     int ph_U[MAX_PHASES];               // per output phase: tap progression and column count, precomputed on the host
+    // round 3: bf16 activation image of the output, [B][out_cb][Tdst][8 channels] (channel-block-major, the layout the bf16
+    // kernels stage by LDS-DMA); null = not wanted.  Written beside the fp32 output by the fused epilogues.
+    unsigned short* out_h = nullptr;
+    int out_cb = 0;
 };
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
 
 __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, int ch, int to) {
     if (p.mode == 0) {
@@ -67,6 +75,7 @@ __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, in
         else if (p.out_act == STEGAN_ACT_TANH) v = tanhf(v);
         if (p.out_btc) p.out[((size_t)b * p.Tdst + to) * p.Cdst + ch] = v;
         else p.out[idx] = v;
+        if (p.out_h) p.out_h[(((size_t)b * p.out_cb + (ch >> 3)) * p.Tdst + to) * 8 + (ch & 7)] = f32_to_bf16_bits(v);
     } else {
         if (p.mask) {
             const float xv = p.mask[((size_t)b * p.Cdst + ch) * p.Tmask + (to >> p.ups)];
@@ -76,6 +85,7 @@ __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, in
         const size_t idx = ((size_t)b * p.Cdst + ch) * p.Tdst + to;
         if (p.res) v += p.res[idx];
         p.out[idx] = v;
+        if (p.out_h) p.out_h[(((size_t)b * p.out_cb + (ch >> 3)) * p.Tdst + to) * 8 + (ch & 7)] = f32_to_bf16_bits(v);
     }
 }
 

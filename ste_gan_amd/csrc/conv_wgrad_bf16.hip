@@ -72,21 +72,30 @@ __device__ __forceinline__ bf16x8 tr_operand(const char* a0, int d1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-// SIV: staging items per thread and operand with 16-byte loads.  Long rows (T >= 64: one batch element per chunk) need ONE
-// item each; that variant holds 64 staging registers less and is told to fit two blocks per CU (amdgpu_waves_per_eu: a
-// block is one wave per SIMD), where the two-item variant -- short rows, several batch elements and their halos per
-// chunk -- runs one block per CU (its LDS images do not fit twice either).
+// SIV: staging items per PRODUCER thread and operand with 16-byte loads (long rows, T >= 64: one; short rows, several
+// batch elements and their halos per chunk: two).
+//
+// Round 3: 8 waves with fixed roles, as in conv_bf16.hip.  Waves 0-3 (consumers, 2 co x 2 ci) only read operands and issue
+// MFMAs; waves 4-7 (producers) only stage: fp32 loads two chunks ahead into two register sets (no accumulators live in a
+// producer, so the registers are free), conversion + LDS stores one chunk ahead, one barrier per chunk.  The first
+// version had every wave do both in sequence -- load, MFMA, convert, store -- with one wave per SIMD and mostly one block
+// per CU: a chunk of the 512 -> 1024 k5 layer took 2.6 us for 640 cycles of MFMA work (124 us per launch, 130 TFLOP/s).
+// BiasW: the bias gradient rides in the same grid (blocks past the tile blocks), so a layer whose reduction is not
+// sliced needs ONE launch: its blocks add their tile straight into dW (no slab, no reduce launch).
+struct BiasW { const float* dy; float* db; int B, C, T, per, slices, vec, first; FastDiv fdT; };
+
 #ifndef STEGAN_WGRAD_WAVES
 #define STEGAN_WGRAD_WAVES 2
 #endif
 template <int TM, int TN, int KT, bool XV, int SIV>
-__device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restrict__ dw_direct) {
     constexpr int BM = 64 * TM, BN = 64 * TN;          // co x ci tile of the block
     constexpr int CBA = BM / 8, CBX = BN / 8;          // channel-block planes of the two images
     constexpr int SI = XV ? SIV : WS_MAX;
     extern __shared__ __align__(16) char smem[];       // dy image 0 | x image 0 | dy image 1 | x image 1
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;               // index inside the role's 256 threads
+    const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // block -> (ci tile fastest, co tile, group, tap group, slice): neighbours share the dy tile
@@ -107,14 +116,16 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
     const int nchunks = b_chunks * h.u_chunks;
 
     const int abuf = CBA * h.RSA * 16, xbuf = CBX * h.RSX * 16, bufsz = abuf + xbuf;
+    const int xsh = XV ? 2 + h.ups : 0;
+    const int xgm = (1 << xsh) - 1;
+
+    // =========================== producers (waves 4-7) ===========================
+    if (producer) {
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)h.x, 0, (int)h.x_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)h.dy, 0, (int)h.dy_bytes, 0x00020000);
     const bool relu = h.relu != 0;
-
     // ---- staging items (chunk invariant part): item = (channel block, slot or run of 4 slots), slots fastest.  With the
     // nearest-x2 upsample one 16-byte load of 4 source positions of x feeds 8 slots (as in conv_bf16.hip)
-    const int xsh = XV ? 2 + h.ups : 0;
-    const int xgm = (1 << xsh) - 1;
     int a_cg[SI], a_seg[SI], a_uu[SI], a_lds[SI];       // dy: plane, batch element within the chunk, position, LDS byte (-1: none)
     int x_cg[SI], x_seg[SI], x_sl[SI], x_lds[SI];
 #pragma unroll
@@ -135,51 +146,21 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
             x_lds[it] = (it < h.xit && cg < CBX) ? (cg * h.RSX + slot) * 16 : -1;
         }
     }
-    // ---- operand addresses.  Lane l: half hl, channel l & 31 of the wave's 32-channel tile; inside its 16-lane group
-    // i = l & 15 it supplies the piece (row q = i >> 2, channels 4 p .. 4 p + 3 with p = i & 3) of each transposed read
-    const int hl = lane >> 5, g16 = (lane >> 4) & 1, qrow = (lane >> 2) & 3, pp = lane & 3;
-    int a_byte[TM], b_byte[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-        a_byte[i] = (((wm * TM + i) * 4 + 2 * g16 + (pp >> 1)) * h.RSA + 8 * hl + qrow) * 16 + (pp & 1) * 8;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-        b_byte[j] = (((wn * TN + j) * 4 + 2 * g16 + (pp >> 1)) * h.RSX + qrow * h.stride) * 16 + (pp & 1) * 8;
-    // x slot of the first column of each transposed read: columns r4 = 16 st + 8 hl + 4 rd -> (batch element, position)
-    int xoff[NST_MAX][2];
-#pragma unroll
-    for (int st = 0; st < NST_MAX; ++st)
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int r4 = st * 16 + 8 * hl + 4 * rd;
-            const int seg = (int)fd_div((uint32_t)r4, h.fdRUp), uu = r4 - seg * h.RUp;
-            xoff[st][rd] = (seg * h.SEG + uu * h.stride) * 16;
-        }
-    const int tapB = h.dil * 16;
-
-    f32x16 acc[TM][TN][KT];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
-
-    float ar[XV ? 1 : WS_MAX][8], xr[XV ? 1 : WS_MAX][8];
-    f32x4 av[XV ? SIV : 1][8], xv[XV ? SIV : 1][8];
+    // two register sets: chunk c + 2 is loading while chunk c + 1 is converted and stored.  (The two-item 16-byte variant
+    // would need 256 staging registers for that -- it spilled 65-121 VGPRs when built so: it keeps ONE set and loads one
+    // chunk ahead, its load latency beside the consumers' MFMAs instead of behind a whole chunk.)
+    constexpr bool DEEP = !XV || SIV == 1;
+    float ar0[XV ? 1 : WS_MAX][8], xr0[XV ? 1 : WS_MAX][8], ar1[(XV || !DEEP) ? 1 : WS_MAX][8], xr1[(XV || !DEEP) ? 1 : WS_MAX][8];
+    f32x4 av0[XV ? SIV : 1][8], xv0[XV ? SIV : 1][8], av1[(XV && DEEP) ? SIV : 1][8], xv1[(XV && DEEP) ? SIV : 1][8];
     const int rowb_y = h.Tout * 4, rowb_x = h.Tin * 4;
     const int ylim = h.Cout_g - co0, xlim = h.Cin_g - ci0;       // live channels of the tiles
-    int adj_cur = 0, adj_nxt = 0;                                 // down-rounding of the x window start (XV)
 
-#define WG_LOAD(c_, adj_out)                                                                                    \
+#define WG_LOAD(c_, ar, av, xr, xv)                                                                             \
     {                                                                                                           \
         const int bc_ = (int)fd_div((uint32_t)(c_), h.fdUC), uc_ = (c_) - bc_ * h.u_chunks;                     \
         const int b0_ = b_begin + bc_ * h.NB, u0_ = uc_ * h.RU;                                                 \
         const int q0_ = u0_ * h.stride - h.pad + kk0 * h.dil;                                                   \
         const int qal_ = XV ? (q0_ & ~xgm) : q0_;                                                               \
-        adj_out = q0_ - qal_;                                                                                   \
         _Pragma("unroll") for (int it = 0; it < SI; ++it) {                                                     \
             if (it < h.ait) {                                                                                   \
                 const int b_ = b0_ + a_seg[it], u_ = u0_ + a_uu[it];                                            \
@@ -219,7 +200,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
         const u32x4 w_ = {wpack(r_[0], r_[1], relu_), wpack(r_[2], r_[3], relu_), wpack(r_[4], r_[5], relu_), wpack(r_[6], r_[7], relu_)}; \
         *(u32x4*)(dst_ + lds_) = w_;                                                                            \
     }
-#define WG_STORE(buf_)                                                                                          \
+#define WG_STORE(buf_, ar, av, xr, xv)                                                                          \
     {                                                                                                           \
         char* A_ = smem + (buf_) * bufsz;                                                                       \
         char* X_ = A_ + abuf;                                                                                   \
@@ -228,48 +209,114 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
             if (it < h.xit && x_lds[it] >= 0) { WG_STORE_ONE(X_, x_lds[it], xr[XV ? 0 : it], xv[XV ? it : 0], relu, xsh == 3) }  \
         }                                                                                                       \
     }
-
-    if (nchunks > 0) {
-        WG_LOAD(0, adj_cur)
-        WG_STORE(0)
-    }
-    for (int c = 0; c < nchunks; ++c) {
-        const int cur = c & 1;
-        block_sync();
-        const bool more = c + 1 < nchunks;
-        if (more) WG_LOAD(c + 1, adj_nxt)
-        const char* Acur = smem + cur * bufsz;
-        const char* Xcur = Acur + abuf + adj_cur * 16;
-        for (int st = 0; st < h.NST; ++st) {
-            bf16x8 a[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = tr_operand(Acur + a_byte[i] + st * 256, 64);
-            // xoff is indexed with a runtime st: select through registers (an indexed array would go to scratch)
-            int xo0 = 0, xo1 = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < NST_MAX; ++s2)
-                if (s2 == st) { xo0 = xoff[s2][0]; xo1 = xoff[s2][1]; }
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 b = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b, acc[i][j][k], 0, 0, 0);
+        // chunk c lives in register set c & 1 and LDS buffer c & 1.  Barrier c (the c-th block_sync of BOTH roles) says:
+        // chunk c is staged and visible, and the consumers have finished chunk c - 1 (its buffer may be overwritten).
+        if constexpr (!DEEP) {
+            if (nchunks > 0) {
+                WG_LOAD(0, ar0, av0, xr0, xv0)
+                WG_STORE(0, ar0, av0, xr0, xv0)
+            }
+            for (int c = 0; c < nchunks; ++c) {
+                block_sync();                                         // barrier c
+                if (c + 1 < nchunks) {
+                    WG_LOAD(c + 1, ar0, av0, xr0, xv0)
+                    WG_STORE((c + 1) & 1, ar0, av0, xr0, xv0)
                 }
             }
+            return;
         }
-        if (more) {
-            WG_STORE(cur ^ 1)
-            adj_cur = adj_nxt;
+        if (nchunks > 0) {
+            WG_LOAD(0, ar0, av0, xr0, xv0)
+            if (nchunks > 1) WG_LOAD(1, ar1, av1, xr1, xv1)
+            WG_STORE(0, ar0, av0, xr0, xv0)
         }
+        for (int c = 0; c < nchunks; c += 2) {
+            block_sync();                                             // barrier c
+            if (c + 2 < nchunks) WG_LOAD(c + 2, ar0, av0, xr0, xv0)   // set 0 held chunk c: stored before barrier c
+            if (c + 1 < nchunks) WG_STORE(1, ar1, av1, xr1, xv1)      // chunk c + 1 -> buffer 1 (chunk c - 1 is done with it)
+            if (c + 1 >= nchunks) break;
+            block_sync();                                             // barrier c + 1
+            if (c + 3 < nchunks) WG_LOAD(c + 3, ar1, av1, xr1, xv1)
+            if (c + 2 < nchunks) WG_STORE(0, ar0, av0, xr0, xv0)
+        }
+        return;                                         // the accumulators live in the consumer waves
     }
 #undef WG_LOAD
 #undef WG_STORE
 #undef WG_STORE_ONE
 
-    // ---- slab store: accumulator tile = 32 co (registers: 4 runs of 4 rows) x 32 ci (lanes): coalesced along ci
+    // =========================== consumers (waves 0-3) ===========================
+    // ---- operand addresses.  Lane l: half hl, channel l & 31 of the wave's 32-channel tile; inside its 16-lane group
+    // i = l & 15 it supplies the piece (row q = i >> 2, channels 4 p .. 4 p + 3 with p = i & 3) of each transposed read
+    const int hl = lane >> 5, g16 = (lane >> 4) & 1, qrow = (lane >> 2) & 3, pp = lane & 3;
+    int a_byte[TM], b_byte[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        a_byte[i] = (((wm * TM + i) * 4 + 2 * g16 + (pp >> 1)) * h.RSA + 8 * hl + qrow) * 16 + (pp & 1) * 8;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+        b_byte[j] = (((wn * TN + j) * 4 + 2 * g16 + (pp >> 1)) * h.RSX + qrow * h.stride) * 16 + (pp & 1) * 8;
+    // x slot of the first column of each transposed read: columns r4 = 16 st + 8 hl + 4 rd -> (batch element, position)
+    int xoff[NST_MAX][2];
+#pragma unroll
+    for (int st = 0; st < NST_MAX; ++st)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r4 = st * 16 + 8 * hl + 4 * rd;
+            const int seg = (int)fd_div((uint32_t)r4, h.fdRUp), uu = r4 - seg * h.RUp;
+            xoff[st][rd] = (seg * h.SEG + uu * h.stride) * 16;
+        }
+    const int tapB = h.dil * 16;
+
+    f32x16 acc[TM][TN][KT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int cur = c & 1;
+        block_sync();                                                 // barrier c: chunk c is staged
+        int adj = 0;                                                  // down-rounding of the x window start (XV)
+        if (XV) {
+            const int bc = (int)fd_div((uint32_t)c, h.fdUC), uc = c - bc * h.u_chunks;
+            const int q0 = uc * h.RU * h.stride - h.pad + kk0 * h.dil;
+            adj = q0 - (q0 & ~xgm);
+        }
+        const char* Acur = smem + cur * bufsz;
+        const char* Xcur = Acur + abuf + adj * 16;
+        for (int st = 0; st < h.NST; ++st) {
+            // xoff is indexed with a runtime st: select through registers (an indexed array would go to scratch)
+            int xo0 = 0, xo1 = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < NST_MAX; ++s2)
+                if (s2 == st) { xo0 = xoff[s2][0]; xo1 = xoff[s2][1]; }
+            // every operand read of the k-step is issued before its first MFMA (one exposed LDS round trip per k-step,
+            // not one per tap; the partner producer wave fills the rest)
+            bf16x8 a[TM], bfr[KT][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = tr_operand(Acur + a_byte[i] + st * 256, 64);
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[k][j] = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);
+#pragma unroll
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bfr[k][j], acc[i][j][k], 0, 0, 0);
+        }
+    }
+
+    // ---- store: accumulator tile = 32 co (registers: 4 runs of 4 rows) x 32 ci (lanes).  Sliced reductions write their
+    // partial dW to a slab [slice][kk][co][ci] (coalesced along ci), summed by the reduce kernel in a fixed order; an
+    // unsliced one adds straight into dW (Cout, Cin_g, K): this block is the only writer of its elements.
     const int l31 = lane & 31;
     float* slab = h.partial + (size_t)slice * h.K_eff * h.Cout * h.Cin_g;
 #pragma unroll
@@ -285,17 +332,45 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int co = cob + (e & 3) + 8 * (e >> 2);
-                    if (ci < h.Cin_g && co < h.Cout_g)
-                        slab[((size_t)kk * h.Cout + g * h.Cout_g + co) * h.Cin_g + ci] = acc[i][j][k][e];
+                    if (ci < h.Cin_g && co < h.Cout_g) {
+                        if (dw_direct) dw_direct[((size_t)(g * h.Cout_g + co) * h.Cin_g + ci) * h.K + h.k_lo + kk] += acc[i][j][k][e];
+                        else slab[((size_t)kk * h.Cout + g * h.Cout_g + co) * h.Cin_g + ci] = acc[i][j][k][e];
+                    }
                 }
             }
         }
     }
 }
 
-template <int TM, int TN, int KT, bool XV>
-__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
-    conv_wgrad_bf16_body<TM, TN, KT, XV, WSV_MAX>(h);
+// bias-gradient blocks of the weight-gradient grid (512 threads): db[c] += sum over a batch slice of dy[b, c, :]
+__device__ __forceinline__ void wg_bias_block(const BiasW& ba, int j) {
+    const int c = j / ba.slices, slice = j - c * ba.slices;
+    const int b0 = slice * ba.per, b1 = min(ba.B, b0 + ba.per);
+    float s = 0.f;
+    if (ba.vec) {
+        const int T4 = ba.T >> 2, n = (b1 - b0) * T4;
+        for (int r = threadIdx.x; r < n; r += 512) {
+            const int bi = (int)fd_div((uint32_t)r, ba.fdT), t4 = r - bi * T4;
+            const float4 v = *reinterpret_cast<const float4*>(ba.dy + ((size_t)(b0 + bi) * ba.C + c) * ba.T + 4 * t4);
+            s += (v.x + v.y) + (v.z + v.w);
+        }
+    } else {
+        const int n = (b1 - b0) * ba.T;
+        for (int r = threadIdx.x; r < n; r += 512) {
+            const int bi = (int)fd_div((uint32_t)r, ba.fdT), t_ = r - bi * ba.T;
+            s += ba.dy[((size_t)(b0 + bi) * ba.C + c) * ba.T + t_];
+        }
+    }
+    extern __shared__ __align__(16) char smem_bias[];       // the grid's dynamic LDS (>= 32 bytes: the tile blocks' images)
+    float* part = reinterpret_cast<float*>(smem_bias);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    block_sync();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 8; ++w) tot += part[w];
+        atomicAdd(&ba.db[c], tot);
+    }
 }
 
 #if STEGAN_WGRAD_WAVES > 0
@@ -303,9 +378,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WH h) {
 #else
 #define WG_OCC
 #endif
+template <int TM, int TN, int KT, bool XV>
+__global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_kernel(const WH h, float* dw_direct, const BiasW ba) {
+    if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
+    conv_wgrad_bf16_body<TM, TN, KT, XV, WSV_MAX>(h, dw_direct);
+}
+
 template <int TM, int TN, int KT>
-__global__ __launch_bounds__(256) WG_OCC void conv_wgrad_bf16_one_kernel(const WH h) {
-    conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h);
+__global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_one_kernel(const WH h, float* dw_direct, const BiasW ba) {
+    if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
+    conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h, dw_direct);
 }
 
 // dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
@@ -349,7 +431,7 @@ int wgh_live_taps(const stegan_conv_desc* d, int& k_lo) {
 }
 
 template <int TM, int TN, int KT>
-void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h) {
+void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, float* dw_direct, const BiasW& bw) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -359,9 +441,9 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h) {
     }
     static const bool no_one = getenv("STEGAN_BF16_WGRAD_NO_ONE") != nullptr;       // experiments
     if (xv && h.ait <= 1 && h.xit <= 1 && !no_one)
-        hipLaunchKernelGGL((conv_wgrad_bf16_one_kernel<TM, TN, KT>), grid, dim3(256), lds, s, h);
-    else if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(256), lds, s, h);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(256), lds, s, h);
+        hipLaunchKernelGGL((conv_wgrad_bf16_one_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
+    else if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(512), lds, s, h, dw_direct, bw);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(512), lds, s, h, dw_direct, bw);
 }
 
 }  // namespace
@@ -468,29 +550,36 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
                          d->B, h.Cin_g, h.Cout_g, d->K, h.K_eff, d->stride, d->dilation, d->Tin, d->Tout, BM, BN, KT, h.NTG, h.NB,
                          h.RU, h.R, h.SEG, h.RSA, h.RSX, h.ait, h.xit, lds, tiles, h.slices, (int)xv);
     }
-    dim3 grid((unsigned)(tiles * h.slices));
+    // the bias gradient rides in the same grid (blocks past the tile blocks); an unsliced reduction adds straight into dW
+    BiasW bw;
+    bw.dy = dy; bw.db = db; bw.B = d->B; bw.C = d->Cout; bw.T = d->Tout;
+    bw.slices = db ? bias_grad_slices(d->B, d->Cout, d->Tout) : 0;
+    bw.per = db ? ceil_div(d->B, bw.slices) : 1;
+    bw.slices = db ? ceil_div(d->B, bw.per) : 0;
+    bw.vec = (d->Tout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+    bw.fdT = make_fastdiv((uint32_t)(bw.vec ? d->Tout / 4 : d->Tout));
+    bw.first = (int)(tiles * h.slices);
+    static const bool no_direct = getenv("STEGAN_BF16_WGRAD_NO_DIRECT") != nullptr;      // experiments
+    float* dw_direct = (h.slices == 1 && !no_direct) ? dw : nullptr;
+    dim3 grid((unsigned)(tiles * h.slices + (long)bw.slices * d->Cout));
     if (KT == 1) {
-        if (TM == 2 && TN == 2) wgh_launch<2, 2, 1>(xv, grid, lds, s, h);
-        else if (TM == 2) wgh_launch<2, 1, 1>(xv, grid, lds, s, h);
-        else if (TN == 2) wgh_launch<1, 2, 1>(xv, grid, lds, s, h);
-        else wgh_launch<1, 1, 1>(xv, grid, lds, s, h);
+        if (TM == 2 && TN == 2) wgh_launch<2, 2, 1>(xv, grid, lds, s, h, dw_direct, bw);
+        else if (TM == 2) wgh_launch<2, 1, 1>(xv, grid, lds, s, h, dw_direct, bw);
+        else if (TN == 2) wgh_launch<1, 2, 1>(xv, grid, lds, s, h, dw_direct, bw);
+        else wgh_launch<1, 1, 1>(xv, grid, lds, s, h, dw_direct, bw);
     } else if (KT == 3) {
-        if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h);
-        else wgh_launch<1, 1, 3>(xv, grid, lds, s, h);
-    } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h);
-    else wgh_launch<1, 1, 8>(xv, grid, lds, s, h);
-    {
+        if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
+        else wgh_launch<1, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
+    } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h, dw_direct, bw);
+    else wgh_launch<1, 1, 8>(xv, grid, lds, s, h, dw_direct, bw);
+    if (!dw_direct) {
         const long per_tap = (long)h.Cout * h.Cin_g;
         long rb = (per_tap * h.K_eff + 255) / 256;
         if (rb > 2048) rb = 2048;
         BiasArgs ba;
-        ba.dy = dy; ba.db = db; ba.B = d->B; ba.C = d->Cout; ba.T = d->Tout;
-        ba.slices = db ? bias_grad_slices(d->B, d->Cout, d->Tout) : 0;
-        ba.per = db ? ceil_div(d->B, ba.slices) : 1;
-        ba.slices = db ? ceil_div(d->B, ba.per) : 0;
-        ba.vec = (d->Tout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
-        ba.fdT = make_fastdiv((uint32_t)(ba.vec ? d->Tout / 4 : d->Tout));
-        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)(rb + (long)ba.slices * d->Cout)), dim3(256), 0, s,
+        ba.dy = dy; ba.db = nullptr; ba.B = d->B; ba.C = d->Cout; ba.T = d->Tout; ba.slices = 0; ba.per = 1; ba.vec = 0;
+        ba.fdT = make_fastdiv(1u);
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s,
                            h.partial, dw, per_tap, h.slices, d->K, h.k_lo, h.K_eff, (int)rb, ba);
     }
     STEGAN_LAUNCH_CHECK();

@@ -122,7 +122,8 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     if rc != 1:
         LAST_CONV_KERNEL = kind
         PROFILER.records.append((name, nominal, live, e0, e1,
-                                 (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout)))
+                                 (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout,
+                                  d.pad, d.in_act, d.out_act)))
     return rc
 
 def profiler_by_shape(prof: "ConvProfiler"):
@@ -190,6 +191,33 @@ def _bf16_of(w: Optional[Tensor]) -> Optional[Tensor]:
     """The bf16 companion of a prepared fp32 weight copy (attribute ``h``, attached by prep_weights / ConvPack), or None
     in fp32 mode."""
     return getattr(w, "h", None) if (w is not None and COMPUTE_DTYPE == "bf16") else None
+
+
+# ---- bf16 activation images (round 3) -------------------------------------------------------------------------------
+# In bf16 mode a conv launch also writes its output as a bf16 image in the channel-block-major layout the kernels stage by
+# LDS-DMA -- (B, ceil(C / 8), T, 8), attribute ``.h`` of the fp32 tensor -- and takes its input from such an image when the
+# tensor carries one: the consumer then moves half the bytes with no loads into registers, no conversion and no LDS stores
+# (the producer waves' instruction stream was what bounded the bf16 kernels: DESIGN.md section 6).  The fp32 tensor stays
+# the tensor of record (residuals, masks, losses, parity); an image is only ever read by a conv kernel.
+IMAGES = os.environ.get("STEGAN_BF16_IMAGES", "1") != "0"
+
+
+def _image_of(t: Optional[Tensor], channels: int, length: int) -> Optional[Tensor]:
+    """The bf16 image attached to ``t`` when it matches (B, ceil(C/8), T, 8), else None."""
+    h = getattr(t, "h", None) if (t is not None and IMAGES and COMPUTE_DTYPE == "bf16") else None
+    if h is None or h.dtype != torch.bfloat16 or not h.is_contiguous():
+        return None
+    if tuple(h.shape) != (t.shape[0], (channels + 7) // 8, length, 8) or h.device != t.device:
+        return None
+    return h
+
+
+def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optional[Tensor]:
+    """An empty image for a (B, channels, length) output, or None when the layer does not qualify (whole 8-channel blocks
+    per group) or images are off."""
+    if not (IMAGES and COMPUTE_DTYPE == "bf16") or channels % 8 or (channels // groups) % 8 or channels < 16:
+        return None
+    return torch.empty((like.shape[0], channels // 8, length, 8), device=like.device, dtype=torch.bfloat16)
 
 
 def bump_weight_epoch() -> None:
@@ -281,11 +309,15 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
     wfh = _bf16_of(wf)
     if wfh is not None:
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
-        rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_h(C.byref(d), _p(x), _p(wfh), _p(scale), _p(bias),
-                                                                 _p(residual), _p(y), _p(ws), ws.numel(), _stream()),
+        xh = _image_of(x, cfg.cin, tin)
+        yh = None if cfg.out_btc else _new_image(y, cfg.cout, cfg.groups, tout)
+        rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_hx(C.byref(d), _p(x), _p(xh), _p(wfh), _p(scale), _p(bias),
+                                                                  _p(residual), _p(y), _p(yh), _p(ws), ws.numel(), _stream()),
                     "bf16")
         if rc != 1:
-            check(rc, "stegan_conv1d_fwd_h")
+            check(rc, "stegan_conv1d_fwd_hx")
+            if yh is not None:
+                y.h = yh
             return y
     if wf is not None and COMPUTE_DTYPE != "bf16":       # (bf16 mode does not maintain the fp32 copies: prep_weights)
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
@@ -320,11 +352,16 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     if wbh is not None:
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
-        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_h(C.byref(d), _p(dy), _p(wbh), _p(us), _p(mask_src),
-                                                                      _p(add_src), _p(dx), _p(ws), ws.numel(), _stream()),
+        dyh = _image_of(dy, cfg.cout, tout)
+        dxh = _new_image(dx, cfg.cin, cfg.groups, tin * cfg.upsample) if cfg.upsample == 1 else None
+        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_hx(C.byref(d), _p(dy), _p(dyh), _p(wbh), _p(us),
+                                                                       _p(mask_src), _p(add_src), _p(dx), _p(dxh), _p(ws),
+                                                                       ws.numel(), _stream()),
                     "bf16")
         if rc != 1:
-            check(rc, "stegan_conv1d_bwd_data_h")
+            check(rc, "stegan_conv1d_bwd_data_hx")
+            if dxh is not None:
+                dx.h = dxh
             return dx
     if wb is not None and COMPUTE_DTYPE != "bf16":
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
@@ -578,10 +615,17 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases, raws=None):
             return ys
     whs = [_bf16_of(w) for w in wfs]
     if all(w is not None for w in whs):
-        rc = _lib.lib().stegan_conv1d_fwd_multi_h(n, dptr, _ptr_array(xs), _ptr_array(whs), _ptr_array(scales),
-                                                  _ptr_array(biases), None, _ptr_array(ys), _stream())
+        xhs = [_image_of(x, c.cin, x.shape[2]) for x, c in zip(xs, cfgs)]
+        yhs = [_new_image(y, c.cout, c.groups, y.shape[2]) for y, c in zip(ys, cfgs)]
+        rc = _lib.lib().stegan_conv1d_fwd_multi_hx(n, dptr, _ptr_array(xs), _ptr_array(xhs) if all(h is not None for h in xhs) else None,
+                                                   _ptr_array(whs), _ptr_array(scales), _ptr_array(biases), None,
+                                                   _ptr_array(ys), _ptr_array(yhs) if any(h is not None for h in yhs) else None,
+                                                   _stream())
         if rc != 1:
-            check(rc, "stegan_conv1d_fwd_multi_h")
+            check(rc, "stegan_conv1d_fwd_multi_hx")
+            for y, yh in zip(ys, yhs):
+                if yh is not None:
+                    y.h = yh
             return ys
         return None                     # per-problem launches (each picks bf16 or fp32 on its own)
     if COMPUTE_DTYPE == "bf16":
@@ -613,10 +657,17 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
             return dxs
     whs = [_bf16_of(w) for w in wbs]
     if all(w is not None for w in whs):
-        rc = _lib.lib().stegan_conv1d_bwd_data_multi_h(n, dptr, _ptr_array(dys), _ptr_array(whs), None, None, _ptr_array(dxs),
-                                                       _stream())
+        dyhs = [_image_of(t, c.cout, t.shape[2]) for t, c in zip(dys, cfgs)]
+        dxhs = [_new_image(t, c.cin, c.groups, t.shape[2]) for t, c in zip(dxs, cfgs)]
+        rc = _lib.lib().stegan_conv1d_bwd_data_multi_hx(n, dptr, _ptr_array(dys),
+                                                        _ptr_array(dyhs) if all(h is not None for h in dyhs) else None,
+                                                        _ptr_array(whs), None, None, _ptr_array(dxs),
+                                                        _ptr_array(dxhs) if any(h is not None for h in dxhs) else None, _stream())
         if rc != 1:
-            check(rc, "stegan_conv1d_bwd_data_multi_h")
+            check(rc, "stegan_conv1d_bwd_data_multi_hx")
+            for t, th in zip(dxs, dxhs):
+                if th is not None:
+                    t.h = th
             return dxs
         return None
     if COMPUTE_DTYPE == "bf16":

@@ -35,8 +35,24 @@ def bf16r(t):
     return t.to(torch.bfloat16).to(torch.float64)
 
 
+def make_image(t):
+    """The bf16 activation image of a (B, C, T) tensor: (B, ceil(C/8), T, 8), channel-block-major (ops._image_of)."""
+    B, C, T = t.shape
+    CB = (C + 7) // 8
+    full = torch.zeros(B, CB * 8, T, device=t.device, dtype=t.dtype)
+    full[:, :C] = t
+    return full.view(B, CB, 8, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+
+
 @pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
-def test_conv_bf16_fwd_bwd_data(cfg):
+def test_conv_bf16_with_activation_images(cfg):
+    """The same parity bar with the source handed over as a bf16 image (staged by LDS-DMA, ReLU applied at the operand
+    read) and the output image requested: the image the kernel writes is exactly bf16(fp32 output), rearranged."""
+    test_conv_bf16_fwd_bwd_data(cfg, images=True)
+
+
+@pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16_fwd_bwd_data(cfg, images=False):
     from ste_gan_amd import ops
     B, Cin, Cout, K, s, d, p, g, up, relu, Tin = cfg
     gen = torch.Generator().manual_seed(hash(cfg) % (2 ** 31))
@@ -78,10 +94,17 @@ def test_conv_bf16_fwd_bwd_data(cfg):
     try:
         wf, wb = ops.prep_weights(wg, c, None, sg)
         assert wf.h.dtype == torch.bfloat16 and wb.h is not None
+        if images:
+            xg.h, dyg.h = make_image(xg), make_image(dyg)
+            assert ops._image_of(xg, Cin, Tin) is not None
         y = ops.conv1d_fwd(xg, wg, sg, bg, rg, c, wf)
         k_fwd = ops.LAST_CONV_KERNEL
         dxe = ops.conv1d_bwd_data(dyg, wg, sg, xg if relu else None, addg, c, Tin, wb)
         k_bwd = ops.LAST_CONV_KERNEL
+        if k_fwd == "bf16" and Cout % 8 == 0 and (Cout // g) % 8 == 0 and Cout >= 16:
+            assert torch.equal(y.h.view(torch.int16), make_image(y).view(torch.int16)), "output image != bf16(y)"
+        if k_bwd == "bf16" and up == 1 and Cin % 8 == 0 and (Cin // g) % 8 == 0 and Cin >= 16:
+            assert torch.equal(dxe.h.view(torch.int16), make_image(dxe).view(torch.int16)), "input-gradient image != bf16(dx)"
     finally:
         ops.set_compute_dtype("f32")
     cin_g, cout_g = Cin // g, Cout // g

@@ -194,6 +194,28 @@ int stegan_conv1d_fwd_hx(const stegan_conv_desc* d, const float* x, const uint16
 int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float* dy, const uint16_t* dyh, const uint16_t* wbh,
                               const float* scale, const float* mask_src, const float* add_src, float* dx, uint16_t* dxh,
                               float* workspace, int64_t workspace_floats, void* stream);
+/* the elementwise producers of the path with an image of their output beside it (out_h / dx_h / y_h / dz_h / dqkv_h nullable;
+ * C % 8 == 0; act_bwd additionally T % 4 == 0): as the functions of the same name without `_img` */
+int stegan_act_bwd_add_img(const float* dy, const float* add, const float* y, float* out, uint16_t* out_h, int64_t n, int32_t C,
+                           int32_t T, int32_t act, void* stream);
+int stegan_act_bwd_add_multi_img(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
+                                 float* const* out, uint16_t* const* out_h, const int64_t* n, const int32_t* Cs,
+                                 const int32_t* Ts, int32_t act, void* stream);
+int stegan_fold_upsample2_img(const float* dxe, float* dx, uint16_t* dx_h, int64_t rows, int32_t C, int32_t T, void* stream);
+int stegan_relpos_attention_fwd_img(const float* qkv, const float* rel_emb, float* probs, float* out, uint16_t* out_h, int32_t B,
+                                    int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream);
+int stegan_relpos_attention_bwd_img(const float* qkv, const float* rel_emb, const float* probs, const float* dout,
+                                    float* workspace, float* dqkv, uint16_t* dqkv_h, int32_t B, int32_t H, int32_t A, int32_t T,
+                                    int32_t max_rel, void* stream);
+int stegan_add_layernorm_fwd_img(const float* x, const float* residual, const float* gamma, const float* beta, float* y,
+                                 uint16_t* y_h, float* xhat, float* rstd, int32_t B, int32_t C, int32_t T, float eps,
+                                 void* stream);
+int stegan_add_layernorm_bwd_img(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dz,
+                                 uint16_t* dz_h, int32_t B, int32_t C, int32_t T, void* stream);
+/* weight gradient with both operands as images (nullable; taken only when BOTH are given): as stegan_conv1d_bwd_weight_h */
+int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
+                                void* stream);
 int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
                                const float* const* bias, const float* const* residual, float* const* y,

@@ -63,6 +63,12 @@ __device__ __forceinline__ void block_sync() {
     __syncthreads();
 }
 
+// one element of a bf16 activation image [B][CB = ceil(C / 8)][T][8 channels] (include/stegan_hip.h, "ACTIVATION IMAGES"): what
+// the elementwise producers write beside their fp32 output so that the conv kernel behind them stages it by LDS-DMA
+__device__ __forceinline__ void img_store(unsigned short* __restrict__ img, int CB, int T, int b, int c, int t, float v) {
+    img[(((size_t)b * CB + (c >> 3)) * T + t) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
 // wave64 sum
 __device__ static inline float wave_sum(float v) {
 #pragma unroll

@@ -53,7 +53,14 @@ struct WH {
     int co_tiles, ci_tiles, slices, bps;     // bps = batch elements per slice (multiple of NB)
     unsigned x_bytes, dy_bytes;
     FastDiv fdNGA, fdNGX, fdRUp, fdSEG, fdUC, fdCI, fdCO, fdTG;
+    // round 3: both operands as bf16 activation images [B][C / 8][T][8] (conv_bf16.hip's DirP::out_h): staged by LDS-DMA
+    const unsigned short* xh = nullptr;
+    const unsigned short* dyh = nullptr;
+    unsigned xh_bytes = 0, dyh_bytes = 0;
+    int xslots = 0;            // staged slots of an x plane
 };
+
+constexpr int WDI = 8;         // image path: LDS-DMA wave-instructions per producer wave, operand and chunk
 
 __device__ __forceinline__ unsigned wpack(float a, float b, bool relu) {
     const f32x2 f = {a, b};
@@ -87,8 +94,9 @@ struct BiasW { const float* dy; float* db; int B, C, T, per, slices, vec, first;
 #ifndef STEGAN_WGRAD_WAVES
 #define STEGAN_WGRAD_WAVES 2
 #endif
-template <int TM, int TN, int KT, bool XV, int SIV>
+template <int TM, int TN, int KT, bool XV, int SIV, bool XH = false>
 __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restrict__ dw_direct) {
+    static_assert(!(XV && XH), "the image path has no use for the 16-byte fp32 loads");
     constexpr int BM = 64 * TM, BN = 64 * TN;          // co x ci tile of the block
     constexpr int CBA = BM / 8, CBX = BN / 8;          // channel-block planes of the two images
     constexpr int SI = XV ? SIV : WS_MAX;
@@ -121,6 +129,75 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
 
     // =========================== producers (waves 4-7) ===========================
     if (producer) {
+    if constexpr (XH) {
+        // ---- both operands are bf16 images [B][C / 8][T][8]: a 16-byte piece of the LDS images IS 16 contiguous bytes of
+        // them.  One wave-instruction copies up to 64 consecutive slots of ONE channel-block plane (LDS-DMA lands at
+        // wave-uniform base + 16 * lane, and the planes are padded to the conflict-free pitch); instruction ii of a plane
+        // list goes to wave ii % 4.  Slots past the row / batch slice / padding carry an out-of-range offset (the buffer
+        // unit writes zeros); lanes past a plane's staged slots are switched off.
+        typedef __attribute__((address_space(3))) void* lds_ptr_t;
+        const auto rs_xh = __builtin_amdgcn_make_buffer_rsrc((void*)h.xh, 0, (int)h.xh_bytes, 0x00020000);
+        const auto rs_yh = __builtin_amdgcn_make_buffer_rsrc((void*)h.dyh, 0, (int)h.dyh_bytes, 0x00020000);
+        const int CBy = h.Cout >> 3, CBx = h.Cin >> 3;              // planes per batch element of the two images
+        const int runsA = (h.R + 63) >> 6, runsX = (h.xslots + 63) >> 6;
+        const int nA = CBA * runsA, nX = CBX * runsX;               // wave-instructions per chunk
+        const int ylive = (h.Cout_g - co0 + 7) >> 3, xlive = (h.Cin_g - ci0 + 7) >> 3;     // live planes of the tiles
+        // chunk-invariant per-lane parts
+        int a_lane[WDI], a_seg[WDI], a_uu[WDI], a_ldsb[WDI];        // dy: byte offset without the chunk term | -1, row, position
+        int x_lane[WDI], x_seg[WDI], x_sl[WDI], x_ldsb[WDI];
+#pragma unroll
+        for (int it = 0; it < WDI; ++it) {
+            {
+                const int ii = it * 4 + wave, cg = ii / runsA, run = ii - cg * runsA, slot = run * 64 + lane;
+                const int seg = (int)fd_div((uint32_t)slot, h.fdRUp), uu = slot - seg * h.RUp;
+                const bool on = ii < nA && slot < h.R;
+                a_seg[it] = seg; a_uu[it] = uu;
+                a_ldsb[it] = ii < nA ? (cg * h.RSA + run * 64) * 16 : -1;
+                a_lane[it] = (on && cg < ylive && seg < h.NB && uu < h.RU)
+                                 ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : (on ? -2 : -1);
+            }
+            {
+                const int ii = it * 4 + wave, cg = ii / runsX, run = ii - cg * runsX, slot = run * 64 + lane;
+                const int seg = (int)fd_div((uint32_t)slot, h.fdSEG), sl = slot - seg * h.SEG;
+                const bool on = ii < nX && slot < h.xslots;
+                x_seg[it] = seg; x_sl[it] = sl;
+                x_ldsb[it] = ii < nX ? (cg * h.RSX + run * 64) * 16 : -1;
+                x_lane[it] = (on && cg < xlive) ? ((seg * CBx + ((g * h.Cin_g + ci0) >> 3) + cg) * h.Tin) * 16 : (on ? -2 : -1);
+            }
+        }
+        // -1: lane switched off (past the plane's staged slots); -2: staged as zeros
+#define WG_DMA(c_, buf_)                                                                                        \
+        {                                                                                                       \
+            const int bc_ = (int)fd_div((uint32_t)(c_), h.fdUC), uc_ = (c_) - bc_ * h.u_chunks;                 \
+            const int b0_ = b_begin + bc_ * h.NB, u0_ = uc_ * h.RU;                                             \
+            const int q0_ = u0_ * h.stride - h.pad + kk0 * h.dil;                                               \
+            char* A_ = smem + (buf_) * bufsz;                                                                   \
+            char* X_ = A_ + abuf;                                                                               \
+            const int so_y = (b0_ * CBy * h.Tout + u0_) * 16, so_x = b0_ * CBx * h.Tin * 16;                    \
+            _Pragma("unroll") for (int it = 0; it < WDI; ++it) {                                                \
+                if (a_ldsb[it] >= 0 && a_lane[it] != -1) {                                                      \
+                    const bool ok_ = a_lane[it] >= 0 && b0_ + a_seg[it] < b_end && u0_ + a_uu[it] < h.Tout;     \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr_t)(A_ + a_ldsb[it]), 16,           \
+                                                             ok_ ? a_lane[it] : (int)OOBW, so_y, 0, 0);         \
+                }                                                                                               \
+            }                                                                                                   \
+            _Pragma("unroll") for (int it = 0; it < WDI; ++it) {                                                \
+                if (x_ldsb[it] >= 0 && x_lane[it] != -1) {                                                      \
+                    const int q_ = q0_ + x_sl[it];                                                              \
+                    const bool ok_ = x_lane[it] >= 0 && b0_ + x_seg[it] < b_end && q_ >= 0 && q_ < h.Te;        \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_ptr_t)(X_ + x_ldsb[it]), 16,           \
+                                                             ok_ ? x_lane[it] + (q_ >> h.ups) * 16 : (int)OOBW, so_x, 0, 0); \
+                }                                                                                               \
+            }                                                                                                   \
+        }
+        if (nchunks > 0) WG_DMA(0, 0)
+        for (int c = 0; c < nchunks; ++c) {
+            block_sync();                          // barrier c: chunk c has landed (vmcnt(0) in front of the barrier)
+            if (c + 1 < nchunks) WG_DMA(c + 1, (c + 1) & 1)
+        }
+        return;
+#undef WG_DMA
+    } else {
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)h.x, 0, (int)h.x_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)h.dy, 0, (int)h.dy_bytes, 0x00020000);
     const bool relu = h.relu != 0;
@@ -240,6 +317,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
             if (c + 2 < nchunks) WG_STORE(0, ar0, av0, xr0, xv0)
         }
         return;                                         // the accumulators live in the consumer waves
+    }   // !XH
     }
 #undef WG_LOAD
 #undef WG_STORE
@@ -277,6 +355,9 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
             for (int k = 0; k < KT; ++k)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][k][e] = 0.f;
+    const short rfl = (XH && h.relu) ? (short)0 : (short)-32768;       // max(x, 0) on packed halves, or identity
+    const s16x8 relu_fl = {rfl, rfl, rfl, rfl, rfl, rfl, rfl, rfl};
+    (void)relu_fl;
 
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
@@ -304,6 +385,13 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
             for (int k = 0; k < KT; ++k)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bfr[k][j] = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);
+            if constexpr (XH) {                    // image path: the input ReLU is applied at the operand (LDS-DMA moves bytes)
+#pragma unroll
+                for (int k = 0; k < KT; ++k)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bfr[k][j] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bfr[k][j]), relu_fl));
+            }
 #pragma unroll
             for (int k = 0; k < KT; ++k)
 #pragma unroll
@@ -390,6 +478,12 @@ __global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_one_kernel(const W
     conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h, dw_direct);
 }
 
+template <int TM, int TN, int KT>
+__global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_img_kernel(const WH h, float* dw_direct, const BiasW ba) {
+    if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
+    conv_wgrad_bf16_body<TM, TN, KT, false, 1, true>(h, dw_direct);
+}
+
 // dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
 // The bias gradient rides in the same launch: blocks past the first `rb` are bias_grad_body (channel, batch slice) blocks
 // over the fp32 dy (one launch less per layer: 52 a step).
@@ -437,7 +531,12 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TM, TN, KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_one_kernel<TM, TN, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_img_kernel<TM, TN, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
+    }
+    if (h.xh) {
+        hipLaunchKernelGGL((conv_wgrad_bf16_img_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
+        return;
     }
     static const bool no_one = getenv("STEGAN_BF16_WGRAD_NO_ONE") != nullptr;       // experiments
     if (xv && h.ait <= 1 && h.xit <= 1 && !no_one)
@@ -450,8 +549,9 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
 
 // Accumulates into dw (and db, through the fp32 bias-gradient kernel).  Returns 1 (nothing enqueued) for shapes left to
 // the fp32 kernels: fewer than 16 channels per group on either side, or a workspace too small for one slab.
-extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
-                                          float* workspace, int64_t workspace_floats, void* stream) {
+extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                           const uint16_t* dyh, float* dw, float* db, float* workspace,
+                                           int64_t workspace_floats, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
@@ -459,6 +559,15 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     hipStream_t s = (hipStream_t)stream;
     WH h;
     h.x = x; h.dy = dy;
+    // both operands as bf16 images (LDS-DMA staging): whole 8-channel blocks per group on both sides
+    static const bool no_xh = getenv("STEGAN_BF16_NO_XH") != nullptr;
+    const bool img = xh && dyh && !no_xh && (d->Cin / d->groups) % 8 == 0 && (d->Cout / d->groups) % 8 == 0 &&
+                     (int64_t)d->B * (d->Cin / 8) * d->Tin * 16 < (int64_t)OOBW && (int64_t)d->B * (d->Cout / 8) * d->Tout * 16 < (int64_t)OOBW;
+    if (img) {
+        h.xh = xh; h.dyh = dyh;
+        h.xh_bytes = (unsigned)((int64_t)d->B * (d->Cin / 8) * d->Tin * 16);
+        h.dyh_bytes = (unsigned)((int64_t)d->B * (d->Cout / 8) * d->Tout * 16);
+    }
     h.B = d->B; h.Cin = d->Cin; h.Cout = d->Cout; h.Cin_g = d->Cin / d->groups; h.Cout_g = d->Cout / d->groups;
     h.K = d->K; h.stride = d->stride; h.dil = d->dilation; h.pad = d->pad; h.Tin = d->Tin; h.Tout = d->Tout;
     h.Te = d->Tin * d->upsample; h.ups = d->upsample == 2 ? 1 : 0; h.relu = d->in_act == STEGAN_ACT_RELU;
@@ -478,7 +587,7 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     else { KT = 8; TM = 1; TN = 1; }
     h.NTG = ceil_div(h.K_eff, KT);
     const int BM = 64 * TM, BN = 64 * TN;
-    const bool xv = h.Tin % 4 == 0 && h.Tout % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
+    const bool xv = !img && h.Tin % 4 == 0 && h.Tout % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
                     !getenv("STEGAN_BF16_NO_XV") && !(h.ups && getenv("STEGAN_BF16_NO_XVUP"));
     const int xg = 4 << h.ups;                           // x slots per 16-byte item
     // chunk of the reduction: up to RMAX columns (LDS budget / halo share), whole batch elements when the rows are short
@@ -508,7 +617,10 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
         h.NGX = xv ? xslots / xg : xslots;
         h.ait = ceil_div((BM / 8) * h.NGA, 256);
         h.xit = ceil_div((BN / 8) * h.NGX, 256);
-        if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return false;
+        h.xslots = xslots;
+        if (img) {                                     // DMA pieces, not register items: <= WDI wave-instructions per wave
+            if (ceil_div((BM / 8) * ceil_div(h.R, 64), 4) > WDI || ceil_div((BN / 8) * ceil_div(xslots, 64), 4) > WDI) return false;
+        } else if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return false;
         lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
         return lds <= 160 * 1024;
     };
@@ -584,4 +696,9 @@ extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float
     }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                          float* workspace, int64_t workspace_floats, void* stream) {
+    return stegan_conv1d_bwd_weight_hx(d, x, nullptr, dy, nullptr, dw, db, workspace, workspace_floats, stream);
 }

@@ -5,8 +5,11 @@ namespace {
 
 // add != nullptr: a second gradient of the same tensor (the feature-matching term of a discriminator feature map, known
 // since the forward pass) is summed in here instead of by a separate elementwise kernel in front of this one
+// out_h != nullptr: the result is also written as a bf16 activation image [B][C / 8][T][8] (C % 8 == 0, T % 4 == 0: a
+// thread's four values lie in one row) for the conv kernels that consume this gradient next
 __device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const float* __restrict__ add,
-                                             const float* __restrict__ y, float* __restrict__ out, long n, int act) {
+                                             const float* __restrict__ y, float* __restrict__ out, long n, int act,
+                                             unsigned short* __restrict__ out_h = nullptr, int Cc = 0, int T = 0) {
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     const long stride = (long)gridDim.x * 1024;
     for (; i < n; i += stride) {
@@ -26,6 +29,12 @@ __device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const
                 d.z *= 1.f - v.z * v.z; d.w *= 1.f - v.w * v.w;
             }
             *reinterpret_cast<float4*>(out + i) = d;
+            if (out_h) {
+                const long r = i / T;
+                const int t = (int)(i - r * T), b = (int)(r / Cc), c = (int)(r - (long)b * Cc);
+                img_store(out_h, Cc >> 3, T, b, c, t, d.x); img_store(out_h, Cc >> 3, T, b, c, t + 1, d.y);
+                img_store(out_h, Cc >> 3, T, b, c, t + 2, d.z); img_store(out_h, Cc >> 3, T, b, c, t + 3, d.w);
+            }
         } else {
             for (long j = i; j < n; ++j) {
                 const float v = y[j];
@@ -37,42 +46,57 @@ __device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ add,
-                                                      const float* __restrict__ y, float* __restrict__ out, long n, int act) {
-    act_bwd_body(dy, add, y, out, n, act);
+                                                      const float* __restrict__ y, float* __restrict__ out, long n, int act,
+                                                      unsigned short* __restrict__ out_h, int Cc, int T) {
+    act_bwd_body(dy, add, y, out, n, act, out_h, Cc, T);
 }
 
 // the same for up to ACT_MULTI tensors in one launch (layer L of the five period discriminators): blockIdx.y = tensor
 constexpr int ACT_MULTI = 8;
-struct ActMulti { const float* dy[ACT_MULTI]; const float* add[ACT_MULTI]; const float* y[ACT_MULTI]; float* out[ACT_MULTI]; long n[ACT_MULTI]; };
+struct ActMulti {
+    const float* dy[ACT_MULTI]; const float* add[ACT_MULTI]; const float* y[ACT_MULTI]; float* out[ACT_MULTI]; long n[ACT_MULTI];
+    unsigned short* out_h[ACT_MULTI]; int Cc[ACT_MULTI], T[ACT_MULTI];
+};
 
 __global__ __launch_bounds__(256) void act_bwd_multi_kernel(const ActMulti a, int act) {
     const int k = blockIdx.y;
-    act_bwd_body(a.dy[k], a.add[k], a.y[k], a.out[k], a.n[k], act);
+    act_bwd_body(a.dy[k], a.add[k], a.y[k], a.out[k], a.n[k], act, a.out_h[k], a.Cc[k], a.T[k]);
 }
 
 }  // namespace
 
-extern "C" int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
-                                  void* stream) {
+extern "C" int stegan_act_bwd_add_img(const float* dy, const float* add, const float* y, float* out, uint16_t* out_h,
+                                      int64_t n, int32_t C, int32_t T, int32_t act, void* stream) {
     STEGAN_CHECK_ARG(dy && y && out && n > 0);
+    if (out_h) STEGAN_CHECK_ARG(C > 0 && T > 0 && C % 8 == 0 && T % 4 == 0 && n % ((int64_t)C * T) == 0);
     STEGAN_CHECK_ARG(act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH || act == STEGAN_ACT_RELU);
     STEGAN_CHECK_ARG(((uintptr_t)dy | (uintptr_t)add | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
     long blocks = (n + 1023) / 1024;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, add, y, out, (long)n, act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dy, add, y, out, (long)n, act,
+                       out_h, C, T);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
 
-extern "C" int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
-                                        float* const* out, const int64_t* n, int32_t act, void* stream) {
+extern "C" int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float* out, int64_t n, int32_t act,
+                                  void* stream) {
+    return stegan_act_bwd_add_img(dy, add, y, out, nullptr, n, 0, 0, act, stream);
+}
+
+extern "C" int stegan_act_bwd_add_multi_img(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
+                                            float* const* out, uint16_t* const* out_h, const int64_t* n, const int32_t* Cs,
+                                            const int32_t* Ts, int32_t act, void* stream) {
     STEGAN_CHECK_ARG(m >= 1 && m <= ACT_MULTI && dy && y && out && n);
+    STEGAN_CHECK_ARG(!out_h || (Cs && Ts));
     STEGAN_CHECK_ARG(act == STEGAN_ACT_RELU || act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH);
     ActMulti a;
     long blocks = 1;
     for (int k = 0; k < m; ++k) {
         STEGAN_CHECK_ARG(dy[k] && y[k] && out[k] && n[k] > 0);
         a.dy[k] = dy[k]; a.add[k] = add ? add[k] : nullptr; a.y[k] = y[k]; a.out[k] = out[k]; a.n[k] = (long)n[k];
+        a.out_h[k] = out_h ? out_h[k] : nullptr; a.Cc[k] = out_h ? Cs[k] : 0; a.T[k] = out_h ? Ts[k] : 0;
+        if (a.out_h[k]) STEGAN_CHECK_ARG(a.Cc[k] > 0 && a.T[k] > 0 && a.Cc[k] % 8 == 0 && a.T[k] % 4 == 0 && n[k] % ((int64_t)a.Cc[k] * a.T[k]) == 0);
         STEGAN_CHECK_ARG(((uintptr_t)a.dy[k] | (uintptr_t)a.add[k] | (uintptr_t)a.y[k] | (uintptr_t)a.out[k]) % 16 == 0);
         const long b = ((long)n[k] + 1023) / 1024;
         if (b > blocks) blocks = b;
@@ -81,6 +105,11 @@ extern "C" int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const
     hipLaunchKernelGGL(act_bwd_multi_kernel, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, (hipStream_t)stream, a, act);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
+                                        float* const* out, const int64_t* n, int32_t act, void* stream) {
+    return stegan_act_bwd_add_multi_img(m, dy, add, y, out, nullptr, n, nullptr, nullptr, act, stream);
 }
 
 extern "C" int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream) {

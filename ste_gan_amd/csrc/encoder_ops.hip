@@ -7,9 +7,10 @@
 namespace {
 
 // qkv: (B, 3*C, T), channel = which*C + h*A + a.   emb: (H, 2R-1, A).   P out: (B,H,T,T).  O out: (B, C, T)
+// O_h / dqkv_h (nullable): the output also as a bf16 activation image [B][C / 8][T][8] for the 1 x 1 conv behind it
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
                                                        float* __restrict__ P, float* __restrict__ O, int H, int A,
-                                                       int T, int R, float inv_sqrt_d) {
+                                                       int T, int R, float inv_sqrt_d, unsigned short* __restrict__ O_h) {
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int Cm = H * A;
     const float* q = qkv + ((size_t)b * 3 * Cm + 0 * Cm + h * A) * T;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         float s = 0.f;
         for (int j = 0; j < T; ++j) s += Pb[i * T + j] * v[a * T + j];
         Ob[ai] = s;
+        if (O_h) img_store(O_h, Cm >> 3, T, b, h * A + a, i, s);
     }
 }
 
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
                                                        const float* __restrict__ P, const float* __restrict__ dO,
                                                        float* __restrict__ dS, float* __restrict__ dqkv, int H, int A,
-                                                       int T, int R, float inv_sqrt_d) {
+                                                       int T, int R, float inv_sqrt_d, unsigned short* __restrict__ dqkv_h) {
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int Cm = H * A;
     const size_t base = ((size_t)b * 3 * Cm + h * A) * T;
@@ -114,6 +116,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
         dv[ai] = sv;
         dk[ai] = sk * inv_sqrt_d;
         dq[ai] = sq;
+        if (dqkv_h) {
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, h * A + a, i, sq);
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, Cm + h * A + a, i, sk * inv_sqrt_d);
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, 2 * Cm + h * A + a, i, sv);
+        }
     }
 }
 
@@ -174,7 +181,7 @@ __device__ __forceinline__ void att_stage_many(float* const (&dst)[NA], const fl
 
 __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
                                                              float* __restrict__ P, float* __restrict__ O, int H, int A,
-                                                             int T, int R, float inv_sqrt_d) {
+                                                             int T, int R, float inv_sqrt_d, unsigned short* __restrict__ O_h) {
     extern __shared__ float sm[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int Cm = H * A, AT = A * T;
@@ -220,13 +227,14 @@ __global__ __launch_bounds__(256) void attn_fwd_small_kernel(const float* __rest
         float s = 0.f;
         for (int j = 0; j < T; ++j) s += Ps[i * T + j] * vs[a * T + j];
         Ob[ai] = s;
+        if (O_h) img_store(O_h, Cm >> 3, T, b, h * A + a, i, s);
     }
 }
 
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __restrict__ qkv, const float* __restrict__ emb,
                                                              const float* __restrict__ P, const float* __restrict__ dO,
                                                              float* __restrict__ dqkv, int H, int A, int T, int R,
-                                                             float inv_sqrt_d) {
+                                                             float inv_sqrt_d, unsigned short* __restrict__ dqkv_h) {
     extern __shared__ float sm[];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int Cm = H * A, AT = A * T;
@@ -272,6 +280,11 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
         dv[ai] = sv;
         dk[ai] = sk * inv_sqrt_d;
         dq[ai] = sq;
+        if (dqkv_h) {
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, h * A + a, i, sq);
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, Cm + h * A + a, i, sk * inv_sqrt_d);
+            img_store(dqkv_h, (3 * Cm) >> 3, T, b, 2 * Cm + h * A + a, i, sv);
+        }
     }
 }
 
@@ -279,7 +292,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const float* __rest
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ y, float* __restrict__ xhat,
-                                                     float* __restrict__ rstd, int B, int Cm, int T, float eps) {
+                                                     float* __restrict__ rstd, int B, int Cm, int T, float eps,
+                                                     unsigned short* __restrict__ y_h) {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= B * T) return;
     const int lane = threadIdx.x & 63;
@@ -299,7 +313,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     for (int c = lane; c < Cm; c += 64) {
         const float xh = (x[base + (size_t)c * T] + (r ? r[base + (size_t)c * T] : 0.f) - mean) * rs;
         if (xhat) xhat[base + (size_t)c * T] = xh;
-        y[base + (size_t)c * T] = xh * gamma[c] + beta[c];
+        const float yv = xh * gamma[c] + beta[c];
+        y[base + (size_t)c * T] = yv;
+        if (y_h) img_store(y_h, Cm >> 3, T, b, c, t, yv);
     }
     if (lane == 0 && rstd) rstd[col] = rs;
 }
@@ -307,7 +323,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // dz = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = gamma * dy     (z = x + r; dx = dr = dz)
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     float* __restrict__ dz, int B, int Cm, int T) {
+                                                     float* __restrict__ dz, int B, int Cm, int T,
+                                                     unsigned short* __restrict__ dz_h) {
     const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (col >= B * T) return;
     const int lane = threadIdx.x & 63;
@@ -324,7 +341,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const float rs = rstd[col];
     for (int c = lane; c < Cm; c += 64) {
         const float g = gamma[c] * dy[base + (size_t)c * T];
-        dz[base + (size_t)c * T] = rs * (g - s1 - xhat[base + (size_t)c * T] * s2);
+        const float dv_ = rs * (g - s1 - xhat[base + (size_t)c * T] * s2);
+        dz[base + (size_t)c * T] = dv_;
+        if (dz_h) img_store(dz_h, Cm >> 3, T, b, c, t, dv_);
     }
 }
 
@@ -354,7 +373,8 @@ __device__ __forceinline__ float ln_column_sum(float v, float* red, int tid, int
 __global__ __launch_bounds__(1024) void ln_fwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ y, float* __restrict__ xhat,
-                                                           float* __restrict__ rstd, int Cm, int T, int P, float eps) {
+                                                           float* __restrict__ rstd, int Cm, int T, int P, float eps,
+                                                           unsigned short* __restrict__ y_h) {
     extern __shared__ float red[];
     const int tid = threadIdx.x, nth = T * P, n = Cm * T;
     const size_t off = (size_t)blockIdx.x * n;
@@ -382,7 +402,9 @@ __global__ __launch_bounds__(1024) void ln_fwd_slab_kernel(const float* __restri
             const int c = c0 + e * P;
             const float xh = (z[e] - mean) * rs;
             if (xhat) xhat[off + i] = xh;
-            y[off + i] = xh * gamma[c] + beta[c];
+            const float yv = xh * gamma[c] + beta[c];
+            y[off + i] = yv;
+            if (y_h) img_store(y_h, Cm >> 3, T, blockIdx.x, c, tid % T, yv);
         }
     }
     if (tid < T && rstd) rstd[blockIdx.x * T + tid] = rs;
@@ -390,7 +412,8 @@ __global__ __launch_bounds__(1024) void ln_fwd_slab_kernel(const float* __restri
 
 __global__ __launch_bounds__(1024) void ln_bwd_slab_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           float* __restrict__ dz, int Cm, int T, int P) {
+                                                           float* __restrict__ dz, int Cm, int T, int P,
+                                                           unsigned short* __restrict__ dz_h) {
     extern __shared__ float red[];
     const int tid = threadIdx.x, nth = T * P, n = Cm * T;
     const size_t off = (size_t)blockIdx.x * n;
@@ -411,7 +434,11 @@ __global__ __launch_bounds__(1024) void ln_bwd_slab_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
         const int i = tid + e * nth;
-        if (i < n) dz[off + i] = rs * (g[e] - s1 - xh[e] * s2);
+        if (i < n) {
+            const float dv_ = rs * (g[e] - s1 - xh[e] * s2);
+            dz[off + i] = dv_;
+            if (dz_h) img_store(dz_h, Cm >> 3, T, blockIdx.x, c0 + e * P, tid % T, dv_);
+        }
     }
 }
 
@@ -428,18 +455,42 @@ inline int ln_slab_p(int Cm, int T) {
 
 }  // namespace
 
-extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B,
-                                           int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream) {
+extern "C" int stegan_relpos_attention_fwd_img(const float* qkv, const float* rel_emb, float* probs, float* out, uint16_t* out_h,
+                                               int32_t B, int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream) {
     STEGAN_CHECK_ARG(qkv && rel_emb && probs && out && B > 0 && H > 0 && A > 0 && T > 0 && max_rel > 0);
+    STEGAN_CHECK_ARG(!out_h || (H * A) % 8 == 0);
     const size_t lds_s = ((size_t)3 * A * T + (size_t)(2 * T - 1) * (A + 1) + (size_t)T * T) * sizeof(float);
     if (T <= ATT_TMAX && lds_s <= 64 * 1024) {
         hipLaunchKernelGGL(attn_fwd_small_kernel, dim3(B * H), dim3(256), lds_s, (hipStream_t)stream, qkv, rel_emb, probs, out, H,
-                           A, T, max_rel, 1.f / sqrtf((float)A));
+                           A, T, max_rel, 1.f / sqrtf((float)A), out_h);
         STEGAN_LAUNCH_CHECK();
         return STEGAN_OK;
     }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, out, H, A, T,
-                       max_rel, 1.f / sqrtf((float)A));
+                       max_rel, 1.f / sqrtf((float)A), out_h);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_emb, float* probs, float* out, int32_t B,
+                                           int32_t H, int32_t A, int32_t T, int32_t max_rel, void* stream) {
+    return stegan_relpos_attention_fwd_img(qkv, rel_emb, probs, out, nullptr, B, H, A, T, max_rel, stream);
+}
+
+extern "C" int stegan_relpos_attention_bwd_img(const float* qkv, const float* rel_emb, const float* probs, const float* dout,
+                                               float* workspace, float* dqkv, uint16_t* dqkv_h, int32_t B, int32_t H, int32_t A,
+                                               int32_t T, int32_t max_rel, void* stream) {
+    STEGAN_CHECK_ARG(qkv && rel_emb && probs && dout && workspace && dqkv && B > 0 && H > 0 && A > 0 && T > 0);
+    STEGAN_CHECK_ARG(!dqkv_h || (H * A) % 8 == 0);
+    const size_t lds_s = ((size_t)4 * A * T + (size_t)(2 * T - 1) * (A + 1) + (size_t)2 * T * T) * sizeof(float);
+    if (T <= ATT_TMAX && lds_s <= 64 * 1024) {
+        hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * H), dim3(256), lds_s, (hipStream_t)stream, qkv, rel_emb, probs, dout,
+                           dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A), dqkv_h);
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, dout,
+                       workspace, dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A), dqkv_h);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
@@ -447,16 +498,22 @@ extern "C" int stegan_relpos_attention_fwd(const float* qkv, const float* rel_em
 extern "C" int stegan_relpos_attention_bwd(const float* qkv, const float* rel_emb, const float* probs, const float* dout,
                                            float* workspace, float* dqkv, int32_t B, int32_t H, int32_t A, int32_t T,
                                            int32_t max_rel, void* stream) {
-    STEGAN_CHECK_ARG(qkv && rel_emb && probs && dout && workspace && dqkv && B > 0 && H > 0 && A > 0 && T > 0);
-    const size_t lds_s = ((size_t)4 * A * T + (size_t)(2 * T - 1) * (A + 1) + (size_t)2 * T * T) * sizeof(float);
-    if (T <= ATT_TMAX && lds_s <= 64 * 1024) {
-        hipLaunchKernelGGL(attn_bwd_small_kernel, dim3(B * H), dim3(256), lds_s, (hipStream_t)stream, qkv, rel_emb, probs, dout,
-                           dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A));
+    return stegan_relpos_attention_bwd_img(qkv, rel_emb, probs, dout, workspace, dqkv, nullptr, B, H, A, T, max_rel, stream);
+}
+
+extern "C" int stegan_add_layernorm_fwd_img(const float* x, const float* residual, const float* gamma, const float* beta,
+                                            float* y, uint16_t* y_h, float* xhat, float* rstd, int32_t B, int32_t C, int32_t T,
+                                            float eps, void* stream) {
+    STEGAN_CHECK_ARG(x && gamma && beta && y && B > 0 && C > 0 && T > 0);
+    STEGAN_CHECK_ARG(!y_h || C % 8 == 0);
+    if (const int P = ln_slab_p(C, T)) {
+        hipLaunchKernelGGL(ln_fwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, x,
+                           residual, gamma, beta, y, xhat, rstd, C, T, P, eps, y_h);
         STEGAN_LAUNCH_CHECK();
         return STEGAN_OK;
     }
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, qkv, rel_emb, probs, dout,
-                       workspace, dqkv, H, A, T, max_rel, 1.f / sqrtf((float)A));
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
+                       beta, y, xhat, rstd, B, C, T, eps, y_h);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
@@ -464,30 +521,26 @@ extern "C" int stegan_relpos_attention_bwd(const float* qkv, const float* rel_em
 extern "C" int stegan_add_layernorm_fwd(const float* x, const float* residual, const float* gamma, const float* beta,
                                         float* y, float* xhat, float* rstd, int32_t B, int32_t C, int32_t T, float eps,
                                         void* stream) {
-    STEGAN_CHECK_ARG(x && gamma && beta && y && B > 0 && C > 0 && T > 0);
+    return stegan_add_layernorm_fwd_img(x, residual, gamma, beta, y, nullptr, xhat, rstd, B, C, T, eps, stream);
+}
+
+extern "C" int stegan_add_layernorm_bwd_img(const float* dy, const float* xhat, const float* rstd, const float* gamma,
+                                            float* dz, uint16_t* dz_h, int32_t B, int32_t C, int32_t T, void* stream) {
+    STEGAN_CHECK_ARG(dy && xhat && rstd && gamma && dz && B > 0 && C > 0 && T > 0);
+    STEGAN_CHECK_ARG(!dz_h || C % 8 == 0);
     if (const int P = ln_slab_p(C, T)) {
-        hipLaunchKernelGGL(ln_fwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, x,
-                           residual, gamma, beta, y, xhat, rstd, C, T, P, eps);
+        hipLaunchKernelGGL(ln_bwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, dy,
+                           xhat, rstd, gamma, dz, C, T, P, dz_h);
         STEGAN_LAUNCH_CHECK();
         return STEGAN_OK;
     }
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, x, residual, gamma,
-                       beta, y, xhat, rstd, B, C, T, eps);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma,
+                       dz, B, C, T, dz_h);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
 
 extern "C" int stegan_add_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma,
                                         float* dz, int32_t B, int32_t C, int32_t T, void* stream) {
-    STEGAN_CHECK_ARG(dy && xhat && rstd && gamma && dz && B > 0 && C > 0 && T > 0);
-    if (const int P = ln_slab_p(C, T)) {
-        hipLaunchKernelGGL(ln_bwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, dy,
-                           xhat, rstd, gamma, dz, C, T, P);
-        STEGAN_LAUNCH_CHECK();
-        return STEGAN_OK;
-    }
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ceil_div(B * T, 4)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd, gamma,
-                       dz, B, C, T);
-    STEGAN_LAUNCH_CHECK();
-    return STEGAN_OK;
+    return stegan_add_layernorm_bwd_img(dy, xhat, rstd, gamma, dz, nullptr, B, C, T, stream);
 }

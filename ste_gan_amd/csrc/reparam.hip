@@ -103,13 +103,20 @@ __global__ __launch_bounds__(256) void wn_backward1_kernel(const float* v, const
     wn_backward_row(v, g, dw, dv, dg, row, cols);
 }
 
+// dx_h != nullptr: dx also as a bf16 activation image [B][C / 8][T][8] (C % 8 == 0)
 __global__ __launch_bounds__(256) void fold_upsample2_kernel(const float* __restrict__ dxe, float* __restrict__ dx,
-                                                             long total) {
+                                                             long total, unsigned short* __restrict__ dx_h, int Cc, int T) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     const long stride = (long)gridDim.x * 256;
     for (; i < total; i += stride) {
         const float2 v = reinterpret_cast<const float2*>(dxe)[i];
-        dx[i] = v.x + v.y;
+        const float r = v.x + v.y;
+        dx[i] = r;
+        if (dx_h) {
+            const long row = i / T;
+            const int t = (int)(i - row * T), b = (int)(row / Cc), c = (int)(row - (long)b * Cc);
+            img_store(dx_h, Cc >> 3, T, b, c, t, r);
+        }
     }
 }
 
@@ -150,14 +157,20 @@ extern "C" int stegan_wn_backward1(const float* v, const float* g, const float* 
     return STEGAN_OK;
 }
 
-extern "C" int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream) {
+extern "C" int stegan_fold_upsample2_img(const float* dxe, float* dx, uint16_t* dx_h, int64_t rows, int32_t C, int32_t T,
+                                         void* stream) {
     STEGAN_CHECK_ARG(dxe && dx && rows > 0 && T > 0);
+    if (dx_h) STEGAN_CHECK_ARG(C > 0 && C % 8 == 0 && rows % C == 0);
     const long total = (long)rows * T;   // T = folded (output) length; dxe rows have 2T floats, 8-byte aligned pairs
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(fold_upsample2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxe, dx, total);
+    hipLaunchKernelGGL(fold_upsample2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dxe, dx, total, dx_h, C, T);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream) {
+    return stegan_fold_upsample2_img(dxe, dx, nullptr, rows, 0, T, stream);
 }
 
 extern "C" int stegan_abi_version(void) { return STEGAN_ABI_VERSION; }

@@ -200,6 +200,7 @@ def _bf16_of(w: Optional[Tensor]) -> Optional[Tensor]:
 # (the producer waves' instruction stream was what bounded the bf16 kernels: DESIGN.md section 6).  The fp32 tensor stays
 # the tensor of record (residuals, masks, losses, parity); an image is only ever read by a conv kernel.
 IMAGES = os.environ.get("STEGAN_BF16_IMAGES", "1") != "0"
+IMG_STATS: Optional[dict] = None      # diagnostics (scripts/image_coverage.py): (mode, had image) -> [launches, shapes]
 
 
 def _image_of(t: Optional[Tensor], channels: int, length: int) -> Optional[Tensor]:
@@ -310,6 +311,8 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
     if wfh is not None:
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
         xh = _image_of(x, cfg.cin, tin)
+        if IMG_STATS is not None:
+            IMG_STATS.setdefault((0, xh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
         yh = None if cfg.out_btc else _new_image(y, cfg.cout, cfg.groups, tout)
         rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_hx(C.byref(d), _p(x), _p(xh), _p(wfh), _p(scale), _p(bias),
                                                                   _p(residual), _p(y), _p(yh), _p(ws), ws.numel(), _stream()),
@@ -353,6 +356,8 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
         dyh = _image_of(dy, cfg.cout, tout)
+        if IMG_STATS is not None:
+            IMG_STATS.setdefault((1, dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
         dxh = _new_image(dx, cfg.cin, cfg.groups, tin * cfg.upsample) if cfg.upsample == 1 else None
         rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_hx(C.byref(d), _p(dy), _p(dyh), _p(wbh), _p(us),
                                                                        _p(mask_src), _p(add_src), _p(dx), _p(dxh), _p(ws),
@@ -390,10 +395,13 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
             return
     ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
     if COMPUTE_DTYPE == "bf16":
-        rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_h(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
-                                                                        ws.numel(), _stream()), "bf16")
+        xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
+        if IMG_STATS is not None:
+            IMG_STATS.setdefault((2, xh is not None and dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
+        rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_hx(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw),
+                                                                         _p(db), _p(ws), ws.numel(), _stream()), "bf16")
         if rc != 1:
-            check(rc, "stegan_conv1d_bwd_weight_h")
+            check(rc, "stegan_conv1d_bwd_weight_hx")
             return
     check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                                                       ws.numel(), _stream())),
@@ -491,7 +499,11 @@ def wn_scale(v: Tensor, g: Tensor) -> Tensor:
 def fold_upsample2(dxe: Tensor) -> Tensor:
     B, Cc, Te = dxe.shape
     dx = torch.empty((B, Cc, Te // 2), device=dxe.device, dtype=torch.float32)
-    check(_lib.lib().stegan_fold_upsample2(_p(dxe), _p(dx), B * Cc, Te // 2, _stream()), "stegan_fold_upsample2")
+    dxh = _new_image(dx, Cc, 1, Te // 2)
+    check(_lib.lib().stegan_fold_upsample2_img(_p(dxe), _p(dx), _p(dxh), B * Cc, Cc, Te // 2, _stream()),
+          "stegan_fold_upsample2_img")
+    if dxh is not None:
+        dx.h = dxh
     return dx
 
 
@@ -719,8 +731,15 @@ class _WNConvMultiFn(torch.autograd.Function):
                 raise RuntimeError("ste_gan_amd.act_bwd: folded gradient does not match the activation gradient")
             outs = [torch.empty_like(g) for g in gs]
             numels = (C.c_int64 * n)(*[g.numel() for g in gs])
-            check(_lib.lib().stegan_act_bwd_add_multi(n, _ptr_array(gs), _ptr_array(adds), _ptr_array(ys), _ptr_array(outs),
-                                                      numels, acts.pop(), _stream()), "stegan_act_bwd_add_multi")
+            ohs = [_new_image(o, o.shape[1], 1, o.shape[2]) if (o.dim() == 3 and o.shape[2] % 4 == 0) else None for o in outs]
+            check(_lib.lib().stegan_act_bwd_add_multi_img(
+                n, _ptr_array(gs), _ptr_array(adds), _ptr_array(ys), _ptr_array(outs), _ptr_array(ohs), numels,
+                (C.c_int32 * n)(*[o.shape[1] if o.dim() == 3 else 0 for o in outs]),
+                (C.c_int32 * n)(*[o.shape[2] if o.dim() == 3 else 0 for o in outs]), acts.pop(), _stream()),
+                "stegan_act_bwd_add_multi_img")
+            for o, oh in zip(outs, ohs):
+                if oh is not None:
+                    o.h = oh
             gs = outs
         else:
             gs = [act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g
@@ -786,7 +805,14 @@ def act_bwd(dy: Tensor, y: Tensor, act: int, add: Optional[Tensor] = None) -> Te
     out = torch.empty_like(dy)
     if add is not None and (add.numel() != dy.numel() or not dy.is_contiguous()):
         raise RuntimeError("ste_gan_amd.act_bwd: folded gradient does not match the activation gradient")
-    check(_lib.lib().stegan_act_bwd_add(_p(dy), _p(add), _p(y), _p(out), dy.numel(), act, _stream()), "stegan_act_bwd_add")
+    outh = None
+    if dy.dim() == 3 and dy.is_contiguous() and dy.shape[2] % 4 == 0:
+        outh = _new_image(out, dy.shape[1], 1, dy.shape[2])
+    Cc, T = (dy.shape[1], dy.shape[2]) if outh is not None else (0, 0)
+    check(_lib.lib().stegan_act_bwd_add_img(_p(dy), _p(add), _p(y), _p(out), _p(outh), dy.numel(), Cc, T, act, _stream()),
+          "stegan_act_bwd_add_img")
+    if outh is not None:
+        out.h = outh
     return out
 
 
@@ -1474,8 +1500,11 @@ class _RelPosAttnFn(torch.autograd.Function):
         A = Cm // H
         probs = torch.empty((B, H, T, T), device=qkv.device, dtype=torch.float32)
         out = torch.empty((B, Cm, T), device=qkv.device, dtype=torch.float32)
-        check(_lib.lib().stegan_relpos_attention_fwd(_p(qkv), _p(rel_emb), _p(probs), _p(out), B, H, A, T, max_rel,
-                                                     _stream()), "stegan_relpos_attention_fwd")
+        outh = _new_image(out, Cm, 1, T)
+        check(_lib.lib().stegan_relpos_attention_fwd_img(_p(qkv), _p(rel_emb), _p(probs), _p(out), _p(outh), B, H, A, T, max_rel,
+                                                         _stream()), "stegan_relpos_attention_fwd_img")
+        if outh is not None:
+            out.h = outh
         ctx.dims = (B, H, A, T, max_rel)
         ctx.save_for_backward(qkv, rel_emb, probs)
         return out
@@ -1487,8 +1516,11 @@ class _RelPosAttnFn(torch.autograd.Function):
         dout = _gpu_f32(dout, "grad_output")
         ws = torch.empty_like(probs)
         dqkv = torch.empty_like(qkv)
-        check(_lib.lib().stegan_relpos_attention_bwd(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(ws), _p(dqkv), B, H, A,
-                                                     T, max_rel, _stream()), "stegan_relpos_attention_bwd")
+        dqkvh = _new_image(dqkv, 3 * H * A, 1, T)
+        check(_lib.lib().stegan_relpos_attention_bwd_img(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(ws), _p(dqkv), _p(dqkvh),
+                                                         B, H, A, T, max_rel, _stream()), "stegan_relpos_attention_bwd_img")
+        if dqkvh is not None:
+            dqkv.h = dqkvh
         return dqkv, None, None, None
 
 
@@ -1506,8 +1538,11 @@ class _AddLayerNormFn(torch.autograd.Function):
         y = torch.empty_like(x)
         xhat = torch.empty_like(x)
         rstd = torch.empty(B * T, device=x.device, dtype=torch.float32)
-        check(_lib.lib().stegan_add_layernorm_fwd(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(xhat), _p(rstd), B,
-                                                  Cm, T, eps, _stream()), "stegan_add_layernorm_fwd")
+        yh = _new_image(y, Cm, 1, T)
+        check(_lib.lib().stegan_add_layernorm_fwd_img(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(yh), _p(xhat), _p(rstd),
+                                                      B, Cm, T, eps, _stream()), "stegan_add_layernorm_fwd_img")
+        if yh is not None:
+            y.h = yh
         ctx.save_for_backward(xhat, rstd, gamma)
         return y
 
@@ -1517,8 +1552,11 @@ class _AddLayerNormFn(torch.autograd.Function):
         dy = _gpu_f32(dy, "grad_output")
         B, Cm, T = dy.shape
         dz = torch.empty_like(dy)
-        check(_lib.lib().stegan_add_layernorm_bwd(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dz), B, Cm, T, _stream()),
-              "stegan_add_layernorm_bwd")
+        dzh = _new_image(dz, Cm, 1, T)
+        check(_lib.lib().stegan_add_layernorm_bwd_img(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dz), _p(dzh), B, Cm, T, _stream()),
+              "stegan_add_layernorm_bwd_img")
+        if dzh is not None:
+            dz.h = dzh
         hand = ctx.hand[1] if ctx.hand is not None and ctx.hand[0] == PARK_DX else None
         if hand is not None and not hand.taken and ctx.needs_input_grad[0]:
             hand.parked = dz                       # the conv that also reads x adds it inside its input-gradient kernel

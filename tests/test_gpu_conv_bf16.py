@@ -129,7 +129,13 @@ def test_conv_bf16_ragged_rows_with_16_byte_loads(cfg, monkeypatch):
 
 
 @pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
-def test_conv_bf16_bwd_weight(cfg):
+def test_conv_bf16_bwd_weight_with_activation_images(cfg):
+    """Both operands handed over as bf16 images (LDS-DMA staging, ReLU at the operand read): the same parity bar."""
+    test_conv_bf16_bwd_weight(cfg, images=True)
+
+
+@pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
+def test_conv_bf16_bwd_weight(cfg, images=False):
     """dW (accumulated into a non-zero buffer) and db of stegan_conv1d_bwd_weight_h against fp64 on bf16-rounded operands."""
     from ste_gan_amd import ops
     B, Cin, Cout, K, s, d, p, g, up, relu, Tin = cfg
@@ -154,7 +160,10 @@ def test_conv_bf16_bwd_weight(cfg):
     db = torch.full((Cout,), -1.0, device="cuda")
     ops.set_compute_dtype("bf16")
     try:
-        ops.conv1d_bwd_weight(x.cuda(), dy.cuda(), c, dw, db)
+        xg, dyg = x.cuda(), dy.cuda()
+        if images:
+            xg.h, dyg.h = make_image(xg), make_image(dyg)
+        ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
         kern = ops.LAST_CONV_KERNEL
     finally:
         ops.set_compute_dtype("f32")

@@ -47,8 +47,17 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / (3 * n) * 1e3
 
 
+def make_image(t):
+    B, C, T = t.shape
+    CB = (C + 7) // 8
+    full = torch.zeros(B, CB * 8, T, device=t.device, dtype=t.dtype)
+    full[:, :C] = t
+    return full.view(B, CB, 8, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+
+
 rows = []
 only_mode = os.environ.get("LAYER_MODE")
+with_images = os.environ.get("LAYER_IMAGES", "1") != "0"
 for shape, (count, nominal, name) in shapes.items():
     mode, B, Cin, Cout, K, s, d, g, up, Tin, Tout, pad, in_act, out_act = shape
     if only_mode is not None and int(only_mode) != mode:
@@ -57,6 +66,10 @@ for shape, (count, nominal, name) in shapes.items():
     x = torch.randn(B, Cin, Tin, device=dev); w = torch.randn(Cout, Cin // g, K, device=dev) * 0.05
     sc = torch.rand(Cout, device=dev) + 0.5; bias = torch.randn(Cout, device=dev)
     dy = torch.randn(B, Cout, Tout, device=dev)
+    if with_images and Cin >= 16:
+        x.h = make_image(x)
+    if with_images and Cout >= 16:
+        dy.h = make_image(dy)
     wf, wb = ops.prep_weights(w, c, None, sc)
     try:
         if mode == 0:

@@ -68,6 +68,7 @@ struct HP {
     int xh_cb = 0;                // channel blocks per batch element of the image = ceil(Csrc / 8)
     unsigned xh_bytes = 0;
     int xnit = 0;                   // X DMA wave-instructions per producer wave and chunk = ceil(NCB * XROW / 256)
+    int nstage = 2;               // image path: LDS stages of the chunk ring (nstage - 1 chunks in flight)
 };
 
 constexpr int HXD_MAX = 8;     // X DMA wave-instructions per producer wave and chunk (8 x 256 pieces of 16 bytes = 32 KiB)
@@ -90,6 +91,20 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
 #define HB_DBG(bit_) false
 #endif
 
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the instruction takes an immediate, so one case per value.  Waiting for
+// FEWER outstanding operations than asked is always safe (it only waits longer): counts above the table wait for 36.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define WV_CASE(k_) case k_: asm volatile("s_waitcnt vmcnt(" #k_ ")" ::: "memory"); break;
+    switch (n) {
+        WV_CASE(0) WV_CASE(1) WV_CASE(2) WV_CASE(3) WV_CASE(4) WV_CASE(5) WV_CASE(6) WV_CASE(7) WV_CASE(8) WV_CASE(9)
+        WV_CASE(10) WV_CASE(11) WV_CASE(12) WV_CASE(13) WV_CASE(14) WV_CASE(15) WV_CASE(16) WV_CASE(17) WV_CASE(18)
+        WV_CASE(19) WV_CASE(20) WV_CASE(21) WV_CASE(22) WV_CASE(23) WV_CASE(24) WV_CASE(25) WV_CASE(26) WV_CASE(27)
+        WV_CASE(28) WV_CASE(29) WV_CASE(30) WV_CASE(31) WV_CASE(32) WV_CASE(33) WV_CASE(34) WV_CASE(35)
+        default: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
+    }
+#undef WV_CASE
+}
+
 template <int TM, int TN, int LOGNCB, bool XV, bool XH = false>
 __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x, const unsigned bid_y, const unsigned bid_z) {
     static_assert(!(XV && XH), "the image path has no use for the 16-byte fp32 loads");
@@ -111,8 +126,11 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int wm = wave >> 1, wn = wave & 1;
 #ifdef STEGAN_STAMPS          // diagnostic builds only (scripts/bf16_stamps.py): 8 s_memtime stamps per block
 #define HSTAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+// producer wave 0 (thread 256): a second table of 8 stamps per block, 1 Mi entries behind the consumers' table
+#define PSTAMP(i_) if (p.stamps && threadIdx.x == 256) p.stamps[(1u << 19) + (size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
 #else
 #define HSTAMP(i_)
+#define PSTAMP(i_)
 #endif
     HSTAMP(0)
     // one clustered batch of kernarg loads (left alone, hipcc sinks each s_load next to its first use: a string of
@@ -172,7 +190,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int c_end = min(nchunks, c_begin + cps);
     const char* wt_g = (const char*)h.wh + (size_t)g * (p.K + 1) * h.Mpad * h.Cpad * 2;
     const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = NCB * p.XROW * 16;
-    char* const Xbufs = smem + 2 * wbuf;                           // W ring of 2 | X ring of 2
+    const int NS = XH ? h.nstage : 2;                              // stages of the chunk ring
+    char* const Xbufs = smem + NS * wbuf;                          // W ring | X ring
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)h.src_bytes, 0x00020000);
     const bool relu = p.in_relu != 0;
     const int row_bytes = p.Tsrc * 4;
@@ -191,11 +210,14 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
 #pragma unroll
     for (int it = 0; it < HW_MAX; ++it) {
-        const int piece = it * 256 + tid;
-        const int m = piece & (BM - 1), r = piece / BM;
-        const int cb = r & (NCB - 1), tap = r >> LOGNCB;
-        const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;            // dead tap of an odd pair: the zero plane
-        w_off[it] = (it < h.wit && tap < ntapsW) ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
+        w_off[it] = 0;
+        if (it < h.wit) {                                    // (items past the tile: not computed -- index setup is on the
+            const int piece = it * 256 + tid;                //  path to the first DMA)
+            const int m = piece & (BM - 1), r = piece / BM;
+            const int cb = r & (NCB - 1), tap = r >> LOGNCB;
+            const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;        // dead tap of an odd pair: the zero plane
+            w_off[it] = tap < ntapsW ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
+        }
     }
 #define HB_DMA_W(c_, buf_)                                                                                      \
     {                                                                                                           \
@@ -220,20 +242,26 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         const auto rsrc_h = __builtin_amdgcn_make_buffer_rsrc((void*)h.xh, 0, (int)h.xh_bytes, 0x00020000);
         const int npieces = NCB * p.XROW;
         const int cbg0 = g * (p.C2_g >> 3);                       // first channel block of the group inside the image
+        const int nch = c_end - c_begin;
+        // the first chunk's weights go out BEFORE the X offsets are computed: their round trip runs under that arithmetic
+        if (nch > 0) HB_DMA_W(c_begin, 0)
         unsigned xd_voff[HXD_MAX];
         int xd_cb[HXD_MAX];
 #pragma unroll
         for (int it = 0; it < HXD_MAX; ++it) {
-            const int piece = it * 256 + tid;
-            const int cb = (int)fd_div((uint32_t)piece, p.fdXROW), slot = piece - cb * p.XROW;
-            const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
-            const int b = b_lo + sg;
-            const int q = (sg == 0 ? qbase0 : qbaseN) + sl;
-            const int qs = p.mode == 0 ? (q >> p.ups) : q;
-            xd_cb[it] = piece < npieces ? cb : -1;                // -1: lane switched off
+            xd_cb[it] = -1;                                       // -1: lane switched off
             xd_voff[it] = OOB;
-            if (it < h.xnit && piece < npieces && sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
-                xd_voff[it] = (unsigned)(((b * h.xh_cb + cbg0 + cb) * p.Tsrc + qs) * 16);
+            if (it < h.xnit) {
+                const int piece = it * 256 + tid;
+                const int cb = (int)fd_div((uint32_t)piece, p.fdXROW), slot = piece - cb * p.XROW;
+                const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
+                const int b = b_lo + sg;
+                const int q = (sg == 0 ? qbase0 : qbaseN) + sl;
+                const int qs = p.mode == 0 ? (q >> p.ups) : q;
+                if (piece < npieces) xd_cb[it] = cb;
+                if (piece < npieces && sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
+                    xd_voff[it] = (unsigned)(((b * h.xh_cb + cbg0 + cb) * p.Tsrc + qs) * 16);
+            }
         }
         const int chunk_x = NCB * p.Tsrc * 16;                    // bytes between the image planes of neighbouring chunks
 #define HB_DMA_X(c_, buf_)                                                                                      \
@@ -248,17 +276,40 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                 }                                                                                               \
             }                                                                                                   \
         }
-        if (c_begin < c_end) {
-            HB_DMA_X(c_begin, 0)
-            HB_DMA_W(c_begin, 0)
+        // Ring of NS stages, NS - 1 chunks in flight.  An iteration of a small tile is 128-768 cycles of MFMA against a
+        // DMA round trip of ~1 000 (measured with the stamps: with ONE chunk in flight -- two buffers, the barrier's
+        // vmcnt(0) -- every iteration of a 64 x 64 x 64-channel chunk took 1 030 cycles for 128 cycles of MFMA).  So the
+        // producers wait with a COUNTED vmcnt -- until chunk c + 1 has landed, leaving the younger chunks in flight --
+        // and meet the consumers at a raw s_barrier (__syncthreads() would add vmcnt(0) while a DMA is pending).  A wave
+        // issues the same number of DMA instructions for every chunk (ipc), so the count is (chunks left in flight) x ipc.
+        int ipc = 0;
+#pragma unroll
+        for (int it = 0; it < HXD_MAX; ++it) ipc += (it < h.xnit && (it * 256 + wave * 64) < npieces) ? 1 : 0;
+#pragma unroll
+        for (int it = 0; it < HW_MAX; ++it) ipc += (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB) ? 1 : 0;
+        PSTAMP(0)                                                    // setup done
+        for (int j = 0; j < NS - 1 && j < nch; ++j) {               // prologue: chunks 0 .. NS - 2 (chunk 0's weights are out)
+            if (j > 0) HB_DMA_W(c_begin + j, j)
+            HB_DMA_X(c_begin + j, j)
         }
-        for (int c = c_begin; c < c_end; ++c) {
-            const int cur = (c - c_begin) & 1;
-            block_sync();                // all 8 waves: chunk c has landed (the barrier's vmcnt(0)); buffer cur ^ 1 is free
-            if (c + 1 < c_end) {
-                HB_DMA_X(c + 1, cur ^ 1)
-                HB_DMA_W(c + 1, cur ^ 1)
+        PSTAMP(1)                                                    // prologue issued
+        int stage_in = (NS - 1) % NS;                                // stage the next issued chunk goes to
+        for (int j = 0; j < nch; ++j) {
+            // chunk j must have landed before barrier j: the chunks issued after it may stay in flight
+            const int younger = min(NS - 1, nch - j) - 1;            // chunks j + 1 .. issued so far
+            wait_vmcnt(younger * ipc);
+            if (j == 0) { PSTAMP(2) }                                // chunk 0 landed
+            if (j == 5) { PSTAMP(5) }                                // chunk 5 landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // barrier j: chunk j is visible; stage of chunk j - 1 is free
+            asm volatile("" ::: "memory");
+            if (j == 4) { PSTAMP(3) }                                // past barrier 4
+            if (j + NS - 1 < nch) {
+                HB_DMA_W(c_begin + j + NS - 1, stage_in)
+                HB_DMA_X(c_begin + j + NS - 1, stage_in)
+                stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
             }
+            if (j == 4) { PSTAMP(4) }                                // iteration 4's DMAs issued
         }
         return;
 #undef HB_DMA_X
@@ -419,8 +470,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
 #define HB_COMPUTE(c_)                                                                                          \
     if (!HB_DBG(4)) {                                                                                           \
-        const char* Wcur = smem + (((c_) - c_begin) & 1) * wbuf;                                                \
-        const char* Xcur = Xbufs + (((c_) - c_begin) & 1) * xbuf;                                               \
+        const char* Wcur = smem + stage_c * wbuf;                                                               \
+        const char* Xcur = Xbufs + stage_c * xbuf;                                                              \
         bf16x8 aA[TM], bA[TN], aB[TM], bB[TN];                                                                  \
         if (S > 0) HB_LOAD(aA, bA, 0)                                                                           \
         int s = 0;                                                                                              \
@@ -435,8 +486,15 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #ifndef STEGAN_STAMPS_ITER
     HSTAMP(2)
 #endif
+    int stage_c = 0;                                              // ring stage of the chunk being multiplied
     for (int c = c_begin; c < c_end; ++c) {
-        block_sync();
+        if constexpr (XH) {                                       // (the producers' side of this barrier: counted vmcnt, above)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            block_sync();
+        }
 #ifdef STEGAN_STAMPS_ITER                   // diagnostic: tops of iterations 1, 5, 9, 13, 17, 21 in stamps 1..6
         if (c == c_begin + 1) { HSTAMP(1) }
         if (c == c_begin + 5) { HSTAMP(2) }
@@ -449,6 +507,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         if (c == c_begin + 5) { HSTAMP(4) }
 #endif
         HB_COMPUTE(c)
+        stage_c = stage_c + 1 == NS ? 0 : stage_c + 1;
     }
 #undef HB_COMPUTE
 #undef HB_MFMA
@@ -610,6 +669,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     }
 #endif
 #undef HSTAMP
+#undef PSTAMP
 }
 
 // Two 512-thread blocks per CU need 4 waves per SIMD: 128 VGPRs.  Left to itself hipcc gives the 4-byte-load variants
@@ -965,6 +1025,26 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     h.xnit = xh ? ceil_div(NCB * gm.XROW, 256) : 0;
     if (p.out_h && (p.out_btc || p.Cdst % 8 != 0 || p.M_g % 8 != 0)) p.out_h = nullptr;      // whole 8-channel blocks only
     p.out_cb = p.Cdst / 8;
+    h.nstage = 2;
+    if (xh) {
+        // stages of the chunk ring.  TWO by default: with 3 / 4 stages (two / three chunks in flight, counted vmcnt) every
+        // layer got SLOWER -- the train step 6.90 / 7.49 / 7.75 ms with 2 / 3 / 4 stages -- because a chunk is not waiting
+        // for its own round trip: the CU's fetch path from L2 delivers ~17 bytes per cycle whatever is queued (producer
+        // stamps: a wave-instruction of 1 KiB takes ~120-170 cycles to issue once two chunks are outstanding; an iteration
+        // is issue 1 000-1 250 + landing 500 cycles for 16-33 KiB), so more chunks in flight only land later
+        // (STEGAN_BF16_STAGES: experiments)
+        static const char* env_st = getenv("STEGAN_BF16_STAGES");
+        const size_t stage = gm.lds / 2;
+        const int per_block = ceil_div(ceil_div(p.C2_g, CCH), splits);
+        int ns = 2;
+        if (env_st) ns = atoi(env_st);
+        if (ns > 4) ns = 4;
+        if (ns > per_block) ns = per_block;
+        if (ns < 2) ns = 2;
+        while (ns > 2 && (size_t)ns * stage > 160 * 1024) --ns;
+        h.nstage = ns;
+        gm.lds = (size_t)ns * stage;
+    }
     if (p.out_h && gm.lds < 8192) gm.lds = 8192;                  // the image epilogue's scratch (4 waves x 2 KiB)
     { const char* ed = getenv("STEGAN_BF16_DBG"); h.dbg = ed ? atoi(ed) : 0; }
     {

@@ -582,7 +582,13 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
     // tile: 128 x 64 x 3 taps for the dense k = 3 layers; single taps take 128 x 128; more taps 64 x 64 x (5 | 8)
     int TM, TN, KT;
     if (h.K_eff == 1) { KT = 1; TM = h.Cout_g >= 96 ? 2 : 1; TN = h.Cin_g >= 96 ? 2 : 1; }
-    else if (h.K_eff <= 3) { KT = 3; TM = h.Cout_g >= 96 ? 2 : 1; TN = 1; }
+    else if (h.K_eff <= 3) {
+        // (128 x 128 x 3 taps -- more MFMA work per staged byte: 32 KiB per 64-column chunk for 1 536 MFMA cycles per wave
+        // against 24 KiB for 768 -- was built for the image path and measured SLOWER: 245 registers, 41.7 vs 34 us on the
+        // 384 -> 384 layers, train step 7.19 vs 6.98 ms; opt-in for experiments: STEGAN_BF16_WGRAD_223=1)
+        static const bool use_223 = getenv("STEGAN_BF16_WGRAD_223") != nullptr;
+        KT = 3; TM = h.Cout_g >= 96 ? 2 : 1; TN = (img && use_223 && TM == 2 && h.Cin_g >= 128) ? 2 : 1;
+    }
     else if (h.K_eff <= 5) { KT = 5; TM = 1; TN = 1; }
     else { KT = 8; TM = 1; TN = 1; }
     h.NTG = ceil_div(h.K_eff, KT);
@@ -680,7 +686,15 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
         else if (TN == 2) wgh_launch<1, 2, 1>(xv, grid, lds, s, h, dw_direct, bw);
         else wgh_launch<1, 1, 1>(xv, grid, lds, s, h, dw_direct, bw);
     } else if (KT == 3) {
-        if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
+        if (TM == 2 && TN == 2) {
+            static bool attr223 = false;
+            if (!attr223) {
+                (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_img_kernel<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr223 = true;
+            }
+            hipLaunchKernelGGL((conv_wgrad_bf16_img_kernel<2, 2, 3>), grid, dim3(512), lds, s, h, dw_direct, bw);
+        }
+        else if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
         else wgh_launch<1, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
     } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h, dw_direct, bw);
     else wgh_launch<1, 1, 8>(xv, grid, lds, s, h, dw_direct, bw);

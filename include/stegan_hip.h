@@ -194,6 +194,8 @@ int stegan_conv1d_fwd_hx(const stegan_conv_desc* d, const float* x, const uint16
 int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float* dy, const uint16_t* dyh, const uint16_t* wbh,
                               const float* scale, const float* mask_src, const float* add_src, float* dx, uint16_t* dxh,
                               float* workspace, int64_t workspace_floats, void* stream);
+/* diagnostic time mark: a one-lane kernel stores the 100 MHz real-time counter into *slot (scripts/step_marks.py) */
+int stegan_timestamp(uint64_t* slot, void* stream);
 /* the elementwise producers of the path with an image of their output beside it (out_h / dx_h / y_h / dz_h / dqkv_h nullable;
  * C % 8 == 0; act_bwd additionally T % 4 == 0): as the functions of the same name without `_img` */
 int stegan_act_bwd_add_img(const float* dy, const float* add, const float* y, float* out, uint16_t* out_h, int64_t n, int32_t C,

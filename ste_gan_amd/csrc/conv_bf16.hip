@@ -139,6 +139,12 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                  "s"(p.stride), "s"(p.mode), "s"(p.m_tiles), "s"(p.SEG), "s"(p.NSEG), "s"(p.XROW), "s"(p.U0), "s"(p.splits),
                  "s"(p.chunks_per_split), "s"(p.nbx), "s"(p.ny), "s"(p.ups), "s"(p.in_relu), "s"(h.Mpad), "s"(h.Cpad), "s"(h.NG),
                  "s"(h.ntapsW), "s"(h.xit), "s"(h.wit), "s"(h.src_bytes), "s"(h.vec_out));
+    // round 3: the fields of the image path and every magic divisor of the index setup in the same batch (the ISA of the
+    // first image build showed eight dependent s_load / s_waitcnt round trips between kernel entry and the first DMA)
+    asm volatile("" ::"s"(h.xh), "s"(h.wh), "s"(h.xh_cb), "s"(h.xh_bytes), "s"(h.xnit), "s"(h.nstage), "s"(p.out_h), "s"(p.out_cb),
+                 "s"(p.fdNY.mul), "s"(p.fdNY.shift), "s"(p.fdNBX.mul), "s"(p.fdNBX.shift), "s"(p.fdSP.mul), "s"(p.fdSP.shift),
+                 "s"(p.fdMT.mul), "s"(p.fdMT.shift), "s"(p.fdXROW.mul), "s"(p.fdXROW.shift), "s"(p.fdSEG.mul), "s"(p.fdSEG.shift),
+                 "s"(p.fdU0.mul), "s"(p.fdU0.shift), "s"(p.fdU1.mul), "s"(p.fdU1.shift), "s"(p.src), "s"(p.out), "s"(p.partial));
     // 1-D grid.  Blocks are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so linear block L is first
     // mapped to a logical tile id such that every XCD works on ONE contiguous range of ids, and ids run M-tile fastest:
     // the blocks resident on an XCD at any time then cover a few N tiles x all M tiles of a layer -- each X chunk is
@@ -161,14 +167,19 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int g = (int)fd_div((uint32_t)by, p.fdMT);
     const int m0 = (by - g * p.m_tiles) * BM;
 
+    // the phase's six table entries in ONE batch of scalar loads (they sat behind two branches: two more round trips)
+    Taps tp;
+    tp.ntaps = p.ph_ntaps[phase]; tp.kbase = p.ph_kbase[phase]; tp.kstep = p.ph_kstep[phase];
+    tp.off_min = p.ph_offmin[phase]; tp.step = p.ph_step[phase];
+    const int phU = p.ph_U[phase];
+    asm volatile("" ::"s"(tp.ntaps), "s"(tp.kbase), "s"(tp.kstep), "s"(tp.off_min), "s"(tp.step), "s"(phU));
     int U, cs, os;
     if (p.mode == 0) { U = p.U0; cs = p.stride; os = 1; }
-    else { U = p.ph_U[phase]; cs = 1; os = p.stride; }
+    else { U = phU; cs = 1; os = p.stride; }
     const int N = p.B * U;
     const int n0 = bx * BN;
     if (n0 >= N) return;
     const FastDiv fdU = (U == p.U0) ? p.fdU0 : p.fdU1;
-    const Taps tp = phase_taps(p, phase);
     const int ntaps = tp.ntaps, off_min = tp.off_min;
     const int ntapsW = NCB == 1 ? ((ntaps + 1) & ~1) : ntaps;       // NCB == 1: MFMA halves take neighbouring taps
     const int S = NCB == 1 ? (ntapsW >> 1) : ntaps * KS;            // MFMA k-steps per chunk
@@ -1012,6 +1023,12 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             double t = rounds * (5.0 + per * t_iter);
             static const char* env_pen = getenv("STEGAN_BF16_SPLIT_PEN");
             if (sp > 1) t += (env_pen ? atof(env_pen) : 1.0) * (6.0 + (sp + 1) * (double)out_elems * 4.0 / 3e6);
+            // In the train step three or four streams keep every CU's block slots taken, so what a launch costs the step is
+            // not only its own latency but the slot time it occupies: blocks x block time over the chip's ~512 slots
+            // (STEGAN_BF16_SLOT_W weighs it; 0 = latency only, the round-2 model)
+            static const char* env_sw = getenv("STEGAN_BF16_SLOT_W");
+            static const double slot_w = env_sw ? atof(env_sw) : 0.0;
+            t += slot_w * (double)blocks * (5.0 + per * t_iter) / 512.0;
             if (t < best - 1e-9) { best = t; TM = tm; TN = tn; splits = sp; gm = g2; }
         }
     }

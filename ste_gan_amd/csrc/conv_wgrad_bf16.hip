@@ -58,7 +58,16 @@ struct WH {
     const unsigned short* dyh = nullptr;
     unsigned xh_bytes = 0, dyh_bytes = 0;
     int xslots = 0;            // staged slots of an x plane
+    FastDiv fdRSA, fdRSX;      // image path: piece -> (plane, slot) of the padded LDS images
+    unsigned long long* stamps = nullptr;      // diagnostic builds (-DSTEGAN_STAMPS, scripts/stamps_wgrad.py)
 };
+#ifdef STEGAN_STAMPS
+#define WSTAMP(i_) if (h.stamps && threadIdx.x == 0) h.stamps[(size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#define WPSTAMP(i_) if (h.stamps && threadIdx.x == 256) h.stamps[(1u << 19) + (size_t)blockIdx.x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+#else
+#define WSTAMP(i_)
+#define WPSTAMP(i_)
+#endif
 
 constexpr int WDI = 8;         // image path: LDS-DMA wave-instructions per producer wave, operand and chunk
 
@@ -106,6 +115,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
     const bool producer = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    WSTAMP(0)
     // block -> (ci tile fastest, co tile, group, tap group, slice): neighbours share the dy tile
     unsigned t = blockIdx.x;
     unsigned q_ = fd_div(t, h.fdCI);
@@ -139,30 +149,38 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
         const auto rs_xh = __builtin_amdgcn_make_buffer_rsrc((void*)h.xh, 0, (int)h.xh_bytes, 0x00020000);
         const auto rs_yh = __builtin_amdgcn_make_buffer_rsrc((void*)h.dyh, 0, (int)h.dyh_bytes, 0x00020000);
         const int CBy = h.Cout >> 3, CBx = h.Cin >> 3;              // planes per batch element of the two images
-        const int runsA = (h.R + 63) >> 6, runsX = (h.xslots + 63) >> 6;
-        const int nA = CBA * runsA, nX = CBX * runsX;               // wave-instructions per chunk
+        // pieces run LINEARLY over the padded LDS images ([plane][RSA | RSX slots]): instruction ii covers pieces
+        // 64 ii .. 64 ii + 63 whatever plane they fall in (the first image build gave every plane its own runs of 64: a
+        // 70-slot x plane cost two instructions, the second moving 96 bytes); the padding slots between a plane's staged
+        // slots and its pitch are written as zeros and never read
+        const int nA = (CBA * h.RSA + 63) >> 6, nX = (CBX * h.RSX + 63) >> 6;       // wave-instructions per chunk
         const int ylive = (h.Cout_g - co0 + 7) >> 3, xlive = (h.Cin_g - ci0 + 7) >> 3;     // live planes of the tiles
         // chunk-invariant per-lane parts
-        int a_lane[WDI], a_seg[WDI], a_uu[WDI], a_ldsb[WDI];        // dy: byte offset without the chunk term | -1, row, position
+        int a_lane[WDI], a_seg[WDI], a_uu[WDI], a_ldsb[WDI];        // dy: byte offset without the chunk term | -1 | -2, row, position
         int x_lane[WDI], x_seg[WDI], x_sl[WDI], x_ldsb[WDI];
 #pragma unroll
         for (int it = 0; it < WDI; ++it) {
-            {
-                const int ii = it * 4 + wave, cg = ii / runsA, run = ii - cg * runsA, slot = run * 64 + lane;
+            const int ii = it * 4 + wave;
+            a_seg[it] = 0; a_uu[it] = 0; a_ldsb[it] = -1; a_lane[it] = -1;
+            x_seg[it] = 0; x_sl[it] = 0; x_ldsb[it] = -1; x_lane[it] = -1;
+            if (ii < nA) {
+                const int piece = ii * 64 + lane;
+                const int cg = (int)fd_div((uint32_t)piece, h.fdRSA), slot = piece - cg * h.RSA;
                 const int seg = (int)fd_div((uint32_t)slot, h.fdRUp), uu = slot - seg * h.RUp;
-                const bool on = ii < nA && slot < h.R;
                 a_seg[it] = seg; a_uu[it] = uu;
-                a_ldsb[it] = ii < nA ? (cg * h.RSA + run * 64) * 16 : -1;
-                a_lane[it] = (on && cg < ylive && seg < h.NB && uu < h.RU)
-                                 ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : (on ? -2 : -1);
+                a_ldsb[it] = ii * 1024;
+                if (cg < CBA)
+                    a_lane[it] = (slot < h.R && cg < ylive && seg < h.NB && uu < h.RU)
+                                     ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : -2;
             }
-            {
-                const int ii = it * 4 + wave, cg = ii / runsX, run = ii - cg * runsX, slot = run * 64 + lane;
+            if (ii < nX) {
+                const int piece = ii * 64 + lane;
+                const int cg = (int)fd_div((uint32_t)piece, h.fdRSX), slot = piece - cg * h.RSX;
                 const int seg = (int)fd_div((uint32_t)slot, h.fdSEG), sl = slot - seg * h.SEG;
-                const bool on = ii < nX && slot < h.xslots;
                 x_seg[it] = seg; x_sl[it] = sl;
-                x_ldsb[it] = ii < nX ? (cg * h.RSX + run * 64) * 16 : -1;
-                x_lane[it] = (on && cg < xlive) ? ((seg * CBx + ((g * h.Cin_g + ci0) >> 3) + cg) * h.Tin) * 16 : (on ? -2 : -1);
+                x_ldsb[it] = ii * 1024;
+                if (cg < CBX)
+                    x_lane[it] = (slot < h.xslots && cg < xlive) ? ((seg * CBx + ((g * h.Cin_g + ci0) >> 3) + cg) * h.Tin) * 16 : -2;
             }
         }
         // -1: lane switched off (past the plane's staged slots); -2: staged as zeros
@@ -190,10 +208,18 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 }                                                                                               \
             }                                                                                                   \
         }
+        WPSTAMP(0)
         if (nchunks > 0) WG_DMA(0, 0)
+        WPSTAMP(1)
         for (int c = 0; c < nchunks; ++c) {
+            if (c == 5) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WPSTAMP(4)                         // chunk 5 landed
+            }
             block_sync();                          // barrier c: chunk c has landed (vmcnt(0) in front of the barrier)
+            if (c == 4) { WPSTAMP(2) }
             if (c + 1 < nchunks) WG_DMA(c + 1, (c + 1) & 1)
+            if (c == 4) { WPSTAMP(3) }
         }
         return;
 #undef WG_DMA
@@ -359,9 +385,12 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
     const s16x8 relu_fl = {rfl, rfl, rfl, rfl, rfl, rfl, rfl, rfl};
     (void)relu_fl;
 
+    WSTAMP(1)
     for (int c = 0; c < nchunks; ++c) {
         const int cur = c & 1;
         block_sync();                                                 // barrier c: chunk c is staged
+        if (c == 1) { WSTAMP(2) }
+        if (c == 5) { WSTAMP(3) }
         int adj = 0;                                                  // down-rounding of the x window start (XV)
         if (XV) {
             const int bc = (int)fd_div((uint32_t)c, h.fdUC), uc = c - bc * h.u_chunks;
@@ -370,64 +399,119 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
         }
         const char* Acur = smem + cur * bufsz;
         const char* Xcur = Acur + abuf + adj * 16;
-        for (int st = 0; st < h.NST; ++st) {
-            // xoff is indexed with a runtime st: select through registers (an indexed array would go to scratch)
-            int xo0 = 0, xo1 = 0;
-#pragma unroll
-            for (int s2 = 0; s2 < NST_MAX; ++s2)
-                if (s2 == st) { xo0 = xoff[s2][0]; xo1 = xoff[s2][1]; }
-            // every operand read of the k-step is issued before its first MFMA (one exposed LDS round trip per k-step,
-            // not one per tap; the partner producer wave fills the rest)
-            bf16x8 a[TM], bfr[KT][TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = tr_operand(Acur + a_byte[i] + st * 256, 64);
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bfr[k][j] = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);
-            if constexpr (XH) {                    // image path: the input ReLU is applied at the operand (LDS-DMA moves bytes)
-#pragma unroll
-                for (int k = 0; k < KT; ++k)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        bfr[k][j] = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, bfr[k][j]), relu_fl));
-            }
-#pragma unroll
-            for (int k = 0; k < KT; ++k)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bfr[k][j], acc[i][j][k], 0, 0, 0);
+        // k-steps of 16 columns, software-pipelined over two operand register sets: the transposed reads of step st + 1 are
+        // in flight while the MFMAs of step st run (the first version read, waited and multiplied step by step: ~200 cycles
+        // of exposed LDS latency for 64-160 cycles of MFMA per step)
+#define WG_READ(a_, b_, st_)                                                                                    \
+        {                                                                                                       \
+            int xo0 = 0, xo1 = 0;       /* xoff[st_]: selected through registers (an indexed array would go to scratch) */ \
+            _Pragma("unroll") for (int s2 = 0; s2 < NST_MAX; ++s2)                                              \
+                if (s2 == (st_)) { xo0 = xoff[s2][0]; xo1 = xoff[s2][1]; }                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) a_[i] = tr_operand(Acur + a_byte[i] + (st_) * 256, 64); \
+            _Pragma("unroll") for (int k = 0; k < KT; ++k)                                                      \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+                    b_[k][j] = tr_operand(Xcur + b_byte[j] + xo0 + k * tapB, xo1 - xo0);                        \
         }
+#define WG_MFMA(a_, b_)                                                                                         \
+        _Pragma("unroll") for (int k = 0; k < KT; ++k)                                                          \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                    \
+                const bf16x8 bx_ = XH ? __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, b_[k][j]), relu_fl)) \
+                                      : b_[k][j];      /* image path: the input ReLU at the operand */         \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+                    acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i], bx_, acc[i][j][k], 0, 0, 0);  \
+            }
+        bf16x8 aA[TM], bA[KT][TN], aB[TM], bB[KT][TN];
+        if (h.NST > 0) WG_READ(aA, bA, 0)
+        for (int st = 0; st < h.NST; st += 2) {
+            if (st + 1 < h.NST) WG_READ(aB, bB, st + 1)
+            WG_MFMA(aA, bA)
+            if (st + 1 < h.NST) {
+                if (st + 2 < h.NST) WG_READ(aA, bA, st + 2)
+                WG_MFMA(aB, bB)
+            }
+        }
+#undef WG_READ
+#undef WG_MFMA
     }
 
-    // ---- store: accumulator tile = 32 co (registers: 4 runs of 4 rows) x 32 ci (lanes).  Sliced reductions write their
-    // partial dW to a slab [slice][kk][co][ci] (coalesced along ci), summed by the reduce kernel in a fixed order; an
-    // unsliced one adds straight into dW (Cout, Cin_g, K): this block is the only writer of its elements.
+    WSTAMP(4)
+    // ---- store: accumulator tile = 32 co (registers: 4 runs of 4 rows) x 32 ci (lanes), KT taps per element.  dW is
+    // (Cout, Cin_g, K) with the tap innermost, so a lane's KT values of one (co, ci) are CONTIGUOUS there, and the lanes of
+    // a half-wave (consecutive ci) cover 32 x KT contiguous floats: one or two wide accesses per (co, ci) instead of KT
+    // scattered dwords (the first version, tap-outermost with one dword per access, spent 14-40 k cycles per block here:
+    // store-issue bound).  Sliced reductions write their partial dW to a slab in the same [co][ci][kk] order (kk over the
+    // live taps), summed by the reduce kernel in a fixed order; an unsliced one adds straight into dW: this block is
+    // the only writer of its elements.
+    // (the wide accesses go through a buffer descriptor: a (co, ci) group is only dword aligned -- 12 or 20 bytes apart --
+    // and hipcc splits an under-aligned vector access of a flat pointer into dwords, while buffer_load / _store_dwordx4
+    // take any dword-aligned offset)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     const int l31 = lane & 31;
-    float* slab = h.partial + (size_t)slice * h.K_eff * h.Cout * h.Cin_g;
+    const int kq0 = tg * KT;                                // first live tap of this block
+    const int nk = min(KT, h.K_eff - kq0);                  // taps it owns
+    const int KK = dw_direct ? h.K : h.K_eff;               // taps per (co, ci) in the destination
+    float* const dst0 = dw_direct ? dw_direct + h.k_lo + kq0
+                                  : h.partial + (size_t)slice * h.K_eff * h.Cout * h.Cin_g + kq0;
+    const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst0, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        const int kk = tg * KT + k;                        // index among the live taps
-        if (kk >= h.K_eff) continue;
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + (wn * TN + j) * 32 + l31;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + (wn * TN + j) * 32 + l31;
+        for (int i = 0; i < TM; ++i) {
+            const int cob = co0 + (wm * TM + i) * 32 + 4 * hl;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int cob = co0 + (wm * TM + i) * 32 + 4 * hl;
+            for (int e = 0; e < 16; ++e) {
+                const int co = cob + (e & 3) + 8 * (e >> 2);
+                if (ci >= h.Cin_g || co >= h.Cout_g) continue;
+                const int off = (int)((((size_t)(g * h.Cout_g + co) * h.Cin_g + ci) * KK) * 4);       // bytes from dst0
+                float v[KT];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = cob + (e & 3) + 8 * (e >> 2);
-                    if (ci < h.Cin_g && co < h.Cout_g) {
-                        if (dw_direct) dw_direct[((size_t)(g * h.Cout_g + co) * h.Cin_g + ci) * h.K + h.k_lo + kk] += acc[i][j][k][e];
-                        else slab[((size_t)kk * h.Cout + g * h.Cout_g + co) * h.Cin_g + ci] = acc[i][j][k][e];
+                for (int k = 0; k < KT; ++k) v[k] = acc[i][j][k][e];
+                if (nk == KT) {
+                    if (dw_direct) {                        // read-modify-write: all loads first, then the stores
+                        float o[KT];
+                        int k = 0;
+                        if constexpr (KT >= 4) {
+#pragma unroll
+                            for (; k + 4 <= KT; k += 4) {
+                                const u32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_o, off + 4 * k, 0, 0);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) o[k + q] = __builtin_bit_cast(float, t4[q]);
+                            }
+                        }
+                        if constexpr ((KT & 3) >= 2) {
+                            const u32x2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rs_o, off + 4 * k, 0, 0);
+                            o[k] = __builtin_bit_cast(float, t2[0]); o[k + 1] = __builtin_bit_cast(float, t2[1]); k += 2;
+                        }
+                        if constexpr (KT & 1) o[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, off + 4 * k, 0, 0));
+#pragma unroll
+                        for (int q = 0; q < KT; ++q) v[q] += o[q];
                     }
+                    int k = 0;
+                    if constexpr (KT >= 4) {
+#pragma unroll
+                        for (; k + 4 <= KT; k += 4) {
+                            const u32x4 t4 = {__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + 1]),
+                                              __builtin_bit_cast(unsigned, v[k + 2]), __builtin_bit_cast(unsigned, v[k + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(t4, rs_o, off + 4 * k, 0, 0);
+                        }
+                    }
+                    if constexpr ((KT & 3) >= 2) {
+                        const u32x2 t2 = {__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + 1])};
+                        __builtin_amdgcn_raw_buffer_store_b64(t2, rs_o, off + 4 * k, 0, 0);
+                        k += 2;
+                    }
+                    if constexpr (KT & 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), rs_o, off + 4 * k, 0, 0);
+                } else {                                    // ragged last tap group
+                    float* ptr = dst0 + (off >> 2);
+#pragma unroll
+                    for (int k = 0; k < KT; ++k)
+                        if (k < nk) ptr[k] = dw_direct ? ptr[k] + v[k] : v[k];
                 }
             }
         }
     }
+    WSTAMP(5)
 }
 
 // bias-gradient blocks of the weight-gradient grid (512 threads): db[c] += sum over a batch slice of dy[b, c, :]
@@ -497,10 +581,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_kernel(const float
         bias_grad_body(ba.dy, ba.db, ba.B, ba.C, ba.T, ba.per, ba.fdT, ba.vec, j / ba.slices, j % ba.slices);
         return;
     }
+    // slabs are [co][ci][kk] (kk over the K_eff live taps): element i = r * K_eff + kk adds into dw[r * K + k_lo + kk]
     const long total = per_tap * K_eff;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
-        const int kk = (int)(i / per_tap);
-        const long r = i - (long)kk * per_tap;             // co * Cin_g + ci
+        const long r = i / K_eff;                          // co * Cin_g + ci
+        const int kk = (int)(i - r * K_eff);
         const float* src = partial + i;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         int s = 0;
@@ -625,7 +710,7 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
         h.xit = ceil_div((BN / 8) * h.NGX, 256);
         h.xslots = xslots;
         if (img) {                                     // DMA pieces, not register items: <= WDI wave-instructions per wave
-            if (ceil_div((BM / 8) * ceil_div(h.R, 64), 4) > WDI || ceil_div((BN / 8) * ceil_div(xslots, 64), 4) > WDI) return false;
+            if (ceil_div(ceil_div((BM / 8) * h.RSA, 64), 4) > WDI || ceil_div(ceil_div((BN / 8) * h.RSX, 64), 4) > WDI) return false;
         } else if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return false;
         lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
         return lds <= 160 * 1024;
@@ -660,6 +745,8 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
     h.partial = workspace;
     h.fdNGA = make_fastdiv((uint32_t)h.NGA); h.fdNGX = make_fastdiv((uint32_t)h.NGX);
     h.fdRUp = make_fastdiv((uint32_t)h.RUp); h.fdSEG = make_fastdiv((uint32_t)h.SEG);
+    { const char* se = getenv("STEGAN_STAMP_PTR"); h.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }
+    h.fdRSA = make_fastdiv((uint32_t)h.RSA); h.fdRSX = make_fastdiv((uint32_t)h.RSX);
     h.fdUC = make_fastdiv((uint32_t)h.u_chunks); h.fdCI = make_fastdiv((uint32_t)h.ci_tiles);
     h.fdCO = make_fastdiv((uint32_t)h.co_tiles); h.fdTG = make_fastdiv((uint32_t)h.NTG);
     {

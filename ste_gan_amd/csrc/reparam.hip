@@ -120,7 +120,19 @@ __global__ __launch_bounds__(256) void fold_upsample2_kernel(const float* __rest
     }
 }
 
+// diagnostics: one lane writes the chip's constant 100 MHz real-time counter -- a time mark inside a captured graph
+__global__ void timestamp_kernel(unsigned long long* slot) { *slot = __builtin_amdgcn_s_memrealtime(); }
+
 }  // namespace
+
+/* Diagnostic (scripts/step_marks.py): enqueue a one-lane kernel that stores s_memrealtime (100 MHz, the same clock on every
+ * XCD) into *slot: time marks between the kernels of a stream, also inside a captured hipGraph.  Not part of the path. */
+extern "C" int stegan_timestamp(uint64_t* slot, void* stream) {
+    STEGAN_CHECK_ARG(slot);
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
 
 extern "C" int stegan_wn_scales(int32_t n, const float* const* v, const float* const* g, float* const* scale,
                                 const int32_t* rows, const int32_t* cols, int32_t max_rows, void* stream) {

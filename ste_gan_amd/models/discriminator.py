@@ -157,6 +157,8 @@ class _MultiDisc(nn.Module):
         n_side = self._scales_on_side() if side is not None else 0
         scale = [None] * len(self.multi_scale_disc)
         run = lambda i: self.multi_scale_disc[i](xs[i], sn_pre[i] if sn_pre is not None else None)
+        third = self._third_stream(main) if side is not None else None
+        on_third = [len(scale) - n_side - 1] if (third is not None and len(scale) - n_side >= 2) else []
         if side is not None:
             self._handoff(side, [x] + xs[len(scale) - n_side:])
             with torch.cuda.stream(side):
@@ -165,10 +167,18 @@ class _MultiDisc(nn.Module):
                     scale[i] = run(i)
         else:
             results = self._pooled_forward(x)
+        if on_third:
+            self._handoff(third, [xs[i] for i in on_third])
+            with torch.cuda.stream(third):
+                for i in on_third:
+                    scale[i] = run(i)
         for i in range(len(scale) - n_side):
-            scale[i] = run(i)
+            if i not in on_third:
+                scale[i] = run(i)
         if side is not None:
             main.wait_stream(side)
+        if on_third:
+            main.wait_stream(third)
         return results + scale
 
     @staticmethod
@@ -218,6 +228,17 @@ class _MultiDisc(nn.Module):
             m._prep = (m._stamp(), m._prep[1])
 
     _side = None
+    _third = None
+
+    def _third_stream(self, main):
+        """A third stream for the middle scale discriminator (STEGAN_D_THIRD=1; experiment: with the round-2 kernels a third
+        discriminator stream lost, 9.97 vs 9.24 ms per step)."""
+        if os.environ.get("STEGAN_D_THIRD", "0") != "1":
+            return None
+        if _MultiDisc._third is None:
+            _MultiDisc._third = torch.cuda.Stream()
+        _MultiDisc._third.wait_stream(main)
+        return _MultiDisc._third
 
     def _fork(self):
         """(current stream, side stream that waits for it), or (current, None) with STEGAN_D_STREAMS=0.  (In fp32 mode the
@@ -289,6 +310,8 @@ class _MultiDisc(nn.Module):
                 return ("pair", disc(xs[i][:n]), disc(xs[i][n:]))          # batch-major: the halves are contiguous views
             return ("both", disc(xs[i]), n)
 
+        third = self._third_stream(main) if side is not None else None
+        on_third = [ns - n_side - 1] if (third is not None and ns - n_side >= 2) else []
         if side is not None:
             self._handoff(side, [both] + xs[ns - n_side:])
             with torch.cuda.stream(side):
@@ -297,10 +320,18 @@ class _MultiDisc(nn.Module):
                     scale[i] = run(i)
         else:
             pooled = self._pooled_forward(both)
+        if on_third:
+            self._handoff(third, [xs[i] for i in on_third])
+            with torch.cuda.stream(third):
+                for i in on_third:
+                    scale[i] = run(i)
         for i in range(ns - n_side):
-            scale[i] = run(i)
+            if i not in on_third:
+                scale[i] = run(i)
         if side is not None:
             main.wait_stream(side)
+        if on_third:
+            main.wait_stream(third)
         return [("both", fm, n) for fm in pooled] + scale
 
 

@@ -221,6 +221,19 @@ def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optiona
     return torch.empty((like.shape[0], channels // 8, length, 8), device=like.device, dtype=torch.bfloat16)
 
 
+# ---- diagnostics: time marks inside the (captured) step, scripts/step_marks.py -----------------------------------------
+MARKS: Optional[dict] = None        # {"buf": int64 tensor, "names": [...]} when switched on
+
+
+def mark(name: str) -> None:
+    """Enqueue a time mark on the current stream (a one-lane kernel storing the 100 MHz real-time counter)."""
+    if MARKS is None:
+        return
+    i = len(MARKS["names"])
+    MARKS["names"].append(name)
+    check(_lib.lib().stegan_timestamp(C.c_void_p(MARKS["buf"].data_ptr() + 8 * i), _stream()), "stegan_timestamp")
+
+
 def bump_weight_epoch() -> None:
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1

@@ -135,8 +135,10 @@ class GANTrainStep:
         s_t1 = speech_units_t if self.speech_feature_type == DataType.SPEECH_UNITS else batch_dict[self.speech_feature_type]
         out: Dict[str, torch.Tensor] = {}
 
+        ops.mark("step start")
         netG.train()
         x_pred_t = netG(s_t1, sess_idx, spk_mode_idx)                                   # train.py:182
+        ops.mark("G forward done")
 
         # ---- D-independent generator losses (multi-TD, frozen EMG encoder) and THEIR gradient w.r.t. the generated EMG.
         # The reference computes them inside the generator step (train.py:213-256), after the discriminator update, but
@@ -158,10 +160,12 @@ class GANTrainStep:
             torch.cuda.set_stream(side)
         try:
             xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
+            ops.mark("side: start")
             if t.loss_multi_td_error:
                 td_error = self.multi_td_loss(x_t, xp)
                 loss_side = t.loss_multi_td_weight * td_error
                 out["multi_td"] = td_error.detach()
+            ops.mark("side: TD done")
             if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
                 enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets)
                 if t.loss_speech_unit_error:
@@ -174,14 +178,15 @@ class GANTrainStep:
                     out["phoneme"] = enc_out.phoneme_loss.detach()
                 out["phoneme_counters"] = enc_out._counters
             if t.loss_waveform_error:
-                from . import ops
                 wave_loss = ops.mse_loss(xp, x_t)
                 term = t.loss_waveform_weight * wave_loss
                 loss_side = term if loss_side is None else loss_side + term
                 out["waveform"] = wave_loss.detach()
+            ops.mark("side: encoder forward + losses done")
             if loss_side is not None:
                 (g_side,) = torch.autograd.grad(loss_side, xp)
                 loss_side = loss_side.detach()
+            ops.mark("side: backward done")
         finally:
             if side is not None:
                 torch.cuda.set_stream(main_stream)
@@ -191,6 +196,7 @@ class GANTrainStep:
             if hasattr(netD, "forward_pair_logits"):
                 # train.py:190-196 on the concatenated batch: fake | real logits against zeros | ones, unsliced, one launch
                 loss_D = lsgan_pair_loss(netD.forward_pair_logits(x_pred_t.detach(), x_t), 0.0, 1.0, unit_grad=True)
+                ops.mark("D step: forward + loss done")
             else:
                 D_fake_det, D_real = netD(x_pred_t.detach()), netD(x_t)
                 # both terms are plain summands of the scalar handed to backward(): unit upstream gradient
@@ -204,7 +210,9 @@ class GANTrainStep:
             finally:                               #  7.84 ms/step -- three streams are already busy here)
                 if d_async:
                     _ops.wgrad_async(False)
+            ops.mark("D step: backward done")
             self.optD.finalize_grads()
+            ops.mark("D step: gradients finalized")
             out["discriminator"] = loss_D.detach()
         if side is not None and self.comm is not None:
             # under torch.distributed the phases may be separate hipGraphs (GraphedTrainStep): a graph has to end with
@@ -228,6 +236,7 @@ class GANTrainStep:
                 self.optD.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
             else:
                 self.optD.step(finalized=True)                                           # D weights change HERE
+            ops.mark("D optimiser done")
 
         # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
         self._set_d_grad(False)          # D's weight grads from loss_G are discarded by the reference: skip them
@@ -237,8 +246,10 @@ class GANTrainStep:
             _ops.fm_fold_begin()         # the feature maps' producers add the feature-matching gradients themselves
         try:
             D_fake = netD(x_pred_t)
+            ops.mark("G step: D(fake) done")
             with torch.no_grad():
                 D_real = netD(x_t)
+            ops.mark("G step: D(real) done")
             loss_main = None
             if t.loss_adversarial:
                 loss_main = lsgan_loss(D_fake, 1.0, unit_grad=True)
@@ -247,8 +258,10 @@ class GANTrainStep:
                 loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
                 loss_main = loss_feat_w if loss_main is None else loss_main + loss_feat_w
                 out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
+            ops.mark("G step: losses done")
             if side is not None:
                 main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
+            ops.mark("G step: side joined")
             # one pass through the generator for both gradient sources
             roots, grads = [], []
             if loss_main is not None:
@@ -267,7 +280,9 @@ class GANTrainStep:
         finally:
             _ops.fm_fold_abort()
             self._set_d_grad(True)
+        ops.mark("G step: backward done")
         self.optG.finalize_grads()
+        ops.mark("G step: gradients finalized")
         out["generator"] = loss_G.detach() if torch.is_tensor(loss_G) else torch.zeros((), device=x_pred_t.device)
         out["x_pred"] = x_pred_t.detach()
 
@@ -278,6 +293,7 @@ class GANTrainStep:
             self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
         else:
             self.optG.step(finalized=True)
+        ops.mark("G optimiser done")
         out = self._st["out"]
         self._st = None                     # drop the step's tensors
         self.last = out

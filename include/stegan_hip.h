@@ -194,6 +194,15 @@ int stegan_conv1d_fwd_hx(const stegan_conv_desc* d, const float* x, const uint16
 int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float* dy, const uint16_t* dyh, const uint16_t* wbh,
                               const float* scale, const float* mask_src, const float* add_src, float* dx, uint16_t* dxh,
                               float* workspace, int64_t workspace_floats, void* stream);
+/* stegan_adamw_step / stegan_wn_backward that ZERO the gradient they consume (zero_grads / zero_dw != 0): the arenas then
+ * need no fill before the next backward pass (torch.optim semantics keep .grad until zero_grad(); the graph-replayed
+ * train step switches this on, GraphedTrainStep) */
+int stegan_adamw_step_z(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+                        float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t zero_grads,
+                        void* stream);
+int stegan_wn_backward_z(int32_t n, const float* const* v, const float* const* g, float* const* dw, float* const* dv,
+                         float* const* dg, const int32_t* rows, const int32_t* cols, int32_t max_rows, int32_t zero_dw,
+                         void* stream);
 /* diagnostic time mark: a one-lane kernel stores the 100 MHz real-time counter into *slot (scripts/step_marks.py) */
 int stegan_timestamp(uint64_t* slot, void* stream);
 /* the elementwise producers of the path with an image of their output beside it (out_h / dx_h / y_h / dz_h / dqkv_h nullable;

@@ -16,10 +16,12 @@ __global__ void adamw_advance_kernel(float* hyper, double beta1, double beta2) {
     hyper[2] = (float)(1.0 - pow(beta2, (double)t));
 }
 
-__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+// zero_g: the gradient arena is zeroed as it is consumed (the next step's zero_grad() then costs no launch: two fills of
+// 47 + 94 MB sat at the very start of every step, on its critical path)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, long n,
                                                     const float* __restrict__ hyper, float beta1, float beta2,
-                                                    float eps, float wd, float grad_scale) {
+                                                    float eps, float wd, float grad_scale, int zero_g) {
     const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2];
     const float decay = 1.f - lr * wd;
     const float step = lr / bc1;
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         *reinterpret_cast<float4*>(p + i) = pp;
         *reinterpret_cast<float4*>(m + i) = mm;
         *reinterpret_cast<float4*>(v + i) = vv;
+        if (zero_g) *reinterpret_cast<float4*>(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // tail (n % 4) handled by the first threads of block 0
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float vj = v[j] * beta2 + gk * gk * (1.f - beta2);
         pj -= step * (mj / (sqrtf(vj) * inv_sqrt_bc2 + eps));
         p[j] = pj; m[j] = mj; v[j] = vj;
+        if (zero_g) g[j] = 0.f;
     }
 }
 
@@ -66,16 +70,23 @@ extern "C" int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2
     return STEGAN_OK;
 }
 
-extern "C" int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                 const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
-                                 float grad_scale, void* stream) {
+extern "C" int stegan_adamw_step_z(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                                   float grad_scale, int32_t zero_grads, void* stream) {
     STEGAN_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && hyper_dev && n > 0);
     STEGAN_CHECK_ARG(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0);
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, (long)n, hyper_dev, beta1, beta2, eps, weight_decay, grad_scale);
+                       exp_avg_sq, (long)n, hyper_dev, beta1, beta2, eps, weight_decay, grad_scale, zero_grads);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* hyper_dev, float beta1, float beta2, float eps, float weight_decay,
+                                 float grad_scale, void* stream) {
+    return stegan_adamw_step_z(params, const_cast<float*>(grads), exp_avg, exp_avg_sq, n, hyper_dev, beta1, beta2, eps,
+                               weight_decay, grad_scale, 0, stream);
 }

@@ -22,11 +22,13 @@ __device__ __forceinline__ void wn_scale_row(const float* v, const float* g, flo
 }
 
 // one wave per row: ds = <dw,v>; dg = ds/||v||; dv = (g/||v||) dw - (ds g/||v||^3) v
+// zero_dw: the raw gradient row is zeroed once it has been read (the arena then needs no fill before the next backward)
 __device__ __forceinline__ void wn_backward_row(const float* v, const float* g, const float* dw, float* dv,
-                                                float* dg, int row, int C) {
+                                                float* dg, int row, int C, int zero_dw = 0) {
     const int lane = threadIdx.x & 63;
     const float* vr = v + (size_t)row * C;
     const float* dwr = dw + (size_t)row * C;
+    float* dwz = const_cast<float*>(dwr);
     float* dvr = dv + (size_t)row * C;
     // rows of up to 64 * WN_REG columns stay in registers between the two passes (v and dw are read ONCE: 3 instead of 5
     // arena-sized streams -- the kernel is HBM-bound), and their loads are all issued before the first use
@@ -56,7 +58,10 @@ __device__ __forceinline__ void wn_backward_row(const float* v, const float* g, 
 #pragma unroll
         for (int q = 0; q < WN_REG; ++q) {
             const int c = lane + 64 * q;
-            if (64 * q < C && c < C) dvr[c] = s * da[q] - k * va[q];
+            if (64 * q < C && c < C) {
+                dvr[c] = s * da[q] - k * va[q];
+                if (zero_dw) dwz[c] = 0.f;
+            }
         }
         if (lane == 0) dg[row] = dot * inv;
         return;
@@ -69,7 +74,10 @@ __device__ __forceinline__ void wn_backward_row(const float* v, const float* g, 
     const float gv = g[row];
     const float s = gv * inv;
     const float k = dot * gv * inv * inv * inv;
-    for (int c = lane; c < C; c += 64) dvr[c] = s * dwr[c] - k * vr[c];
+    for (int c = lane; c < C; c += 64) {
+        dvr[c] = s * dwr[c] - k * vr[c];
+        if (zero_dw) dwz[c] = 0.f;
+    }
     if (lane == 0) dg[row] = dot * inv;
 }
 
@@ -89,11 +97,11 @@ __global__ __launch_bounds__(256) void wn_scale1_kernel(const float* v, const fl
 
 __global__ __launch_bounds__(256) void wn_backward_kernel(int n, const float* const* v, const float* const* g,
                                                           const float* const* dw, float* const* dv, float* const* dg,
-                                                          const int* rows, const int* cols) {
+                                                          const int* rows, const int* cols, int zero_dw) {
     const int ti = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ti >= n || row >= rows[ti]) return;
-    wn_backward_row(v[ti], g[ti], dw[ti], dv[ti], dg[ti], row, cols[ti]);
+    wn_backward_row(v[ti], g[ti], dw[ti], dv[ti], dg[ti], row, cols[ti], zero_dw);
 }
 
 __global__ __launch_bounds__(256) void wn_backward1_kernel(const float* v, const float* g, const float* dw, float* dv,
@@ -143,14 +151,20 @@ extern "C" int stegan_wn_scales(int32_t n, const float* const* v, const float* c
     return STEGAN_OK;
 }
 
+extern "C" int stegan_wn_backward_z(int32_t n, const float* const* v, const float* const* g, float* const* dw,
+                                    float* const* dv, float* const* dg, const int32_t* rows, const int32_t* cols,
+                                    int32_t max_rows, int32_t zero_dw, void* stream) {
+    STEGAN_CHECK_ARG(n > 0 && v && g && dw && dv && dg && rows && cols && max_rows > 0);
+    hipLaunchKernelGGL(wn_backward_kernel, dim3(ceil_div(max_rows, 4), n), dim3(256), 0, (hipStream_t)stream, n, v, g,
+                       (const float* const*)dw, dv, dg, rows, cols, zero_dw);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
 extern "C" int stegan_wn_backward(int32_t n, const float* const* v, const float* const* g, const float* const* dw,
                                   float* const* dv, float* const* dg, const int32_t* rows, const int32_t* cols,
                                   int32_t max_rows, void* stream) {
-    STEGAN_CHECK_ARG(n > 0 && v && g && dw && dv && dg && rows && cols && max_rows > 0);
-    hipLaunchKernelGGL(wn_backward_kernel, dim3(ceil_div(max_rows, 4), n), dim3(256), 0, (hipStream_t)stream, n, v, g,
-                       dw, dv, dg, rows, cols);
-    STEGAN_LAUNCH_CHECK();
-    return STEGAN_OK;
+    return stegan_wn_backward_z(n, v, g, (float* const*)dw, dv, dg, rows, cols, max_rows, 0, stream);
 }
 
 extern "C" int stegan_wn_scale1(const float* v, const float* g, float* scale, int32_t rows, int32_t cols, void* stream) {

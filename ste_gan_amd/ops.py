@@ -221,6 +221,47 @@ def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optiona
     return torch.empty((like.shape[0], channels // 8, length, 8), device=like.device, dtype=torch.bfloat16)
 
 
+# ---- zeroed scratch for one train step ---------------------------------------------------------------------------------
+# The step needs ~30 zero-initialised buffers (loss words, counters, the spectral-norm layers' raw weight gradients): one
+# torch.zeros() -- one fill launch -- each.  Inside GANTrainStep they are carved from ONE pool that a single fill zeroes at
+# the start of the step (zero_pool_begin); outside a step pooled_zeros() is torch.zeros().
+_ZPOOL = {"buf": None, "off": 0, "active": False}
+ZERO_POOL_BYTES = int(os.environ.get("STEGAN_ZERO_POOL_MB", "48")) << 20
+
+
+def zero_pool_begin(device) -> None:
+    if ZERO_POOL_BYTES <= 0:
+        return
+    if _ZPOOL["buf"] is None or _ZPOOL["buf"].device != torch.device(device):
+        _ZPOOL["buf"] = torch.empty(ZERO_POOL_BYTES, device=device, dtype=torch.uint8)
+        _ZPOOL["used"] = ZERO_POOL_BYTES
+    # zero what the previous step handed out (the whole pool the first time)
+    n = min(ZERO_POOL_BYTES, (_ZPOOL.get("used", ZERO_POOL_BYTES) + 255) & ~255)
+    _ZPOOL["buf"][:n].zero_()
+    _ZPOOL["off"], _ZPOOL["active"] = 0, True
+
+
+def zero_pool_end() -> None:
+    if _ZPOOL["active"]:
+        _ZPOOL["used"] = max(_ZPOOL["off"], 256)
+    _ZPOOL["active"] = False
+
+
+def pooled_zeros(shape, device, dtype=torch.float32) -> Tensor:
+    """torch.zeros(shape) from the step's pre-zeroed pool when one is open (and the request fits), else a fresh fill."""
+    shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+    n = 1
+    for d_ in shape:
+        n *= int(d_)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    off = (_ZPOOL["off"] + 15) & ~15
+    if not _ZPOOL["active"] or _ZPOOL["buf"] is None or _ZPOOL["buf"].device != torch.device(device) or \
+            off + nbytes > ZERO_POOL_BYTES:
+        return torch.zeros(shape, device=device, dtype=dtype)
+    _ZPOOL["off"] = off + nbytes
+    return _ZPOOL["buf"][off:off + nbytes].view(dtype).view(shape)
+
+
 # ---- diagnostics: time marks inside the (captured) step, scripts/step_marks.py -----------------------------------------
 MARKS: Optional[dict] = None        # {"buf": int64 tensor, "names": [...]} when switched on
 
@@ -950,7 +991,7 @@ class _SNConvFn(torch.autograd.Function):
             sink = ctx.sink
             if sink is not None:
                 _sink_touch()
-            dw = torch.zeros_like(w_orig)
+            dw = pooled_zeros(w_orig.shape, dy.device)
             db = torch.zeros(cfg.cout, device=dy.device, dtype=torch.float32) if sink is None else sink[1]
             conv1d_bwd_weight(x, dy, cfg, dw, db)
             rows = w_orig.shape[0]
@@ -1167,7 +1208,7 @@ class _PairLossFn(torch.autograd.Function):
             bf = _gpu_f32(bf, "target")
             if bf.numel() != af.numel():
                 raise RuntimeError(f"The size of tensor a ({list(a.shape)}) must match the size of tensor b ({list(b.shape)})")
-        loss = torch.zeros((), device=af.device, dtype=torch.float32)
+        loss = pooled_zeros((), af.device)
         need = ctx.needs_input_grad[0]
         da = torch.empty_like(af) if need else None
         check(_lib.lib().stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target), af.numel(), mode, 1.0, _p(loss), _p(da),
@@ -1201,7 +1242,7 @@ class _MultiPairLossFn(torch.autograd.Function):
         if isinstance(weight, tuple):  # per-pair (weights, targets, targets2, splits): multi_pair_loss_const
             spec, weight, target = weight, 0.0, 0.0
         a_list, b_list = ts[:n], (ts[n:] if target is None else (None,) * n)
-        loss = torch.zeros((), device=a_list[0].device, dtype=torch.float32)
+        loss = pooled_zeros((), a_list[0].device)
         grads, restores = [], []
         L = _lib.lib()
         afs, bfs, das = [], [], []
@@ -1298,8 +1339,8 @@ class _MultiTDFn(torch.autograd.Function):
         B, T, Cc = x_gen.shape
         L = _lib.lib()
         n = len(wins)
-        loss = torch.zeros((), device=x_gen.device, dtype=torch.float32)
-        per = torch.zeros(3, device=x_gen.device, dtype=torch.float32)
+        loss = pooled_zeros((), x_gen.device)
+        per = pooled_zeros(3, x_gen.device)
         ws = torch.empty(int(L.stegan_multi_td_workspace_floats(B, Cc)), device=x_gen.device, dtype=torch.float32)
         dx = torch.empty_like(x_gen) if ctx.needs_input_grad[1] else None
         wa = (C.c_int32 * n)(*wins)
@@ -1379,7 +1420,7 @@ class _SULossFn(torch.autograd.Function):
         pred = _gpu_f32(pred, "speech_unit_pred")
         D = pred.shape[-1]
         rows = pred.numel() // D
-        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
+        loss = pooled_zeros((), pred.device)
         ws = torch.empty(rows, device=pred.device, dtype=torch.float32)
         dp = torch.empty_like(pred) if ctx.needs_input_grad[1] else None
         check(_lib.lib().stegan_su_loss_fwd_bwd(_p(target), _p(pred), rows, D, 1.0, _p(loss), _p(dp), _p(ws), _stream()),
@@ -1409,8 +1450,8 @@ class _PhonemeCEFn(torch.autograd.Function):
         if targets.numel() != rows:
             raise RuntimeError(f"Expected target size {list(logits.shape[:-1])}, got {list(targets.shape)}")
         dev = logits.device
-        loss = torch.zeros((), device=dev, dtype=torch.float32)
-        counters = torch.zeros(4, device=dev, dtype=torch.int32)
+        loss = pooled_zeros((), dev)
+        counters = pooled_zeros(4, dev, torch.int32)
         argmax = torch.empty(logits.shape[:-1], device=dev, dtype=torch.int64)
         ws = torch.empty(rows, device=dev, dtype=torch.float32)
         dl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None

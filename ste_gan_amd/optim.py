@@ -53,8 +53,11 @@ class FlatParams:
             if hasattr(m, "_prep"):            # layers that keep prepared weight copies of their own
                 m._owner = self
 
+    zero_in_step = False       # the optimiser kernels zero the arena as they consume it (FusedAdamW.zero_in_step)
+
     def zero_grad(self):
-        self.grad.zero_()
+        if not self.zero_in_step:
+            self.grad.zero_()
         for p, o in zip(self.params, self.offsets):          # autograd may have swapped the tensor: re-attach the view
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
@@ -194,8 +197,11 @@ class ConvPack:
             check(L.stegan_conv_prep_bf16_multi(self.n, P(self.t_prep_h), self.prep_h_blocks, s), "stegan_conv_prep_bf16_multi")
         self.prepared_version = key
 
+    zero_in_step = False
+
     def zero(self):
-        self.dw.zero_()
+        if not self.zero_in_step:
+            self.dw.zero_()
 
     def finalize_grads(self):
         """raw dw -> (dv, dg) for every conv, written into the .grad views (1 launch)."""
@@ -203,8 +209,9 @@ class ConvPack:
         ops.wgrad_join()                       # weight gradients launched on a side stream (ops._wgrad_sink)
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: C.c_void_p(t.data_ptr())
-        check(_lib.lib().stegan_wn_backward(self.n, P(self.t_v), P(self.t_g), P(self.t_dw), P(self.t_dv), P(self.t_dg),
-                                            P(self.t_rows), P(self.t_cols), self.max_rows, s), "stegan_wn_backward")
+        check(_lib.lib().stegan_wn_backward_z(self.n, P(self.t_v), P(self.t_g), P(self.t_dw), P(self.t_dv), P(self.t_dg),
+                                              P(self.t_rows), P(self.t_cols), self.max_rows, int(self.zero_in_step), s),
+              "stegan_wn_backward_z")
 
 
 class FusedAdamW:
@@ -228,6 +235,20 @@ class FusedAdamW:
         self.flat.zero_grad()
         if self.pack is not None:
             self.pack.zero()
+
+    def set_zero_in_step(self, on: bool) -> None:
+        """With ``on`` the AdamW kernel zeroes the gradient arena (and the weight-norm backward the raw dW arena) as it
+        consumes it, and ``zero_grad()`` launches nothing: ``.grad`` then reads zero after ``step()`` -- unlike
+        torch.optim, which keeps it until ``zero_grad()`` -- so this is for the replayed train step, where nobody looks
+        (two fills of 47 + 94 MB sat at the start of every step).  Switching it on zeroes the arenas once, eagerly."""
+        on = bool(on)
+        if on and not self.flat.zero_in_step:
+            self.flat.grad.zero_()
+            if self.pack is not None:
+                self.pack.dw.zero_()
+        self.flat.zero_in_step = on
+        if self.pack is not None:
+            self.pack.zero_in_step = on
 
     def finalize_grads(self):
         """Call between backward() and step() / the gradient all-reduce: joins the streams on which backward nodes wrote
@@ -265,11 +286,11 @@ class FusedAdamW:
 
     def launch(self, grad_scale: float = 1.0):
         f = self.flat
-        check(_lib.lib().stegan_adamw_step(
+        check(_lib.lib().stegan_adamw_step_z(
             C.c_void_p(f.flat.data_ptr()), C.c_void_p(f.grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
             C.c_void_p(self.exp_avg_sq.data_ptr()), f.numel, C.c_void_p(self._hyper.data_ptr()),
-            self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale,
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step")
+            self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, int(f.zero_in_step),
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step_z")
         self.flat.epoch += 1           # parameters changed behind torch's back: this network's prepared copies are stale
         if self.pack is not None:
             self.pack.invalidate()

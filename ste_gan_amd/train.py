@@ -125,6 +125,7 @@ class GANTrainStep:
         """Generator forward, the D-independent losses (side stream), the discriminator step up to its gradients."""
         cfg, t = self.cfg, self.cfg.train
         netG, netD = self.netG, self.netD
+        ops.zero_pool_begin(batch_dict[DataType.REAL_EMG].device)     # one fill for the step's zero-initialised scratch
         self.optD.zero_grad()
         self.optG.zero_grad()
         x_t = batch_dict[DataType.REAL_EMG]
@@ -294,6 +295,7 @@ class GANTrainStep:
         else:
             self.optG.step(finalized=True)
         ops.mark("G optimiser done")
+        ops.zero_pool_end()
         out = self._st["out"]
         self._st = None                     # drop the step's tensors
         self.last = out
@@ -344,6 +346,10 @@ class GraphedTrainStep:
                 step(self.static)              # (every rank runs the same number of exchanges)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # the replayed step zeroes its gradient arenas inside the optimiser kernels instead of with fills at its start
+        if os.environ.get("STEGAN_ZERO_IN_STEP", "1") != "0":
+            step.optG.set_zero_in_step(True)
+            step.optD.set_zero_in_step(True)
         self._counts = (step.optG.step_count, step.optD.step_count)
         # Prepared weight copies inside the captured step.  The generator's are re-derived at its start (its weights changed
         # at the end of the previous step): invalidate them so that the capture records the launches.  The discriminator's

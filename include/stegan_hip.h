@@ -203,6 +203,10 @@ int stegan_adamw_step_z(float* params, float* grads, float* exp_avg, float* exp_
 int stegan_wn_backward_z(int32_t n, const float* const* v, const float* const* g, float* const* dw, float* const* dv,
                          float* const* dg, const int32_t* rows, const int32_t* cols, int32_t max_rows, int32_t zero_dw,
                          void* stream);
+/* Planning hint for the bf16 conv launches ENQUEUED WHILE IT IS SET (host-side state, not stream ordered): slot_weight > 0
+ * makes the tile / split-K choice count the chip capacity a launch occupies (blocks x block time) beside its latency --
+ * for a branch of the step that has slack.  0 restores the default. */
+int stegan_conv_plan_hint(float slot_weight);
 /* diagnostic time mark: a one-lane kernel stores the 100 MHz real-time counter into *slot (scripts/step_marks.py) */
 int stegan_timestamp(uint64_t* slot, void* stream);
 /* the elementwise producers of the path with an image of their output beside it (out_h / dx_h / y_h / dz_h / dqkv_h nullable;

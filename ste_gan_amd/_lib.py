@@ -54,6 +54,7 @@ SIGNATURES = {
     "stegan_conv1d_fwd_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_bwd_data_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_timestamp": [_P, _P],
+    "stegan_conv_plan_hint": [C.c_float],
     "stegan_adamw_step_z": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P],
     "stegan_wn_backward_z": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "stegan_act_bwd_add_img": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],

@@ -843,6 +843,10 @@ bool xv_eligible(int Tsrc, const void* src, bool fwd_ups) {
     return (Tsrc % 4 == 0 && ((uintptr_t)src % 16) == 0) || getenv("STEGAN_BF16_XVRAG");
 }
 
+// plan hint (stegan_conv_plan_hint): extra weight of the slot time in the cost model for the launches planned while it is
+// set -- a branch of the step that has slack (the frozen-encoder side branch) can trade its own latency for chip capacity
+double g_plan_slot_w = 0.0;
+
 struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, NG, ntW, xit, wit, span; size_t lds; bool ok; };
 
 // geometry for one (TM, TN): the largest channel chunk whose tiles fit (cch_max caps it: experiments)
@@ -1028,7 +1032,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             // (STEGAN_BF16_SLOT_W weighs it; 0 = latency only, the round-2 model)
             static const char* env_sw = getenv("STEGAN_BF16_SLOT_W");
             static const double slot_w = env_sw ? atof(env_sw) : 0.0;
-            t += slot_w * (double)blocks * (5.0 + per * t_iter) / 512.0;
+            t += (slot_w + g_plan_slot_w) * (double)blocks * (5.0 + per * t_iter) / 512.0;
             if (t < best - 1e-9) { best = t; TM = tm; TN = tn; splits = sp; gm = g2; }
         }
     }
@@ -1158,6 +1162,11 @@ int launch_multi_h(MultiCollectH& mc, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int stegan_conv_plan_hint(float slot_weight) {
+    g_plan_slot_w = slot_weight > 0.f ? (double)slot_weight : 0.0;
+    return STEGAN_OK;
+}
 
 extern "C" int64_t stegan_conv_prep_bf16_elems(const stegan_conv_desc* d, int32_t which) {
     if (!d || d->groups <= 0 || d->K <= 0) return -1;

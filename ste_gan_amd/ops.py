@@ -275,6 +275,11 @@ def mark(name: str) -> None:
     check(_lib.lib().stegan_timestamp(C.c_void_p(MARKS["buf"].data_ptr() + 8 * i), _stream()), "stegan_timestamp")
 
 
+def plan_hint(slot_weight: float) -> None:
+    """See stegan_conv_plan_hint (include/stegan_hip.h)."""
+    check(_lib.lib().stegan_conv_plan_hint(float(slot_weight)), "stegan_conv_plan_hint")
+
+
 def bump_weight_epoch() -> None:
     global WEIGHT_EPOCH
     WEIGHT_EPOCH += 1

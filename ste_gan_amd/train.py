@@ -156,9 +156,12 @@ class GANTrainStep:
         side = self._side_stream() if self.overlap_encoder else None
         loss_side = None
         g_side = None
+        side_w = float(os.environ.get("STEGAN_SIDE_SLOT_W", "0"))
         if side is not None:
             side.wait_stream(main_stream)                      # x_pred, the batch
             torch.cuda.set_stream(side)
+            if side_w > 0:
+                ops.plan_hint(side_w)              # the branch has slack: plan its convs for chip capacity, not latency
         try:
             xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
             ops.mark("side: start")
@@ -191,6 +194,8 @@ class GANTrainStep:
         finally:
             if side is not None:
                 torch.cuda.set_stream(main_stream)
+                if side_w > 0:
+                    ops.plan_hint(0.0)
 
         # ---- discriminator step (train.py:189-199)
         if t.loss_adversarial:

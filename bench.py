@@ -34,7 +34,12 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3,   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
                     "bf16": 2500.0}  # ... v_mfma_f32_32x32x16_bf16, dense (~2.5 PF; never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
 STEP_GFLOP = 1016.9                 # required nominal work of one step at B=64, T_emg=192 (508.4 GMAC)
-STEP_GBYTES = 6.58                  # ... layer-boundary traffic with fp32 activations (what this path stores)
+STEP_GBYTES = 6.58                  # ... layer-boundary traffic with fp32 activations (SURVEY's model: every activation
+                                    # written and read once as fp32, no bf16 images, no split-K slabs)
+try:                                # counters of the committed rocprofv3 --pmc passes over this command (scripts/pmc_summary.py)
+    PMC = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
+except (OSError, ValueError):
+    PMC = {}
 
 
 def make_cfg(workload):
@@ -75,11 +80,69 @@ def build_step(cfg, device):
     return step
 
 
-def cpu_baseline(steps=2):
-    """Oracle (CPU restatement of the reference step, torch ATen/oneDNN fp32) on a bounded sample: B=64, 1+steps steps."""
+def step_rooflines(sec_per_step, dtype):
+    """Whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds).  The HBM side is
+    reported twice: on SURVEY's layer-boundary model, and on the bytes the kernels actually moved through the L2's memory side
+    (FETCH_SIZE x 2 + WRITE_SIZE summed over every kernel of a step, PMC passes) -- the latter includes the bf16 images,
+    split-K and weight-gradient slabs, optimiser state and every re-read the XCD L2s did not absorb; the Infinity Cache
+    serves part of it, so it is an upper bound of the HBM traffic proper."""
+    r = {"algorithmic_gflop": STEP_GFLOP, "layer_boundary_gbytes": STEP_GBYTES,
+         "per_gpu_tflops": round(STEP_GFLOP / (1e3 * sec_per_step), 2),
+         "mfma_frac": round(STEP_GFLOP / (1e3 * sec_per_step) / MFMA_PEAK_TFLOPS[dtype], 4),
+         "per_gpu_gbytes_per_s": round(STEP_GBYTES / sec_per_step, 1),
+         "hbm_frac": round(STEP_GBYTES / sec_per_step / HBM_PEAK_GBS, 4)}
+    moved = PMC.get("hbm_bytes_per_step")
+    if moved and dtype == "bf16":
+        r["moved_gbytes_per_step_pmc"] = round(moved / 1e9, 3)
+        r["hbm_frac_on_bytes_moved"] = round(moved / 1e9 / sec_per_step / HBM_PEAK_GBS, 4)
+        r["hbm_frac"] = r["hbm_frac_on_bytes_moved"]
+        r["hbm_frac_layer_boundary_model"] = round(STEP_GBYTES / sec_per_step / HBM_PEAK_GBS, 4)
+    r["binding"] = "neither: the step is bound by launch / per-block latency chains (DESIGN.md section 6)"
+    return r
+
+
+def host_cpu():
+    """(physical cores, model name) of the host from /proc/cpuinfo (torch.get_num_threads() counts SMT siblings on some
+    hosts and a cgroup share on others: the physical count is what the threads were pinned to below)."""
+    cores, model, phys, core = set(), "unknown", None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None and core is not None:
+                cores.add((phys, core)); phys = core = None
+        if phys is not None and core is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    n = len(cores) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))          # never more threads than this process may run on
+    except AttributeError:
+        pass
+    try:                                                  # ... nor than its cgroup's CPU quota pays for
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n), model
+
+
+def cpu_baseline(steps=5, warm=2):
+    """Oracle (CPU restatement of the reference step, torch ATen/oneDNN fp32) on a bounded sample: B=64, warm + steps steps
+    (2 warm-up + >= 5 timed), one thread per physical core."""
     from oracle import shapes as oshapes
     from oracle import stegan_oracle as O
     torch.manual_seed(0)
+    cores, model = host_cpu()
+    torch.set_num_threads(cores)
 
     def rnd(shapes):
         sd = {}
@@ -103,14 +166,18 @@ def cpu_baseline(steps=2):
     batch = {"su": torch.randn(B, T_SU, 256, generator=gen), "x_real": torch.tanh(torch.randn(B, T_EMG, 8, generator=gen)),
              "sess": torch.randint(0, 17, (B,), generator=gen), "phonemes": torch.randint(0, 48, (B, T_SU), generator=gen)}
     batch["feats"] = batch["su"]
-    O.train_step(g_sd, d_sd, e_sd, og, od, batch)                      # warm-up
-    t0 = time.time()
-    for _ in range(steps):
+    for _ in range(warm):
         O.train_step(g_sd, d_sd, e_sd, og, od, batch)
-    dt = (time.time() - t0) / steps
-    return {"value": B * T_EMG / dt, "unit": "EMG frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} full train steps at B=64, T_emg=192 after 1 warm-up (oracle/stegan_oracle.py train_step, "
-                      f"torch-CPU fp32, {dt:.2f} s/step)"}
+    times = []
+    for _ in range(steps):
+        t0 = time.time()
+        O.train_step(g_sd, d_sd, e_sd, og, od, batch)
+        times.append(time.time() - t0)
+    dt = sum(times) / steps
+    return {"value": B * T_EMG / dt, "unit": "EMG frames/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "sample": f"{steps} full train steps at B=64, T_emg=192 after {warm} warm-up steps (oracle/stegan_oracle.py "
+                      f"train_step, torch-CPU fp32, {cores} threads = physical cores; mean {dt:.2f} s/step, "
+                      f"min {min(times):.2f}, max {max(times):.2f})"}
 
 
 def gen_infer(args, cfg, device, quiet=False):
@@ -188,7 +255,7 @@ def launch_ranks(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -316,24 +383,40 @@ def main():
                       round(2 * macs / (ms * 1e-3) / 1e12, 1), file=sys.stderr)
         name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
         raw_avg_ms = a["ms"] / a["launches"]
-        for v in agg.values():                             # net of the event bracket (see above)
-            v["ms"] = max(v["ms"] - event_overhead_ms * v["launches"], 0.25 * v["ms"])
+        for v in agg.values():
+            if v["kernel_timed"] == v["launches"]:          # the dispatches' own begin / end timestamps: no bracket inside
+                v["ms"], v["timing"] = v["kernel_ms"], "kernel timestamps (hipExtLaunchKernelGGL start / stop events)"
+            else:                                          # net of the event bracket (see above)
+                v["ms"], v["timing"] = max(v["ms"] - event_overhead_ms * v["launches"], 0.25 * v["ms"]), "event bracket, net"
         avg_ms = a["ms"] / a["launches"]
         flops_per_launch = 2.0 * a["nominal_macs"] / a["launches"]
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
         all_ms = sum(v["ms"] for v in agg.values())
         all_fl = 2.0 * sum(v["nominal_macs"] for v in agg.values())
-        traffic = None      # HBM bytes per launch from the committed PMC passes (bench.py itself cannot run rocprofv3)
+        # HBM-side bytes and matrix-pipe busy fraction from the committed PMC passes over this same command (bench.py cannot
+        # run rocprofv3 on itself): profiles/r03_pmc_summary.json, written by scripts/pmc_summary.py from the raw per-dispatch
+        # rows kept beside it.  traffic = the kernel family's average per launch in that run; traffic_over_algorithmic compares
+        # per-STEP totals (the family's PMC bytes per step / the algorithmic bytes of the same launches counted live here), so
+        # it does not depend on how many problems a multi-problem launch carried.
+        traffic = mfma_busy = over = None
+        fam_key = "conv_wgrad_bf16" if "wgrad_bf16" in name else name.split("<")[0]
+        fam_live = [v for k, v in agg.items() if ("wgrad_bf16" in k) == ("wgrad_bf16" in name) and k.split("<")[0] == name.split("<")[0]]
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-            key = name.split("<")[0]
-            traffic = tj[key]["hbm_bytes_per_launch"]
-        except Exception:
+            fam = PMC["families"][fam_key]
+            traffic = fam["hbm_bytes_per_launch"]
+            mfma_busy = fam["mfma_busy_frac"]
+            alg_step = sum(v["alg_bytes"] for v in fam_live) / args.profile_steps
+            over = round(fam["hbm_bytes_per_step"] / alg_step, 2) if alg_step else None
+        except (KeyError, TypeError):
             pass
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_over_algorithmic": over, "mfma_busy_frac": mfma_busy,
+                "algorithmic_bytes_per_launch": int(a["alg_bytes"] / a["launches"]),
+                "counters": "profiles/r03_pmc_summary.json (rocprofv3 --pmc passes over this command; raw rows beside it)",
                 "launches_per_step": a["launches"] // args.profile_steps, "avg_launch_us": round(avg_ms * 1e3, 2),
+                "timing": a["timing"],
                 "avg_launch_us_with_event_bracket": round(raw_avg_ms * 1e3, 2),
                 "event_bracket_us": round(event_overhead_ms * 1e3, 2),
                 "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 4),
@@ -383,12 +466,7 @@ def main():
                            "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around 2 eager RCCL all-reduces") if graphed else "eager"},
                 "roofline": roof,
                 # whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds)
-                "step_rooflines": {"algorithmic_gflop": STEP_GFLOP, "layer_boundary_gbytes": STEP_GBYTES,
-                                   "per_gpu_tflops": round(STEP_GFLOP / (1e3 * dt / args.steps), 2),
-                                   "mfma_frac": round(STEP_GFLOP / (1e3 * dt / args.steps) / MFMA_PEAK_TFLOPS[args.dtype], 4),
-                                   "per_gpu_gbytes_per_s": round(STEP_GBYTES / (dt / args.steps), 1),
-                                   "hbm_frac": round(STEP_GBYTES / (dt / args.steps) / HBM_PEAK_GBS, 4),
-                                   "binding": "neither: the step is bound by launch / per-block latency chains (DESIGN.md section 6)"},
+                "step_rooflines": step_rooflines(dt / args.steps, args.dtype),
                 "fp32_parity_path": f32_path, "cpu_baseline": cpu, "generator_inference": gi,
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)

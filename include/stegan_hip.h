@@ -207,6 +207,13 @@ int stegan_wn_backward_z(int32_t n, const float* const* v, const float* const* g
  * makes the tile / split-K choice count the chip capacity a launch occupies (blocks x block time) beside its latency --
  * for a branch of the step that has slack.  0 restores the default. */
 int stegan_conv_plan_hint(float slot_weight);
+/* kernel-timestamp timing of the bf16 conv / weight-gradient launches (bench.py's roofline pass): while on, each such launch
+ * carries a start / stop event pair holding the dispatch's own begin / end timestamps (hipExtLaunchKernelGGL), so a duration is
+ * the kernel's, without the marker packets and dispatch gaps of an event bracket.  _count: pairs recorded so far;
+ * _collect: waits for them, writes their durations (ms, launch order) and empties the list.  Not for use under stream capture. */
+int stegan_kernel_timing(int32_t on);
+int64_t stegan_kernel_timing_count(void);
+int stegan_kernel_timing_collect(float* ms, int64_t cap);
 /* diagnostic time mark: a one-lane kernel stores the 100 MHz real-time counter into *slot (scripts/step_marks.py) */
 int stegan_timestamp(uint64_t* slot, void* stream);
 /* the elementwise producers of the path with an image of their output beside it (out_h / dx_h / y_h / dz_h / dqkv_h nullable;

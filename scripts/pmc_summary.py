@@ -80,6 +80,13 @@ def main():
             "fetch_kib_raw_per_launch": round(c.get("FETCH_SIZE", 0.0) / n, 1),
             "write_kib_per_launch": round(c.get("WRITE_SIZE", 0.0) / n, 1),
             "hbm_bytes_per_launch": int(hbm / n)}
+    # steps in the run = optimiser launches / 2 (one AdamW launch per network and step, eager warm-ups and replays alike)
+    nsteps = max(1, launches.get("adamw", 0) // 2)
+    res["steps_counted"] = nsteps
+    for fam, v in res["families"].items():
+        v["hbm_bytes_per_step"] = int(v["hbm_bytes_per_launch"] * v["launches"] / nsteps)
+        v["launches_per_step"] = round(v["launches"] / nsteps, 1)
+    res["hbm_bytes_per_step"] = int(tot_bytes / nsteps)
     res["hbm_bytes_all_kernels_whole_run"] = int(tot_bytes)
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

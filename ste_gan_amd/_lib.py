@@ -54,6 +54,8 @@ SIGNATURES = {
     "stegan_conv1d_fwd_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_bwd_data_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_timestamp": [_P, _P],
+    "stegan_kernel_timing": [_I32],
+    "stegan_kernel_timing_collect": [_P, _I64],
     "stegan_conv_plan_hint": [C.c_float],
     "stegan_adamw_step_z": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P],
     "stegan_wn_backward_z": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
@@ -125,7 +127,8 @@ INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_conv_prep_floats": [_D, _I32],
                 "stegan_conv_prep_bf16_elems": [_D, _I32],
                 "stegan_conv_prep_bf16_tiles": [_D],
-                "stegan_conv_workspace_floats": [_D, _I32]}
+                "stegan_conv_workspace_floats": [_D, _I32],
+                "stegan_kernel_timing_count": []}
 
 _lib = None
 

@@ -10,6 +10,23 @@
         if (!(cond)) return STEGAN_E_ARG; \
     } while (0)
 
+// Kernel-timestamp timing of the conv launches (stegan_kernel_timing_*, conv_bf16.hip): while it is on, the bf16 conv and
+// weight-gradient launches go through hipExtLaunchKernelGGL with a start / stop event pair, which carry the dispatch's OWN
+// begin / end timestamps (what the rocprofv3 kernel trace reports) -- no marker packets or dispatch gaps inside the bracket.
+#include <hip/hip_ext.h>
+bool stegan_timing_on();
+void stegan_timing_pair(hipEvent_t* start, hipEvent_t* stop);      // a fresh pair, appended to the list of this run
+#define STEGAN_TIMED_LAUNCH(kernel, grid, block, lds, stream, ...)                                             \
+    do {                                                                                                        \
+        if (stegan_timing_on()) {                                                                               \
+            hipEvent_t e0__, e1__;                                                                              \
+            stegan_timing_pair(&e0__, &e1__);                                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0__, e1__, 0, __VA_ARGS__);                \
+        } else {                                                                                                \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                  \
+        }                                                                                                       \
+    } while (0)
+
 #define STEGAN_LAUNCH_CHECK()                 \
     do {                                      \
         hipError_t e__ = hipGetLastError();   \

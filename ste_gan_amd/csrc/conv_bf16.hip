@@ -908,13 +908,48 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
     return fallback;
 }
 
+}  // namespace
+
+// ---- kernel-timestamp timing (common.h) -----------------------------------------------------------------------------------
+#include <vector>
+static bool g_timing = false;
+static std::vector<hipEvent_t> g_timing_events;        // start, stop, start, stop, ...
+bool stegan_timing_on() { return g_timing; }
+void stegan_timing_pair(hipEvent_t* start, hipEvent_t* stop) {
+    (void)hipEventCreate(start);
+    (void)hipEventCreate(stop);
+    g_timing_events.push_back(*start);
+    g_timing_events.push_back(*stop);
+}
+extern "C" int stegan_kernel_timing(int on) {
+    g_timing = on != 0;
+    return STEGAN_OK;
+}
+extern "C" int64_t stegan_kernel_timing_count() { return (int64_t)(g_timing_events.size() / 2); }
+extern "C" int stegan_kernel_timing_collect(float* ms, int64_t cap) {
+    const int64_t n = (int64_t)(g_timing_events.size() / 2);
+    if (n > cap) return STEGAN_E_ARG;
+    for (int64_t i = 0; i < n; ++i) {
+        hipEvent_t e0 = g_timing_events[2 * i], e1 = g_timing_events[2 * i + 1];
+        hipError_t e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[i], e0, e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (e != hipSuccess) { g_timing_events.clear(); return (int)e; }
+    }
+    g_timing_events.clear();
+    return STEGAN_OK;
+}
+
+namespace {
+
 template <int TM, int TN, bool XV, bool XH = false>
 void launch_variant(int logNCB, dim3 grid, size_t lds, hipStream_t s, const HP& h) {
     switch (logNCB) {
-        case 0: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 0, XV, XH>), grid, dim3(512), lds, s, h); break;
-        case 1: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 1, XV, XH>), grid, dim3(512), lds, s, h); break;
-        case 2: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 2, XV, XH>), grid, dim3(512), lds, s, h); break;
-        default: hipLaunchKernelGGL((conv_bf16_kernel<TM, TN, 3, XV, XH>), grid, dim3(512), lds, s, h); break;
+        case 0: STEGAN_TIMED_LAUNCH((conv_bf16_kernel<TM, TN, 0, XV, XH>), grid, dim3(512), lds, s, h); break;
+        case 1: STEGAN_TIMED_LAUNCH((conv_bf16_kernel<TM, TN, 1, XV, XH>), grid, dim3(512), lds, s, h); break;
+        case 2: STEGAN_TIMED_LAUNCH((conv_bf16_kernel<TM, TN, 2, XV, XH>), grid, dim3(512), lds, s, h); break;
+        default: STEGAN_TIMED_LAUNCH((conv_bf16_kernel<TM, TN, 3, XV, XH>), grid, dim3(512), lds, s, h); break;
     }
 }
 

@@ -620,14 +620,14 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
         attr = true;
     }
     if (h.xh) {
-        hipLaunchKernelGGL((conv_wgrad_bf16_img_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
+        STEGAN_TIMED_LAUNCH((conv_wgrad_bf16_img_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
         return;
     }
     static const bool no_one = getenv("STEGAN_BF16_WGRAD_NO_ONE") != nullptr;       // experiments
     if (xv && h.ait <= 1 && h.xit <= 1 && !no_one)
-        hipLaunchKernelGGL((conv_wgrad_bf16_one_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
-    else if (xv) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(512), lds, s, h, dw_direct, bw);
-    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(512), lds, s, h, dw_direct, bw);
+        STEGAN_TIMED_LAUNCH((conv_wgrad_bf16_one_kernel<TM, TN, KT>), grid, dim3(512), lds, s, h, dw_direct, bw);
+    else if (xv) STEGAN_TIMED_LAUNCH((conv_wgrad_bf16_kernel<TM, TN, KT, true>), grid, dim3(512), lds, s, h, dw_direct, bw);
+    else STEGAN_TIMED_LAUNCH((conv_wgrad_bf16_kernel<TM, TN, KT, false>), grid, dim3(512), lds, s, h, dw_direct, bw);
 }
 
 }  // namespace
@@ -779,7 +779,7 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
                 (void)hipFuncSetAttribute((const void*)conv_wgrad_bf16_img_kernel<2, 2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr223 = true;
             }
-            hipLaunchKernelGGL((conv_wgrad_bf16_img_kernel<2, 2, 3>), grid, dim3(512), lds, s, h, dw_direct, bw);
+            STEGAN_TIMED_LAUNCH((conv_wgrad_bf16_img_kernel<2, 2, 3>), grid, dim3(512), lds, s, h, dw_direct, bw);
         }
         else if (TM == 2) wgh_launch<2, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
         else wgh_launch<1, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);

@@ -71,8 +71,19 @@ def _desc(cfg: ConvCfg, B: int, tin: int, tout: int) -> ConvDesc:
 class ConvProfiler:
     """Collects (kernel instantiation, nominal MACs, live MACs, start/end event) for every conv launch."""
 
-    def __init__(self):
+    def __init__(self, kernel_timestamps: bool = True):
         self.records = []
+        # durations from the dispatches' own begin / end timestamps (stegan_kernel_timing, bf16 conv and weight-gradient
+        # kernels) beside the event brackets: record i owns the pairs [first, first + n) of the library's list
+        self.kernel_timestamps = kernel_timestamps
+        self.pairs = []
+        if kernel_timestamps:
+            check(_lib.lib().stegan_kernel_timing(1), "stegan_kernel_timing")
+
+    def close(self):
+        if self.kernel_timestamps:
+            check(_lib.lib().stegan_kernel_timing(0), "stegan_kernel_timing")
+            self.kernel_timestamps = False
 
     def plan(self, d: ConvDesc, mode: int):
         tile, splits, live = C.c_int32(), C.c_int32(), C.c_int64()
@@ -81,16 +92,46 @@ class ConvProfiler:
         nominal = d.B * d.Tout * d.Cout * (d.Cin // d.groups) * d.K
         return f"conv_igemm_kernel<{mode}, {tile.value // 64}, {tile.value // 64}>", nominal, live.value
 
+    def kernel_ms(self):
+        """Per record: the summed kernel-timestamp durations of its timed launches (ms), or None where it had none."""
+        n = _lib.lib().stegan_kernel_timing_count()
+        buf = (C.c_float * max(1, n))()
+        check(_lib.lib().stegan_kernel_timing_collect(buf, n), "stegan_kernel_timing_collect")
+        return [sum(buf[f:f + c]) if c and f + c <= n else None for f, c in self.pairs]
+
     def summary(self):
         torch.cuda.synchronize()
+        kms = self.kernel_ms() if self.pairs else []
+        self.close()
         agg = {}
-        for name, nominal, live, e0, e1, *_ in self.records:
-            a = agg.setdefault(name, dict(launches=0, ms=0.0, nominal_macs=0, live_macs=0))
+        for i, (name, nominal, live, e0, e1, *rest) in enumerate(self.records):
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, nominal_macs=0, live_macs=0, alg_bytes=0, kernel_ms=0.0,
+                                          kernel_timed=0))
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
+            if i < len(kms) and kms[i] is not None:
+                a["kernel_ms"] += kms[i]
+                a["kernel_timed"] += 1
             a["nominal_macs"] += nominal
             a["live_macs"] += live
+            if rest:
+                a["alg_bytes"] += self.alg_bytes(rest[0])
         return agg
+
+    @staticmethod
+    def alg_bytes(shape) -> int:
+        """Bytes a launch must move if every operand is read once and every result written once, as this path stores them:
+        activations and their gradients read as bf16 images (2 B; 4 B in fp32 mode), weights 2 B (4 B), results written as
+        fp32 plus -- in bf16 mode -- the bf16 image for the next layer (6 B); weight gradients fp32."""
+        mode, B, Cin, Cout, K, stride, dil, groups, up, Tin, Tout = shape[:11]
+        e = 2 if COMPUTE_DTYPE == "bf16" else 4
+        o = 6 if COMPUTE_DTYPE == "bf16" else 4
+        w, x, y = Cout * (Cin // groups) * K, B * Cin * Tin, B * Cout * Tout
+        if mode == 0:
+            return e * (x + w) + o * y
+        if mode == 1:
+            return e * (y + w) + o * x
+        return e * (x + y) + 4 * w
 
 
 PROFILER: Optional[ConvProfiler] = None
@@ -116,11 +157,13 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     elif mode == 2:
         name = "bwd_weight (conv_wgrad_kernel | conv_igemm_kernel<2>)"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    first = _lib.lib().stegan_kernel_timing_count() if PROFILER.kernel_timestamps else 0
     e0.record()
     rc = fn()
     e1.record()
     if rc != 1:
         LAST_CONV_KERNEL = kind
+        PROFILER.pairs.append((first, (_lib.lib().stegan_kernel_timing_count() - first) if PROFILER.kernel_timestamps else 0))
         PROFILER.records.append((name, nominal, live, e0, e1,
                                  (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout,
                                   d.pad, d.in_act, d.out_act)))

@@ -87,6 +87,10 @@ class GANTrainStep:
         # autograd accumulation kernel per feature map (ops.fm_fold_begin)
         self.fold_fm = os.environ.get("STEGAN_FOLD_FM", "1") != "0"
         self._side = None
+        # the side branch in two halves, each forked and joined inside its phase: forward + losses beside the discriminator
+        # step (phase_d), backward beside the D update and the generator-side discriminator passes (phase_g).  Set by
+        # GraphedTrainStep under torch.distributed, where the phases are separate hipGraphs around the gradient exchanges
+        self.split_side = False
 
     def _side_stream(self):
         if self._side is None:
@@ -123,24 +127,8 @@ class GANTrainStep:
 
     def phase_d(self, batch_dict: Dict[str, torch.Tensor]) -> None:
         """Generator forward, the D-independent losses (side stream), the discriminator step up to its gradients."""
-        cfg, t = self.cfg, self.cfg.train
-        netG, netD = self.netG, self.netD
-        ops.zero_pool_begin(batch_dict[DataType.REAL_EMG].device)     # one fill for the step's zero-initialised scratch
-        self.optD.zero_grad()
-        self.optG.zero_grad()
-        x_t = batch_dict[DataType.REAL_EMG]
-        speech_units_t = batch_dict[DataType.SPEECH_UNITS]
-        sess_idx = batch_dict[DataType.SESSION_INDEX]
-        spk_mode_idx = batch_dict[DataType.SPEAKING_MODE_INDEX]
-        phoneme_targets = batch_dict[DataType.PHONEMES]
-        s_t1 = speech_units_t if self.speech_feature_type == DataType.SPEECH_UNITS else batch_dict[self.speech_feature_type]
-        out: Dict[str, torch.Tensor] = {}
-
-        ops.mark("step start")
-        netG.train()
-        x_pred_t = netG(s_t1, sess_idx, spk_mode_idx)                                   # train.py:182
-        ops.mark("G forward done")
-
+        self._p_fwd(batch_dict)
+        st = self._st
         # ---- D-independent generator losses (multi-TD, frozen EMG encoder) and THEIR gradient w.r.t. the generated EMG.
         # The reference computes them inside the generator step (train.py:213-256), after the discriminator update, but
         # they read nothing the discriminator step writes.  Here they run -- forward AND backward, down to d loss / d x_pred
@@ -152,52 +140,106 @@ class GANTrainStep:
         # generator step and relied on loss_G.backward() to overlap the two sub-graphs; the round-2 kernel trace showed the
         # captured graph running them one after the other: 0.8 ms of encoder forward and 1.5 ms of encoder backward with
         # every other queue idle.)
-        main_stream = torch.cuda.current_stream()
+        main_stream = st["main_stream"]
         side = self._side_stream() if self.overlap_encoder else None
-        loss_side = None
-        g_side = None
         side_w = float(os.environ.get("STEGAN_SIDE_SLOT_W", "0"))
         if side is not None:
             side.wait_stream(main_stream)                      # x_pred, the batch
             torch.cuda.set_stream(side)
             if side_w > 0:
                 ops.plan_hint(side_w)              # the branch has slack: plan its convs for chip capacity, not latency
+        split = side is not None and self.split_side
         try:
-            xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
-            ops.mark("side: start")
-            if t.loss_multi_td_error:
-                td_error = self.multi_td_loss(x_t, xp)
-                loss_side = t.loss_multi_td_weight * td_error
-                out["multi_td"] = td_error.detach()
-            ops.mark("side: TD done")
-            if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
-                enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets)
-                if t.loss_speech_unit_error:
-                    term = t.loss_speech_unit_weight * enc_out.speech_unit_loss
-                    loss_side = term if loss_side is None else loss_side + term
-                    out["speech_unit"] = enc_out.speech_unit_loss.detach()
-                if t.loss_phoneme_error:
-                    term = t.loss_phoneme_weight * enc_out.phoneme_loss
-                    loss_side = term if loss_side is None else loss_side + term
-                    out["phoneme"] = enc_out.phoneme_loss.detach()
-                out["phoneme_counters"] = enc_out._counters
-            if t.loss_waveform_error:
-                wave_loss = ops.mse_loss(xp, x_t)
-                term = t.loss_waveform_weight * wave_loss
-                loss_side = term if loss_side is None else loss_side + term
-                out["waveform"] = wave_loss.detach()
-            ops.mark("side: encoder forward + losses done")
-            if loss_side is not None:
-                (g_side,) = torch.autograd.grad(loss_side, xp)
-                loss_side = loss_side.detach()
-            ops.mark("side: backward done")
+            if split:
+                self._p_side_fwd()
+            else:
+                self._p_side()
         finally:
             if side is not None:
                 torch.cuda.set_stream(main_stream)
                 if side_w > 0:
                     ops.plan_hint(0.0)
+        self._p_disc()
+        if side is not None and (self.comm is not None or split):
+            # under torch.distributed this phase ends with the side stream joined: the gradient exchange that follows is
+            # issued from the main stream, and a captured phase (GraphedTrainStep) must end with every forked stream joined.
+            # The branch's BACKWARD pass then runs beside the first half of phase_g (split_side); without the split the
+            # phase lasts until the whole branch is done -- 1.3 ms after the discriminator's gradients are ready.
+            main_stream.wait_stream(side)
+            side = None
+        st["side"] = side
+        st["side_bwd_pending"] = split
 
-        # ---- discriminator step (train.py:189-199)
+    def _p_fwd(self, batch_dict: Dict[str, torch.Tensor]) -> None:
+        """Start of a step: zero scratch / gradient arenas, generator forward (train.py:182)."""
+        netG = self.netG
+        ops.zero_pool_begin(batch_dict[DataType.REAL_EMG].device)     # one fill for the step's zero-initialised scratch
+        self.optD.zero_grad()
+        self.optG.zero_grad()
+        speech_units_t = batch_dict[DataType.SPEECH_UNITS]
+        s_t1 = speech_units_t if self.speech_feature_type == DataType.SPEECH_UNITS else batch_dict[self.speech_feature_type]
+        ops.mark("step start")
+        netG.train()
+        x_pred_t = netG(s_t1, batch_dict[DataType.SESSION_INDEX], batch_dict[DataType.SPEAKING_MODE_INDEX])   # train.py:182
+        ops.mark("G forward done")
+        self._st = dict(out={}, x_pred_t=x_pred_t, x_t=batch_dict[DataType.REAL_EMG], side=None,
+                        main_stream=torch.cuda.current_stream(), loss_side=None, g_side=None,
+                        speech_units_t=speech_units_t, phoneme_targets=batch_dict[DataType.PHONEMES])
+
+    def _p_side_fwd(self) -> None:
+        """The D-independent generator losses (forward), on the CURRENT stream ..."""
+        t = self.cfg.train
+        st = self._st
+        out, x_pred_t, x_t = st["out"], st["x_pred_t"], st["x_t"]
+        speech_units_t, phoneme_targets = st["speech_units_t"], st["phoneme_targets"]
+        loss_side = None
+        xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
+        ops.mark("side: start")
+        if t.loss_multi_td_error:
+            td_error = self.multi_td_loss(x_t, xp)
+            loss_side = t.loss_multi_td_weight * td_error
+            out["multi_td"] = td_error.detach()
+        ops.mark("side: TD done")
+        if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
+            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets)
+            if t.loss_speech_unit_error:
+                term = t.loss_speech_unit_weight * enc_out.speech_unit_loss
+                loss_side = term if loss_side is None else loss_side + term
+                out["speech_unit"] = enc_out.speech_unit_loss.detach()
+            if t.loss_phoneme_error:
+                term = t.loss_phoneme_weight * enc_out.phoneme_loss
+                loss_side = term if loss_side is None else loss_side + term
+                out["phoneme"] = enc_out.phoneme_loss.detach()
+            out["phoneme_counters"] = enc_out._counters
+        if t.loss_waveform_error:
+            wave_loss = ops.mse_loss(xp, x_t)
+            term = t.loss_waveform_weight * wave_loss
+            loss_side = term if loss_side is None else loss_side + term
+            out["waveform"] = wave_loss.detach()
+        ops.mark("side: encoder forward + losses done")
+        st["loss_side"], st["xp"] = loss_side, xp
+
+    def _p_side_bwd(self) -> None:
+        """... and their gradient w.r.t. the generated EMG (the backward pass of the side branch)."""
+        st = self._st
+        loss_side, xp = st["loss_side"], st.pop("xp")
+        g_side = None
+        if loss_side is not None:
+            (g_side,) = torch.autograd.grad(loss_side, xp)
+            loss_side = loss_side.detach()
+        ops.mark("side: backward done")
+        st["loss_side"], st["g_side"] = loss_side, g_side
+
+    def _p_side(self) -> None:
+        self._p_side_fwd()
+        self._p_side_bwd()
+
+    def _p_disc(self) -> None:
+        """The discriminator step up to its finalized gradients (train.py:189-199)."""
+        t = self.cfg.train
+        netD = self.netD
+        st = self._st
+        out, x_pred_t, x_t = st["out"], st["x_pred_t"], st["x_t"]
         if t.loss_adversarial:
             if hasattr(netD, "forward_pair_logits"):
                 # train.py:190-196 on the concatenated batch: fake | real logits against zeros | ones, unsliced, one launch
@@ -220,22 +262,30 @@ class GANTrainStep:
             self.optD.finalize_grads()
             ops.mark("D step: gradients finalized")
             out["discriminator"] = loss_D.detach()
-        if side is not None and self.comm is not None:
-            # under torch.distributed the phases may be separate hipGraphs (GraphedTrainStep): a graph has to end with
-            # every forked stream joined.  The side branch is shorter than the discriminator step, so nothing is lost.
-            main_stream.wait_stream(side)
-            side = None
-        self._st = dict(out=out, x_pred_t=x_pred_t, x_t=x_t, side=side, main_stream=main_stream, loss_side=loss_side,
-                        g_side=g_side)
 
     def phase_g(self) -> None:
         """D's optimiser step (after its gradient exchange), the generator-side discriminator passes, the generator's
         backward pass up to its gradients."""
+        st = self._st
+        if st.get("side_bwd_pending"):
+            main_stream, side = st["main_stream"], self._side_stream()
+            side.wait_stream(main_stream)
+            torch.cuda.set_stream(side)
+            try:
+                self._p_side_bwd()             # (autograd runs each node on the stream of its forward: this side stream)
+            finally:
+                torch.cuda.set_stream(main_stream)
+            st["side"] = side                  # joined in _p_g2, in front of the generator's backward pass
+            st["side_bwd_pending"] = False
+        self._p_g1()
+        self._p_g2()
+
+    def _p_g1(self) -> None:
+        """D's optimiser step and the generator-side discriminator passes with the updated D, up to the D-side losses."""
         t = self.cfg.train
         netD = self.netD
         st = self._st
-        out, x_pred_t, x_t, side, main_stream = st["out"], st["x_pred_t"], st["x_t"], st["side"], st["main_stream"]
-        loss_side, g_side = st["loss_side"], st["g_side"]
+        out, x_pred_t, x_t = st["out"], st["x_pred_t"], st["x_t"]
         if t.loss_adversarial:
             if self.comm is not None:
                 self.comm.wait(getattr(self, "_d_handle", None))
@@ -265,6 +315,19 @@ class GANTrainStep:
                 loss_main = loss_feat_w if loss_main is None else loss_main + loss_feat_w
                 out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
             ops.mark("G step: losses done")
+        except BaseException:
+            _ops.fm_fold_abort()
+            self._set_d_grad(True)
+            raise
+        st["loss_main"], st["fold"] = loss_main, fold
+
+    def _p_g2(self) -> None:
+        """Join of the side branch, ONE backward pass through the generator for both gradient sources, its gradients."""
+        from . import ops as _ops
+        st = self._st
+        out, x_pred_t, side, main_stream = st["out"], st["x_pred_t"], st["side"], st["main_stream"]
+        loss_side, g_side, loss_main, fold = st["loss_side"], st["g_side"], st["loss_main"], st["fold"]
+        try:
             if side is not None:
                 main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
             ops.mark("G step: side joined")
@@ -286,6 +349,7 @@ class GANTrainStep:
         finally:
             _ops.fm_fold_abort()
             self._set_d_grad(True)
+        st["loss_main"] = None
         ops.mark("G step: backward done")
         self.optG.finalize_grads()
         ops.mark("G step: gradients finalized")
@@ -336,8 +400,8 @@ class GraphedTrainStep:
     graph (``stegan_adamw_advance``), so replays can queue arbitrarily far ahead of the GPU.  Requirement: fixed batch shapes.
 
     Single process: ONE graph.  Under torch.distributed (one process per GPU): THREE graphs -- the step's phases
-    (GANTrainStep.phase_d / phase_g / phase_opt), sharing one memory pool -- with the two RCCL gradient all-reduces launched
-    eagerly between them: collectives stay outside the captures, and an eager step would be bound by the host (22.7 ms of
+    (GANTrainStep.phase_d / phase_g / phase_opt), sharing one memory pool, the side branch cut in two so that no graph
+    waits for it (see __init__) -- with the two RCCL gradient all-reduces launched eagerly between them: collectives stay outside the captures, and an eager step would be bound by the host (22.7 ms of
     launch overhead against 8.8 ms of GPU time).
     """
 
@@ -378,6 +442,15 @@ class GraphedTrainStep:
             self.graphs = None
         else:
             step._d_handle = step._g_handle = None            # nothing to await inside the captures
+            # THREE graphs: phase_d | phase_g | phase_opt around the two exchanges.  The side branch (multi-TD + frozen
+            # encoder, forward and backward: 2.5 ms, the longest arm of the step) would make the first graph end 1.3 ms after
+            # the discriminator's gradients are ready if it ran there as a whole (round 2), so it is cut in two: forward +
+            # losses in the first graph beside the discriminator step, backward in the second beside the D update and the
+            # generator-side discriminator passes (GANTrainStep.split_side).  Measured on one GPU with a 1-rank RCCL group
+            # (scripts/ddp_graph_timing.py): see DESIGN.md.  (Tried and dropped: the branch as a FOURTH graph replayed on its own
+            # stream across the exchange -- 8.5 ms/step: streams map onto 4 hardware queues, the replay stream shared one with
+            # the discriminator graph's internal fork streams and the two ran one after the other.)
+            step.split_side = os.environ.get("STEGAN_SPLIT_SIDE", "1") != "0"
             g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, **mode):
                 step.phase_d(self.static)

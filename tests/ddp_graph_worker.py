@@ -1,5 +1,5 @@
-"""The three-graph replay under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
-(``parallel.shutdown``); run in-process by test_gpu_train_step.py::test_three_graph_replay_with_process_group_matches_golden
+"""The three-graph replay (side branch split over the first two; STEGAN_SPLIT_SIDE=0: whole in the first) under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
+(``parallel.shutdown``); run in-process by test_gpu_train_step.py::test_multi_graph_replay_with_process_group_matches_golden
 and usable as a script."""
 import os
 import sys

@@ -1,7 +1,7 @@
 """-m gpu: the data-parallel train step on the GPU kernels (VERDICT r02 "multi-rank correctness").
 
 Two ranks (gloo, both on the box's one card) each run ``GANTrainStep`` on HALF of a detfill batch -- eagerly, and as the
-three replayed hipGraphs around the two gradient exchanges -- for two optimiser steps.  Checked: the replicas' parameters
+three replayed hipGraphs (the side branch split over the first two) around the two gradient exchanges -- for two optimiser steps.  Checked: the replicas' parameters
 are bit-identical, and equal the single-process step on the WHOLE batch (every loss is a batch mean; the exchange
 averages the gradients) to 2e-5 in every tensor's norm and 2e-4 element-wise.  The ranks end through
 ``parallel.shutdown`` and must exit with code 0 (no os._exit escape)."""

@@ -275,14 +275,18 @@ def test_graph_replay_matches_golden(golden):
         close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
 
 
-def test_three_graph_replay_with_process_group_matches_golden():
+@pytest.mark.parametrize("split_side", ["1", "0"])
+def test_three_graph_replay_with_process_group_matches_golden(split_side, monkeypatch):
     """Under torch.distributed GraphedTrainStep captures the step's three phases as three hipGraphs (one memory pool) and
-    launches the two gradient all-reduces eagerly between them: with a 1-rank RCCL group the replay must reproduce the golden
-    two-step fixture like the single-graph and the eager paths -- IN THIS PROCESS, ending in the ordered teardown
-    (parallel.shutdown: drain, drop graphs + pool + comm stream, destroy_process_group).  Round 2 ran this in a child that
-    left through os._exit: the abort it dodged was the capture-mode race fixed since (GraphedTrainStep, thread_local)."""
+    launches the two gradient all-reduces eagerly between them; the side branch (multi-TD + frozen encoder) is cut in two --
+    forward in the first graph, backward in the second (STEGAN_SPLIT_SIDE=0: whole in the first, the round-2 arrangement).
+    With a 1-rank RCCL group the replay must reproduce the golden two-step fixture like the single-graph and the eager
+    paths -- IN THIS PROCESS, ending in the ordered teardown (parallel.shutdown: drain, drop graphs + pool + comm stream,
+    destroy_process_group).  Round 2 ran this in a child that left through os._exit: the abort it dodged was the
+    capture-mode race fixed since (GraphedTrainStep, thread_local)."""
     import torch.distributed as dist
     import ddp_graph_worker
+    monkeypatch.setenv("STEGAN_SPLIT_SIDE", split_side)
     assert not dist.is_initialized()
     ddp_graph_worker.main()
     assert not dist.is_initialized()

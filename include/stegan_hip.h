@@ -238,6 +238,22 @@ int stegan_add_layernorm_bwd_img(const float* dy, const float* xhat, const float
 int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
                                 const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
                                 void* stream);
+/* the same with the sum of the batch-slice slabs DEFERRED: when the launch sliced the batch, *deferred describes the pending sum
+ * (dw[r * K + k_lo + kk] += sum over slices of partial[slice][r * K_eff + kk]; used_floats of the workspace hold the slabs and must
+ * stay untouched until it ran) and no reduce kernel is launched; slices == 0: nothing is pending (dW was accumulated directly, or
+ * the shape went elsewhere: return 1 as stegan_conv1d_bwd_weight_hx).  stegan_wgrad_reduce_multi runs the pending sums of any number of
+ * layers as one launch per 48 (same summation order per element as the per-layer kernel: identical results); the caller orders it
+ * after every weight-gradient launch it covers (ops.wgrad_join). */
+typedef struct stegan_wgrad_reduce {
+    const float* partial;
+    float* dw;
+    int64_t per_tap, used_floats;
+    int32_t slices, K, k_lo, K_eff;
+} stegan_wgrad_reduce;
+int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                 const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
+                                 stegan_wgrad_reduce* deferred, void* stream);
+int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream);
 int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
                                const float* const* bias, const float* const* residual, float* const* y,

@@ -1,4 +1,4 @@
-"""Builds ste_gan_amd/libstegan_hip.so (gfx950 code objects) and the C oracle helpers in-tree.
+"""Builds ste_gan_amd/libstegan_hip.so (gfx950 code objects) in-tree (the oracle is Python: nothing else to compile).
 
 hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
 """

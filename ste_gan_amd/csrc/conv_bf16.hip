@@ -73,6 +73,7 @@ struct HP {
     // into 2^xlgm x 2^(3 - xlgm) rectangles, one per XCD; xlgm = 0 is the round-2 placement (all M tiles of a few N tiles per
     // XCD: X once, W by every XCD), larger xlgm trades re-reads of X for fewer re-reads of W.  xlgm < 0: identity (experiments)
     int xlgm = 0, xR = 1;
+    int rot = 1;                  // image path: rotated chunk walk per block (STEGAN_BF16_ROT=0: every block starts at chunk 0)
 };
 
 constexpr int HXD_MAX = 8;     // X DMA wave-instructions per producer wave and chunk (8 x 256 pieces of 16 bytes = 32 KiB)
@@ -274,8 +275,16 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         const int npieces = NCB * p.XROW;
         const int cbg0 = g * (p.C2_g >> 3);                       // first channel block of the group inside the image
         const int nch = c_end - c_begin;
+        // The blocks of an XCD that share an operand tile (the N tiles of one M tile share its W chunks, the M tiles of one N
+        // tile its X chunks) start together and walk the chunks in step: every line is requested by all of them at the same
+        // moment, the first request misses the L2 and the others queue behind the same fill -- everybody sees the miss
+        // latency.  Each block therefore starts its walk at a different chunk (rot) and wraps around: at any moment the
+        // sharers fetch DIFFERENT chunks, and all but the first touch of a line are L2 hits.  The sum over the chunks is the
+        // same set of terms in a rotated order (fp32 rounding differs in the last bit; parity bounds unchanged).
+        const int rot = (nch > 1 && h.rot) ? (int)((unsigned)(bx + by) % (unsigned)nch) : 0;
+#define HB_CID(j_) (c_begin + (j_) + rot - (((j_) + rot) >= nch ? nch : 0))
         // the first chunk's weights go out BEFORE the X offsets are computed: their round trip runs under that arithmetic
-        if (nch > 0) HB_DMA_W(c_begin, 0)
+        if (nch > 0) HB_DMA_W(HB_CID(0), 0)
         unsigned xd_voff[HXD_MAX];
         int xd_cb[HXD_MAX];
 #pragma unroll
@@ -320,8 +329,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         for (int it = 0; it < HW_MAX; ++it) ipc += (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB) ? 1 : 0;
         PSTAMP(0)                                                    // setup done
         for (int j = 0; j < NS - 1 && j < nch; ++j) {               // prologue: chunks 0 .. NS - 2 (chunk 0's weights are out)
-            if (j > 0) HB_DMA_W(c_begin + j, j)
-            HB_DMA_X(c_begin + j, j)
+            if (j > 0) HB_DMA_W(HB_CID(j), j)
+            HB_DMA_X(HB_CID(j), j)
         }
         PSTAMP(1)                                                    // prologue issued
         int stage_in = (NS - 1) % NS;                                // stage the next issued chunk goes to
@@ -336,14 +345,15 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             asm volatile("" ::: "memory");
             if (j == 4) { PSTAMP(3) }                                // past barrier 4
             if (j + NS - 1 < nch) {
-                HB_DMA_W(c_begin + j + NS - 1, stage_in)
-                HB_DMA_X(c_begin + j + NS - 1, stage_in)
+                HB_DMA_W(HB_CID(j + NS - 1), stage_in)
+                HB_DMA_X(HB_CID(j + NS - 1), stage_in)
                 stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
             }
             if (j == 4) { PSTAMP(4) }                                // iteration 4's DMAs issued
         }
         return;
 #undef HB_DMA_X
+#undef HB_CID
     } else {
     constexpr int XI = XV ? HXV_MAX : HX_MAX;
     unsigned x_voff[XI];
@@ -1165,6 +1175,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             if (l == 0 || c < best) { best = c; h.xlgm = l; }
         }
         if (env_x) h.xlgm = atoi(env_x);
+        { const char* er = getenv("STEGAN_BF16_ROT"); h.rot = er ? atoi(er) : 1; }
         while (h.xlgm > 0 && ((1 << h.xlgm) > p.ny || (8 >> h.xlgm) > h.xR)) --h.xlgm;
     }
     for (int ph = 0; ph < MAX_PHASES; ++ph) {

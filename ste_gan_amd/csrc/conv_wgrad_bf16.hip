@@ -634,9 +634,11 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
 
 // Accumulates into dw (and db, through the fp32 bias-gradient kernel).  Returns 1 (nothing enqueued) for shapes left to
 // the fp32 kernels: fewer than 16 channels per group on either side, or a workspace too small for one slab.
-extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
-                                           const uint16_t* dyh, float* dw, float* db, float* workspace,
-                                           int64_t workspace_floats, void* stream) {
+static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy, const uint16_t* dyh,
+                   float* dw, float* db, float* workspace, int64_t workspace_floats, stegan_wgrad_reduce* deferred,
+                   void* stream) {
+    if (deferred) { deferred->partial = nullptr; deferred->dw = nullptr; deferred->per_tap = 0; deferred->slices = 0;
+                    deferred->K = 0; deferred->k_lo = 0; deferred->K_eff = 0; deferred->used_floats = 0; }
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
@@ -785,7 +787,12 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
         else wgh_launch<1, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
     } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h, dw_direct, bw);
     else wgh_launch<1, 1, 8>(xv, grid, lds, s, h, dw_direct, bw);
-    if (!dw_direct) {
+    if (!dw_direct && deferred) {
+        // the caller sums the slabs later, together with those of other layers (stegan_wgrad_reduce_multi)
+        deferred->partial = h.partial; deferred->dw = dw; deferred->per_tap = (int64_t)h.Cout * h.Cin_g;
+        deferred->slices = h.slices; deferred->K = d->K; deferred->k_lo = h.k_lo; deferred->K_eff = h.K_eff;
+        deferred->used_floats = slab * h.slices;
+    } else if (!dw_direct) {
         const long per_tap = (long)h.Cout * h.Cin_g;
         long rb = (per_tap * h.K_eff + 255) / 256;
         if (rb > 2048) rb = 2048;
@@ -794,6 +801,81 @@ extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const floa
         ba.fdT = make_fastdiv(1u);
         hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s,
                            h.partial, dw, per_tap, h.slices, d->K, h.k_lo, h.K_eff, (int)rb, ba);
+    }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                           const uint16_t* dyh, float* dw, float* db, float* workspace,
+                                           int64_t workspace_floats, void* stream) {
+    return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, nullptr, stream);
+}
+
+extern "C" int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                            const uint16_t* dyh, float* dw, float* db, float* workspace,
+                                            int64_t workspace_floats, stegan_wgrad_reduce* deferred, void* stream) {
+    STEGAN_CHECK_ARG(deferred);
+    return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, deferred, stream);
+}
+
+// ---- the deferred slab sums of up to WRM_MAX layers in ONE launch (52 reduce launches a step become one per phase)
+namespace {
+constexpr int WRM_MAX = 48;
+struct WRMulti {
+    const float* partial[WRM_MAX];
+    float* dw[WRM_MAX];
+    long per_tap[WRM_MAX];
+    int slices[WRM_MAX], K[WRM_MAX], k_lo[WRM_MAX], K_eff[WRM_MAX];
+    int first[WRM_MAX + 1];           // first block of every item; first[n] = grid size
+    int n;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_multi_kernel(const WRMulti a) {
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) it = i;
+    const int rb = a.first[it + 1] - a.first[it], blk = (int)blockIdx.x - a.first[it];
+    const float* __restrict__ partial = a.partial[it];
+    float* __restrict__ dw = a.dw[it];
+    const int K_eff = a.K_eff[it], K = a.K[it], k_lo = a.k_lo[it], slices = a.slices[it];
+    const long total = a.per_tap[it] * K_eff;
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
+        const long r = i / K_eff;
+        const int kk = (int)(i - r * K_eff);
+        const float* src = partial + i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= slices; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * total];
+        }
+        for (; s < slices; ++s) v[0] += src[(size_t)s * total];
+        dw[r * K + k_lo + kk] += (v[0] + v[1]) + (v[2] + v[3]);       // the summation order of the per-layer reduce kernel
+    }
+}
+}  // namespace
+
+extern "C" int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream) {
+    STEGAN_CHECK_ARG(n >= 0 && (n == 0 || items));
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += WRM_MAX) {
+        WRMulti a;
+        a.n = 0; a.first[0] = 0;
+        for (int i = base; i < n && a.n < WRM_MAX; ++i) {
+            const stegan_wgrad_reduce& it = items[i];
+            if (it.slices <= 0) continue;
+            STEGAN_CHECK_ARG(it.partial && it.dw && it.per_tap > 0 && it.K_eff > 0);
+            long rb = (it.per_tap * it.K_eff + 255) / 256;
+            if (rb > 1024) rb = 1024;
+            const int j = a.n++;
+            a.partial[j] = it.partial; a.dw[j] = it.dw; a.per_tap[j] = (long)it.per_tap; a.slices[j] = it.slices;
+            a.K[j] = it.K; a.k_lo[j] = it.k_lo; a.K_eff[j] = it.K_eff;
+            a.first[j + 1] = a.first[j] + (int)rb;
+        }
+        if (a.n == 0) continue;
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_multi_kernel, dim3((unsigned)a.first[a.n]), dim3(256), 0, s, a);
     }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;

@@ -485,8 +485,38 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     return dx
 
 
-def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor]) -> None:
-    """Accumulates into dw (and db)."""
+class WgradReduce(C.Structure):       # mirrors struct stegan_wgrad_reduce
+    _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("per_tap", C.c_int64), ("used_floats", C.c_int64),
+                ("slices", C.c_int32), ("K", C.c_int32), ("k_lo", C.c_int32), ("K_eff", C.c_int32)]
+
+
+# Deferred slab sums of the sliced weight gradients (sink mode: dW is a view of a gradient arena that nothing reads before
+# ConvPack.finalize_grads -> wgrad_join): the slabs of a phase's layers live side by side in one arena and ONE multi-problem
+# launch per phase adds them into the arenas (52 reduce launches a step otherwise).  The arena is a fixed buffer per device
+# (captured graphs hold its address); a layer that does not fit any more sums its slabs at once, the round-2 way.
+# MEASURED AND SWITCHED OFF: 6.97 ms per step against 6.87 with the per-layer reduce launches -- those are spread over the
+# backward pass and fill gaps on busy streams, the batched sum sits alone between the last weight gradient and the optimiser.
+# Kept as an option (STEGAN_WGRAD_DEFER=1; tests/test_gpu_train_step.py runs the golden step through it).
+WGRAD_DEFER = os.environ.get("STEGAN_WGRAD_DEFER", "0") == "1"
+_WG_ARENA_FLOATS = int(os.environ.get("STEGAN_WGRAD_ARENA_MB", "1024")) * (1 << 18)
+_WG_ARENA: dict = {}           # device -> [arena, floats in use]
+_WG_DEFERRED: list = []        # (WgradReduce, dw tensor kept alive)
+
+
+def _wgrad_reduce_flush() -> None:
+    """The pending slab sums as one launch on the CURRENT stream (which the caller has ordered behind every weight-gradient
+    launch: wgrad_join), and the arena is free again for the launches ordered behind this one."""
+    if _WG_DEFERRED:
+        arr = (WgradReduce * len(_WG_DEFERRED))(*[it for it, _ in _WG_DEFERRED])
+        check(_lib.lib().stegan_wgrad_reduce_multi(len(_WG_DEFERRED), arr, _stream()), "stegan_wgrad_reduce_multi")
+        _WG_DEFERRED.clear()
+    for st in _WG_ARENA.values():
+        st[1] = 0
+
+
+def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor], defer: bool = False) -> None:
+    """Accumulates into dw (and db).  ``defer``: the caller promises that dw is read only after ops.wgrad_join() (gradient
+    sinks); the sum over the batch slices may then be postponed to that call."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
     if cfg.cout == 1 and SKINNY:
@@ -495,16 +525,36 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_weight_skinny")
             return
-    ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
     if COMPUTE_DTYPE == "bf16":
         xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
         if IMG_STATS is not None:
             IMG_STATS.setdefault((2, xh is not None and dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
+        if defer and WGRAD_DEFER and PROFILER is None and x.is_cuda:
+            st = _WG_ARENA.get(x.device)
+            if st is None:
+                st = _WG_ARENA[x.device] = [torch.empty(_WG_ARENA_FLOATS, device=x.device, dtype=torch.float32), 0]
+            arena, used = st
+            room = arena.numel() - used
+            if room >= dw.numel() * 8:                    # room for at least 8 slices: worth a deferred launch
+                item = WgradReduce()
+                ws = arena[used:]
+                rc = _lib.lib().stegan_conv1d_bwd_weight_hxd(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw), _p(db),
+                                                             _p(ws), min(room, dw.numel() * 64), C.byref(item), _stream())
+                if rc != 1:
+                    check(rc, "stegan_conv1d_bwd_weight_hxd")
+                    global LAST_CONV_KERNEL
+                    LAST_CONV_KERNEL = "bf16"
+                    if item.slices > 0:
+                        st[1] = used + ((int(item.used_floats) + 63) & ~63)
+                        _WG_DEFERRED.append((item, dw))
+                    return
+        ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
         rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_hx(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw),
                                                                          _p(db), _p(ws), ws.numel(), _stream()), "bf16")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_weight_hx")
             return
+    ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
     check(_timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_ws(C.byref(d), _p(x), _p(dy), _p(dw), _p(db), _p(ws),
                                                                       ws.numel(), _stream())),
           "stegan_conv1d_bwd_weight_ws")
@@ -547,14 +597,14 @@ def _wgrad_flush() -> None:
     side.wait_stream(torch.cuda.current_stream())       # ONE cross-queue edge for the whole batch (11 us each inside a
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
         for x, dy, cfg, dw, db in _WG_PENDING:
-            conv1d_bwd_weight(x, dy, cfg, dw, db)
+            conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True)
     _WG_KEEP.extend((x, dy) for x, dy, _, _, _ in _WG_PENDING)
     _WG_PENDING.clear()
 
 
 def _wgrad_sink(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor]) -> None:
     if not _WG_ON[0] or PROFILER is not None or not x.is_cuda:
-        conv1d_bwd_weight(x, dy, cfg, dw, db)
+        conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True)
         return
     _WG_PENDING.append((x, dy, cfg, dw, db))
     if len(_WG_PENDING) >= WGRAD_BATCH:
@@ -587,6 +637,7 @@ def wgrad_join() -> None:
         if key != cur.cuda_stream:
             cur.wait_stream(s_)
     _SINK_STREAMS.clear()
+    _wgrad_reduce_flush()          # behind every weight-gradient launch of the phase: their slabs' sums, one launch
 
 
 def wn_scale(v: Tensor, g: Tensor) -> Tensor:
@@ -862,7 +913,7 @@ class _WNConvMultiFn(torch.autograd.Function):
             if not done:
                 for x, g, l in zip(xs, gs, layers):
                     if l[5] is not None:
-                        conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None)
+                        conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None, defer=True)
         dxs = [None] * n
         need = [ctx.needs_input_grad[2 + i] for i in range(n)]
         if any(need):

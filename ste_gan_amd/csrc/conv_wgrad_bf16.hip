@@ -51,6 +51,7 @@ struct WH {
     int NGA, NGX, ait, xit;    // staging groups per plane (slots or runs of 4), items per thread
     int u_chunks;              // chunks along time = ceil(Tout / RU)
     int co_tiles, ci_tiles, slices, bps;     // bps = batch elements per slice (multiple of NB)
+    int xcd = 1, rot = 1;                    // image kernel: XCD-contiguous tile ids; rotated chunk walk (experiments: 0)
     unsigned x_bytes, dy_bytes;
     FastDiv fdNGA, fdNGX, fdRUp, fdSEG, fdUC, fdCI, fdCO, fdTG;
     // round 3: both operands as bf16 activation images [B][C / 8][T][8] (conv_bf16.hip's DirP::out_h): staged by LDS-DMA
@@ -104,7 +105,7 @@ struct BiasW { const float* dy; float* db; int B, C, T, per, slices, vec, first;
 #define STEGAN_WGRAD_WAVES 2
 #endif
 template <int TM, int TN, int KT, bool XV, int SIV, bool XH = false>
-__device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restrict__ dw_direct) {
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restrict__ dw_direct, unsigned tile_id) {
     static_assert(!(XV && XH), "the image path has no use for the 16-byte fp32 loads");
     constexpr int BM = 64 * TM, BN = 64 * TN;          // co x ci tile of the block
     constexpr int CBA = BM / 8, CBX = BN / 8;          // channel-block planes of the two images
@@ -117,7 +118,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
     const int wm = wave >> 1, wn = wave & 1;
     WSTAMP(0)
     // block -> (ci tile fastest, co tile, group, tap group, slice): neighbours share the dy tile
-    unsigned t = blockIdx.x;
+    unsigned t = tile_id;
     unsigned q_ = fd_div(t, h.fdCI);
     const int ci_t = (int)(t - q_ * h.ci_tiles); t = q_;
     q_ = fd_div(t, h.fdCO);
@@ -208,8 +209,13 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 }                                                                                               \
             }                                                                                                   \
         }
+        // the blocks that share an operand slice walk its chunks from different starting points (conv_bf16.hip: at any moment
+        // the sharers of a line fetch different chunks; all but the first touch are L2 hits); the sum is the same set of
+        // terms in a rotated order
+        const int rot = (nchunks > 1 && h.rot) ? (int)((unsigned)(ci_t + co_t) % (unsigned)nchunks) : 0;
+#define WG_CID(c_) ((c_) + rot - (((c_) + rot) >= nchunks ? nchunks : 0))
         WPSTAMP(0)
-        if (nchunks > 0) WG_DMA(0, 0)
+        if (nchunks > 0) WG_DMA(WG_CID(0), 0)
         WPSTAMP(1)
         for (int c = 0; c < nchunks; ++c) {
             if (c == 5) {
@@ -218,10 +224,11 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
             }
             block_sync();                          // barrier c: chunk c has landed (vmcnt(0) in front of the barrier)
             if (c == 4) { WPSTAMP(2) }
-            if (c + 1 < nchunks) WG_DMA(c + 1, (c + 1) & 1)
+            if (c + 1 < nchunks) WG_DMA(WG_CID(c + 1), (c + 1) & 1)
             if (c == 4) { WPSTAMP(3) }
         }
         return;
+#undef WG_CID
 #undef WG_DMA
     } else {
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)h.x, 0, (int)h.x_bytes, 0x00020000);
@@ -553,19 +560,28 @@ __device__ __forceinline__ void wg_bias_block(const BiasW& ba, int j) {
 template <int TM, int TN, int KT, bool XV>
 __global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_kernel(const WH h, float* dw_direct, const BiasW ba) {
     if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
-    conv_wgrad_bf16_body<TM, TN, KT, XV, WSV_MAX>(h, dw_direct);
+    conv_wgrad_bf16_body<TM, TN, KT, XV, WSV_MAX>(h, dw_direct, blockIdx.x);
 }
 
 template <int TM, int TN, int KT>
 __global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_one_kernel(const WH h, float* dw_direct, const BiasW ba) {
     if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
-    conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h, dw_direct);
+    conv_wgrad_bf16_body<TM, TN, KT, true, 1>(h, dw_direct, blockIdx.x);
 }
 
 template <int TM, int TN, int KT>
 __global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_img_kernel(const WH h, float* dw_direct, const BiasW ba) {
     if ((int)blockIdx.x >= ba.first) { wg_bias_block(ba, (int)blockIdx.x - ba.first); return; }
-    conv_wgrad_bf16_body<TM, TN, KT, false, 1, true>(h, dw_direct);
+    // Blocks are dealt round-robin over the 8 XCDs: every XCD takes ONE contiguous range of tile ids (ids run ci tile, co tile,
+    // group, tap group, slice: a range is a slice, or part of one), so the x / dy rows of a batch slice are fetched into one
+    // L2 instead of eight (round 2: 4.8x the operand bytes through the fabric per launch).
+    unsigned t = blockIdx.x;
+    if (h.xcd) {
+        const unsigned total = (unsigned)ba.first, L = blockIdx.x;
+        const unsigned q8 = total >> 3, r8 = total & 7, xcd = L & 7;
+        t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (L >> 3);
+    }
+    conv_wgrad_bf16_body<TM, TN, KT, false, 1, true>(h, dw_direct, t);
 }
 
 // dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
@@ -745,6 +761,8 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
     h.bps = ceil_div(b_chunks, (int)want) * h.NB;
     h.slices = ceil_div(h.B, h.bps);
     h.partial = workspace;
+    { const char* e1 = getenv("STEGAN_BF16_WGRAD_XCD"); h.xcd = e1 ? atoi(e1) : 1; }
+    { const char* e2 = getenv("STEGAN_BF16_WGRAD_ROT"); h.rot = e2 ? atoi(e2) : 1; }
     h.fdNGA = make_fastdiv((uint32_t)h.NGA); h.fdNGX = make_fastdiv((uint32_t)h.NGX);
     h.fdRUp = make_fastdiv((uint32_t)h.RUp); h.fdSEG = make_fastdiv((uint32_t)h.SEG);
     { const char* se = getenv("STEGAN_STAMP_PTR"); h.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }

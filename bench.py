@@ -176,7 +176,7 @@ def cpu_baseline(steps=5, warm=2):
     dt = sum(times) / steps
     return {"value": B * T_EMG / dt, "unit": "EMG frames/s", "cores": cores, "kind": "port", "cpu_model": model,
             "sample": f"{steps} full train steps at B=64, T_emg=192 after {warm} warm-up steps (oracle/stegan_oracle.py "
-                      f"train_step, torch-CPU fp32, {cores} threads = physical cores; mean {dt:.2f} s/step, "
+                      f"train_step, torch-CPU fp32, {cores} threads = min(physical cores, affinity, cgroup CPU quota); mean {dt:.2f} s/step, "
                       f"min {min(times):.2f}, max {max(times):.2f})"}
 
 

@@ -76,6 +76,10 @@ struct HP {
     int rot = 1;                  // image path: rotated chunk walk per block (STEGAN_BF16_ROT=0: every block starts at chunk 0)
 };
 
+// a scalar moved into a vector register through an opaque instruction: the value cannot be re-derived (re-loaded) later
+__device__ __forceinline__ int vg(int s) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+__device__ __forceinline__ unsigned vg(unsigned s) { unsigned v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
+
 constexpr int HXD_MAX = 8;     // X DMA wave-instructions per producer wave and chunk (8 x 256 pieces of 16 bytes = 32 KiB)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
@@ -133,11 +137,15 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #define HSTAMP(i_) if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
 // producer wave 0 (thread 256): a second table of 8 stamps per block, 1 Mi entries behind the consumers' table
 #define PSTAMP(i_) if (p.stamps && threadIdx.x == 256) p.stamps[(1u << 19) + (size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
+// ... and a third one for the stretch between kernel entry and the first DMA
+#define QSTAMP(i_) if (p.stamps && threadIdx.x == 256) p.stamps[(1u << 19) + (1u << 18) + (size_t)bid_x * 8 + (i_)] = __builtin_amdgcn_s_memtime();
 #else
 #define HSTAMP(i_)
 #define PSTAMP(i_)
+#define QSTAMP(i_)
 #endif
     HSTAMP(0)
+    PSTAMP(6)                                                        // producer wave 0 enters
     // one clustered batch of kernarg loads (left alone, hipcc sinks each s_load next to its first use: a string of
     // dependent load + wait round trips through the index setup)
     asm volatile("" ::"s"(p.B), "s"(p.Csrc), "s"(p.Cdst), "s"(p.Tsrc), "s"(p.Tq), "s"(p.Tdst), "s"(p.C2_g), "s"(p.M_g), "s"(p.K),
@@ -156,6 +164,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // fetched into that L2 once and reused by the M tiles, the W chunks of all M tiles stay resident across its N tiles
     // (with the natural x-fastest order every XCD streams the whole of X and W through its L2: measured 3-4 TB/s of
     // Infinity-Cache traffic bound the kernel).  Placement only affects speed, never results.
+    QSTAMP(0)                                                        // kernel arguments have arrived
     int bx, by, phase, split;
     const int nsplits = p.splits, cps = p.chunks_per_split;
     {
@@ -187,6 +196,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     }
     const int g = (int)fd_div((uint32_t)by, p.fdMT);
     const int m0 = (by - g * p.m_tiles) * BM;
+    QSTAMP(1)                                                        // tile decoded
 
     // the phase's six table entries in ONE batch of scalar loads (they sat behind two branches: two more round trips)
     Taps tp;
@@ -234,6 +244,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // (each role computes only its own per-lane state inside its branch: register demand is the maximum of the two
     // roles, not their sum)
     if (producer) {
+    QSTAMP(2)                                                        // phase table, chunk range, ... : role-independent setup done
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef const __attribute__((address_space(1))) void* gptr_t;
     // ---- W staging: piece = it * 256 + tid -> LDS byte 16 * piece; piece = (tap * NCB + cb) * BM + m.  The bf16 weights
@@ -284,23 +295,37 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         const int rot = (nch > 1 && h.rot) ? (int)((unsigned)(bx + by) % (unsigned)nch) : 0;
 #define HB_CID(j_) (c_begin + (j_) + rot - (((j_) + rot) >= nch ? nch : 0))
         // the first chunk's weights go out BEFORE the X offsets are computed: their round trip runs under that arithmetic
+        QSTAMP(3)                                                    // W offsets, X descriptor done
         if (nch > 0) HB_DMA_W(HB_CID(0), 0)
+        PSTAMP(7)                                                    // tile decode + W offsets done, first W DMA issued
         unsigned xd_voff[HXD_MAX];
         int xd_cb[HXD_MAX];
+        {
+            // The loop-invariant scalars of the item arithmetic, moved into VECTOR registers once (vg: an opaque v_mov).  Left
+            // as kernel-argument fields the compiler -- out of scalar registers with the whole HP struct live -- re-loaded
+            // them from the kernarg segment inside EVERY item (two dependent s_load / s_waitcnt round trips per item) and
+            // spilled scalars to vector lanes around them: the producers' setup took 7 500 cycles to the first X DMA.  Vector
+            // registers are plentiful here (52 of 512 in use), and an asm result cannot be rematerialised.
+            const unsigned xr_mul = vg(p.fdXROW.mul), xr_sh = vg(p.fdXROW.shift), xrow = vg((unsigned)p.XROW);
+            const unsigned sg_mul = vg(p.fdSEG.mul), sg_sh = vg(p.fdSEG.shift), seg = vg((unsigned)p.SEG);
+            const int blo = vg(b_lo), q0 = vg(qbase0), qN = vg(qbaseN), nseg = vg(p.NSEG), nb = vg(p.B), tq = vg(p.Tq);
+            const int rowcb = vg(h.xh_cb), cb0 = vg(cbg0), tsrc = vg(p.Tsrc), npc = vg(npieces);
+            const int upsh = vg(p.mode == 0 ? p.ups : 0);
 #pragma unroll
-        for (int it = 0; it < HXD_MAX; ++it) {
-            xd_cb[it] = -1;                                       // -1: lane switched off
-            xd_voff[it] = OOB;
-            if (it < h.xnit) {
-                const int piece = it * 256 + tid;
-                const int cb = (int)fd_div((uint32_t)piece, p.fdXROW), slot = piece - cb * p.XROW;
-                const int sg = (int)fd_div((uint32_t)slot, p.fdSEG), sl = slot - sg * p.SEG;
-                const int b = b_lo + sg;
-                const int q = (sg == 0 ? qbase0 : qbaseN) + sl;
-                const int qs = p.mode == 0 ? (q >> p.ups) : q;
-                if (piece < npieces) xd_cb[it] = cb;
-                if (piece < npieces && sg < p.NSEG && b < p.B && q >= 0 && q < p.Tq)
-                    xd_voff[it] = (unsigned)(((b * h.xh_cb + cbg0 + cb) * p.Tsrc + qs) * 16);
+            for (int it = 0; it < HXD_MAX; ++it) {
+                xd_cb[it] = -1;                                   // -1: lane switched off
+                xd_voff[it] = OOB;
+                if (it < h.xnit) {
+                    const unsigned piece = (unsigned)(it * 256 + tid);
+                    const unsigned cb = (__umulhi(piece, xr_mul) + piece) >> xr_sh, slot = piece - cb * xrow;
+                    const unsigned sg = (__umulhi(slot, sg_mul) + slot) >> sg_sh, sl = slot - sg * seg;
+                    const int b = blo + (int)sg;
+                    const int q = (sg == 0 ? q0 : qN) + (int)sl;
+                    const bool in = (int)piece < npc;
+                    const bool ok = in & ((int)sg < nseg) & (b < nb) & (q >= 0) & (q < tq);
+                    xd_cb[it] = in ? (int)cb : -1;
+                    xd_voff[it] = ok ? (unsigned)(((b * rowcb + cb0 + (int)cb) * tsrc + (q >> upsh)) * 16) : OOB;
+                }
             }
         }
         const int chunk_x = NCB * p.Tsrc * 16;                    // bytes between the image planes of neighbouring chunks

@@ -74,6 +74,7 @@ struct HP {
     // XCD: X once, W by every XCD), larger xlgm trades re-reads of X for fewer re-reads of W.  xlgm < 0: identity (experiments)
     int xlgm = 0, xR = 1;
     int rot = 1;                  // image path: rotated chunk walk per block (STEGAN_BF16_ROT=0: every block starts at chunk 0)
+    int cw0 = 1;                  // image path: the consumer waves request chunk 0's weights (STEGAN_BF16_CW0=0: the producers)
 };
 
 // a scalar moved into a vector register through an opaque instruction: the value cannot be re-derived (re-loaded) later
@@ -240,6 +241,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int chunk_w = NCB * h.Mpad * 16;                         // bytes between the weights of neighbouring chunks
 
 
+    // image path, two-stage ring: the consumers request chunk 0's weights (h.cw0; STEGAN_BF16_CW0=0: the producers do)
+    const bool cw0 = XH && h.cw0 != 0 && h.nstage == 2;
     // ================= producers (waves 4-7): stage chunk c + 1 while the consumers multiply chunk c =================
     // (each role computes only its own per-lane state inside its branch: register demand is the maximum of the two
     // roles, not their sum)
@@ -251,17 +254,18 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // are stored [g][k][cb][m][8 channels], so the 64 lanes of a wave-instruction copy 1 KiB of CONTIGUOUS global memory
     const int CB = h.Cpad >> 3;
     int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
-#pragma unroll
-    for (int it = 0; it < HW_MAX; ++it) {
-        w_off[it] = 0;
-        if (it < h.wit) {                                    // (items past the tile: not computed -- index setup is on the
-            const int piece = it * 256 + tid;                //  path to the first DMA)
-            const int m = piece & (BM - 1), r = piece / BM;
-            const int cb = r & (NCB - 1), tap = r >> LOGNCB;
-            const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;        // dead tap of an odd pair: the zero plane
-            w_off[it] = tap < ntapsW ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      // (unused pieces: whole waves, skipped)
-        }
+#define HB_W_OFFSETS                                                                                            \
+    _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                     \
+        w_off[it] = 0;                                                                                          \
+        if (it < h.wit) {                                    /* (items past the tile: not computed -- index setup is */ \
+            const int piece = it * 256 + tid;                /*  on the path to the first DMA)                      */ \
+            const int m = piece & (BM - 1), r = piece / BM;                                                     \
+            const int cb = r & (NCB - 1), tap = r >> LOGNCB;                                                    \
+            const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;        /* dead tap of an odd pair: the zero plane */ \
+            w_off[it] = tap < ntapsW ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      /* (unused pieces: whole waves, skipped) */ \
+        }                                                                                                       \
     }
+    if (!cw0) { HB_W_OFFSETS }   // cw0: chunk 0's weights are the consumers' business; the offsets follow the first X DMAs
 #define HB_DMA_W(c_, buf_)                                                                                      \
     {                                                                                                           \
         const char* wc_ = wt_g + (size_t)(c_) * chunk_w;                                                        \
@@ -296,7 +300,9 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #define HB_CID(j_) (c_begin + (j_) + rot - (((j_) + rot) >= nch ? nch : 0))
         // the first chunk's weights go out BEFORE the X offsets are computed: their round trip runs under that arithmetic
         QSTAMP(3)                                                    // W offsets, X descriptor done
-        if (nch > 0) HB_DMA_W(HB_CID(0), 0)
+        // (chunk 0's weights are requested by the CONSUMER waves, which otherwise idle until the first barrier: the W path
+        // and the X path to the first chunk then run side by side -- see the consumers' side below)
+        if (nch > 0 && !cw0) HB_DMA_W(HB_CID(0), 0)
         PSTAMP(7)                                                    // tile decode + W offsets done, first W DMA issued
         unsigned xd_voff[HXD_MAX];
         int xd_cb[HXD_MAX];
@@ -353,6 +359,10 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
         for (int it = 0; it < HW_MAX; ++it) ipc += (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB) ? 1 : 0;
         PSTAMP(0)                                                    // setup done
+        if (cw0) {                                                   // (two stages: the prologue is chunk 0's X tile)
+            if (nch > 0) HB_DMA_X(HB_CID(0), 0)
+            HB_W_OFFSETS                                             // ... and under its round trip, the W offsets of chunks 1 ..
+        } else
         for (int j = 0; j < NS - 1 && j < nch; ++j) {               // prologue: chunks 0 .. NS - 2 (chunk 0's weights are out)
             if (j > 0) HB_DMA_W(HB_CID(j), j)
             HB_DMA_X(HB_CID(j), j)
@@ -482,8 +492,33 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #undef HB_STORE_X
 #undef HB_STORE_X_
 #undef HB_DMA_W
+#undef HB_W_OFFSETS
 
     // ================= consumers (waves 0-3): LDS operand reads + MFMAs, then the epilogue =================
+    // ---- chunk 0's weights (cw0): the same pieces the producers would request (piece = it * 256 + tid of the role), issued
+    // here FIRST, before the consumers' own index setup: their round trip runs under it, and the producers go straight to
+    // the X offsets.  The first barrier is preceded by this role's vmcnt(0).
+    if constexpr (XH) {
+        if (cw0 && c_begin < c_end) {
+            typedef __attribute__((address_space(3))) void* lds_ptr_t;
+            typedef const __attribute__((address_space(1))) void* gptr_t;
+            const int nch0 = c_end - c_begin;
+            const int rot0 = (nch0 > 1 && h.rot) ? (int)((unsigned)(bx + by) % (unsigned)nch0) : 0;
+            const char* wc = wt_g + (size_t)(c_begin + rot0) * chunk_w;
+            const int CBw = h.Cpad >> 3;
+#pragma unroll
+            for (int it = 0; it < HW_MAX; ++it) {
+                if (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB && !HB_DBG(2)) {
+                    const int piece = it * 256 + tid;
+                    const int m = piece & (BM - 1), r = piece / BM;
+                    const int cb = r & (NCB - 1), tap = r >> LOGNCB;
+                    const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;
+                    const int wo = tap < ntapsW ? ((k * CBw + cb) * h.Mpad + m0 + m) * 16 : 0;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wc + wo), (lds_ptr_t)(smem + (it * 256 + wave * 64) * 16), 16, 0, 0);
+                }
+            }
+        }
+    }
     // ---- per-lane operand addresses.  Reduction "atoms" (tap, cb) are BM (W) / XROW or step (X) 16-byte pieces apart; the
     // two lane halves of an MFMA take atoms 2 s and 2 s + 1 of k-step s: W offset s * 2 BM * 16 for every chunk shape
     const int hl = lane >> 5, l31 = lane & 31;
@@ -555,6 +590,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     int stage_c = 0;                                              // ring stage of the chunk being multiplied
     for (int c = c_begin; c < c_end; ++c) {
         if constexpr (XH) {                                       // (the producers' side of this barrier: counted vmcnt, above)
+            if (cw0 && c == c_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this role's DMAs of chunk 0
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -1201,6 +1237,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         }
         if (env_x) h.xlgm = atoi(env_x);
         { const char* er = getenv("STEGAN_BF16_ROT"); h.rot = er ? atoi(er) : 1; }
+        { const char* ec = getenv("STEGAN_BF16_CW0"); h.cw0 = ec ? atoi(ec) : 1; }
         while (h.xlgm > 0 && ((1 << h.xlgm) > p.ny || (8 >> h.xlgm) > h.xR)) --h.xlgm;
     }
     for (int ph = 0; ph < MAX_PHASES; ++ph) {

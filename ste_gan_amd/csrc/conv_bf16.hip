@@ -232,7 +232,9 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const int c_begin = split * cps;
     const int c_end = min(nchunks, c_begin + cps);
     const char* wt_g = (const char*)h.wh + (size_t)g * (p.K + 1) * h.Mpad * h.Cpad * 2;
-    const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = NCB * p.XROW * 16;
+    // (the X stage is padded to whole waves of 64 pieces: the lean DMA issue of the image path lets the lanes past the tile
+    // write their zeros there instead of masking them)
+    const int wbuf = h.ntapsW * NCB * BM * 16, xbuf = ((NCB * p.XROW + 63) & ~63) * 16;
     const int NS = XH ? h.nstage : 2;                              // stages of the chunk ring
     char* const Xbufs = smem + NS * wbuf;                          // W ring | X ring
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.src, 0, (int)h.src_bytes, 0x00020000);
@@ -302,7 +304,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         QSTAMP(3)                                                    // W offsets, X descriptor done
         // (chunk 0's weights are requested by the CONSUMER waves, which otherwise idle until the first barrier: the W path
         // and the X path to the first chunk then run side by side -- see the consumers' side below)
-        if (nch > 0 && !cw0) HB_DMA_W(HB_CID(0), 0)
+        if (nch > 0 && !cw0) HB_DMA_W(HB_CID(0), 0)      // (old form: before the descriptor / counts exist)
         PSTAMP(7)                                                    // tile decode + W offsets done, first W DMA issued
         unsigned xd_voff[HXD_MAX];
         int xd_cb[HXD_MAX];
@@ -335,17 +337,52 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             }
         }
         const int chunk_x = NCB * p.Tsrc * 16;                    // bytes between the image planes of neighbouring chunks
+        // ---- lean issue.  The first version guarded every item with its own conditions; hipcc turned them into a mask
+        // register and TWO taken branches per item (out of line and back), a 64-bit address add and an exec save / restore
+        // around each X item: 130 cycles per DMA instruction, 1 300 per chunk -- the issue, not the memory system, set the
+        // iteration time (scripts/micro/stage_rate.hip: the same ring staged with straight-line issue takes 625 / 890 cycles
+        // per 16 / 32 KiB chunk on L2 hits, 1 150 / 1 540 on misses; the conv's iterations took 1 470 / 1 940).  Now: the number
+        // of items of THIS wave is one scalar (nw, nx), a switch falls through that many straight-line items, the weights go
+        // through a buffer descriptor too (offset register + scalar chunk offset: no address arithmetic per item), and the
+        // lanes past the X tile are not masked: their offset is out of range, so they write zeros into the stage's padding.
+        const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)wt_g, 0, (p.K + 1) * h.Mpad * h.Cpad * 2, 0x00020000);
+        const int wpieces = ntapsW * BM * NCB;
+        const int nw = wpieces > wave * 64 ? min(h.wit, (wpieces - wave * 64 + 255) >> 8) : 0;
+        const int nx = npieces > wave * 64 ? min(h.xnit, (npieces - wave * 64 + 255) >> 8) : 0;
+#define HB_W_IT(i_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(Wd_ + ((i_) * 256 + wave * 64) * 16), 16, w_off[i_], so_, 0, 0);
+#define HB_DMA_W2(c_, buf_)                                                                                     \
+        if (!HB_DBG(2)) {                                                                                       \
+            char* Wd_ = smem + (buf_) * wbuf;                                                                   \
+            const int so_ = (c_) * chunk_w;                                                                     \
+            switch (nw) {                                                                                       \
+                case 12: HB_W_IT(11) [[fallthrough]]; case 11: HB_W_IT(10) [[fallthrough]];                     \
+                case 10: HB_W_IT(9) [[fallthrough]];  case 9: HB_W_IT(8) [[fallthrough]];                       \
+                case 8: HB_W_IT(7) [[fallthrough]];   case 7: HB_W_IT(6) [[fallthrough]];                       \
+                case 6: HB_W_IT(5) [[fallthrough]];   case 5: HB_W_IT(4) [[fallthrough]];                       \
+                case 4: HB_W_IT(3) [[fallthrough]];   case 3: HB_W_IT(2) [[fallthrough]];                       \
+                case 2: HB_W_IT(1) [[fallthrough]];   case 1: HB_W_IT(0) [[fallthrough]];                       \
+                default: break;                                                                                 \
+            }                                                                                                   \
+        }
+        static_assert(HW_MAX == 12 && HXD_MAX == 8, "the item switches of the lean DMA issue are written out for 12 / 8 items");
+#define HB_X_IT(i_, vo_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h, (lds_ptr_t)(Xd_ + ((i_) * 256 + wave * 64) * 16), 16, vo_, sx_, 0, 0);
+#define HB_X_SW(VO_)                                                                                            \
+            switch (nx) {                                                                                       \
+                case 8: HB_X_IT(7, VO_(7)) [[fallthrough]]; case 7: HB_X_IT(6, VO_(6)) [[fallthrough]];         \
+                case 6: HB_X_IT(5, VO_(5)) [[fallthrough]]; case 5: HB_X_IT(4, VO_(4)) [[fallthrough]];         \
+                case 4: HB_X_IT(3, VO_(3)) [[fallthrough]]; case 3: HB_X_IT(2, VO_(2)) [[fallthrough]];         \
+                case 2: HB_X_IT(1, VO_(1)) [[fallthrough]]; case 1: HB_X_IT(0, VO_(0)) [[fallthrough]];         \
+                default: break;                                                                                 \
+            }
+#define HB_VO_FULL(i_) (int)xd_voff[i_]
+#define HB_VO_RAG(i_) (xd_cb[i_] < live_ ? (int)xd_voff[i_] : (int)OOB)
 #define HB_DMA_X(c_, buf_)                                                                                      \
-        {                                                                                                       \
+        if (!HB_DBG(1)) {                                                                                       \
             const int live_ = (p.C2_g - (c_) * CCH + 7) >> 3;   /* channel blocks of the group left for this chunk */ \
             char* Xd_ = Xbufs + (buf_) * xbuf;                                                                  \
-            _Pragma("unroll") for (int it = 0; it < HXD_MAX; ++it) {                                            \
-                if (it < h.xnit && xd_cb[it] >= 0 && !HB_DBG(1)) {                                            \
-                    const int vo_ = xd_cb[it] < live_ ? (int)xd_voff[it] : (int)OOB;                            \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h, (lds_ptr_t)(Xd_ + (it * 256 + wave * 64) * 16), 16, \
-                                                             vo_, (c_) * chunk_x, 0, 0);                        \
-                }                                                                                               \
-            }                                                                                                   \
+            const int sx_ = (c_) * chunk_x;                                                                     \
+            if (live_ >= NCB) { HB_X_SW(HB_VO_FULL) }           /* every channel block of the chunk exists */   \
+            else { HB_X_SW(HB_VO_RAG) }                         /* ragged last chunk: the blocks past the group read zeros */ \
         }
         // Ring of NS stages, NS - 1 chunks in flight.  An iteration of a small tile is 128-768 cycles of MFMA against a
         // DMA round trip of ~1 000 (measured with the stamps: with ONE chunk in flight -- two buffers, the barrier's
@@ -353,18 +390,14 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         // producers wait with a COUNTED vmcnt -- until chunk c + 1 has landed, leaving the younger chunks in flight --
         // and meet the consumers at a raw s_barrier (__syncthreads() would add vmcnt(0) while a DMA is pending).  A wave
         // issues the same number of DMA instructions for every chunk (ipc), so the count is (chunks left in flight) x ipc.
-        int ipc = 0;
-#pragma unroll
-        for (int it = 0; it < HXD_MAX; ++it) ipc += (it < h.xnit && (it * 256 + wave * 64) < npieces) ? 1 : 0;
-#pragma unroll
-        for (int it = 0; it < HW_MAX; ++it) ipc += (it < h.wit && (it * 256 + wave * 64) < ntapsW * BM * NCB) ? 1 : 0;
+        const int ipc = nw + nx;
         PSTAMP(0)                                                    // setup done
         if (cw0) {                                                   // (two stages: the prologue is chunk 0's X tile)
             if (nch > 0) HB_DMA_X(HB_CID(0), 0)
             HB_W_OFFSETS                                             // ... and under its round trip, the W offsets of chunks 1 ..
         } else
         for (int j = 0; j < NS - 1 && j < nch; ++j) {               // prologue: chunks 0 .. NS - 2 (chunk 0's weights are out)
-            if (j > 0) HB_DMA_W(HB_CID(j), j)
+            if (j > 0) HB_DMA_W2(HB_CID(j), j)
             HB_DMA_X(HB_CID(j), j)
         }
         PSTAMP(1)                                                    // prologue issued
@@ -380,7 +413,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             asm volatile("" ::: "memory");
             if (j == 4) { PSTAMP(3) }                                // past barrier 4
             if (j + NS - 1 < nch) {
-                HB_DMA_W(HB_CID(j + NS - 1), stage_in)
+                HB_DMA_W2(HB_CID(j + NS - 1), stage_in)
                 HB_DMA_X(HB_CID(j + NS - 1), stage_in)
                 stage_in = stage_in + 1 == NS ? 0 : stage_in + 1;
             }
@@ -388,6 +421,12 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         }
         return;
 #undef HB_DMA_X
+#undef HB_DMA_W2
+#undef HB_W_IT
+#undef HB_X_IT
+#undef HB_X_SW
+#undef HB_VO_FULL
+#undef HB_VO_RAG
 #undef HB_CID
     } else {
     constexpr int XI = XV ? HXV_MAX : HX_MAX;
@@ -967,7 +1006,7 @@ GeoH plan_bf16(int TM, int TN, int C2_g, int ntaps_max, int span_taps, int step_
         const int xit = ceil_div(NCB * NG, 256), wit = ceil_div(ntW * BM * NCB, 256);
         // image source: the X tile is DMA pieces, not register items -- bounded by HXD_MAX wave-instructions per wave
         if ((dma_x ? xit > HXD_MAX : xit > (xv ? HXV_MAX : HX_MAX)) || wit > HW_MAX) continue;
-        const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)XROW * NCB * 16);       // W ring of 2, X ring of 2
+        const size_t lds = 2 * ((size_t)ntW * BM * NCB * 16 + (size_t)((XROW * NCB + 63) & ~63) * 16);       // W ring of 2, X ring of 2 (X stage padded to 64 pieces)
         if (lds > 160 * 1024) continue;
         GeoH c = gm;
         c.logNCB = logNCB; c.SEG = SEG; c.NSEG = NSEG; c.XROW = XROW; c.NG = NG; c.ntW = ntW;

@@ -32,6 +32,27 @@ __global__ __launch_bounds__(512) void k(const uint4* __restrict__ src, unsigned
                 for (int it = 0; it < PER; ++it)
                     __builtin_amdgcn_global_load_lds((gptr_t)(chunk + it * 256 + tid), (lds_ptr_t)(stage + (it * 256 + wave * 64) * 16), 16, 0, 0);
                 __builtin_amdgcn_s_waitcnt(0);
+            } else if (MODE == 3 || MODE == 4) {                 // DMA through a buffer descriptor; 4: runs of 12 pieces (192 B) 18 KiB apart
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 1 << 20, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < PER; ++it) {
+                    const int piece = it * 256 + tid;
+                    const int off = MODE == 3 ? piece * 16 : ((piece / 12) * 18432 + (piece % 12) * 16) & ((1 << 20) - 16);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(stage + (it * 256 + wave * 64) * 16), 16, off,
+                                                             (c % (1024 / KB)) * (MODE == 3 ? PIECES * 16 : 192), 0, 0);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+            } else if (MODE == 2) {                              // mixed: a quarter of the chunk through registers, the rest by DMA
+                constexpr int PR = PER / 4 > 0 ? PER / 4 : 1;
+                uint4 r[PR];
+#pragma unroll
+                for (int it = 0; it < PR; ++it) r[it] = chunk[it * 256 + tid];
+#pragma unroll
+                for (int it = PR; it < PER; ++it)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(chunk + it * 256 + tid), (lds_ptr_t)(stage + (it * 256 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+                for (int it = 0; it < PR; ++it) *(uint4*)(stage + (it * 256 + tid) * 16) = r[it];
+                __builtin_amdgcn_s_waitcnt(0);
             } else {
                 uint4 r[PER];
 #pragma unroll
@@ -59,7 +80,7 @@ void run(const uint4* src, unsigned long long* cyc, unsigned* sink, int G, int s
     hipMemcpy(h.data(), cyc, G * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
     printf("%-9s %s chunk %2d KiB, %3d blocks: %6llu cycles per chunk = %5.1f B/clk per CU (min %llu, max %llu)\n",
-           MODE == 0 ? "LDS-DMA" : "registers", shared ? "shared (L2 hits)" : "private (misses) ", KB, G, h[G / 2], KB * 1024.0 / h[G / 2], h[0], h[G - 1]);
+           MODE == 0 ? "LDS-DMA" : MODE == 1 ? "registers" : MODE == 2 ? "mixed 1:3" : MODE == 3 ? "DMA bufdesc" : "DMA 192B runs", shared ? "shared (L2 hits)" : "private (misses) ", KB, G, h[G / 2], KB * 1024.0 / h[G / 2], h[0], h[G - 1]);
 }
 
 int main() {
@@ -68,9 +89,9 @@ int main() {
     hipMemset(src, 1, (size_t)256 << 20);
     for (int shared = 0; shared < 2; ++shared)
     for (int G : {144, 256}) {
-        run<0, 16>(src, cyc, sink, G, shared); run<1, 16>(src, cyc, sink, G, shared);
-        run<0, 32>(src, cyc, sink, G, shared); run<1, 32>(src, cyc, sink, G, shared);
-        run<0, 64>(src, cyc, sink, G, shared); run<1, 64>(src, cyc, sink, G, shared);
+        run<0, 16>(src, cyc, sink, G, shared); run<3, 16>(src, cyc, sink, G, shared); run<4, 16>(src, cyc, sink, G, shared);
+        run<0, 32>(src, cyc, sink, G, shared); run<3, 32>(src, cyc, sink, G, shared); run<4, 32>(src, cyc, sink, G, shared);
+        
     }
     return 0;
 }

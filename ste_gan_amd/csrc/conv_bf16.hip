@@ -342,7 +342,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         // around each X item: 130 cycles per DMA instruction, 1 300 per chunk -- the issue, not the memory system, set the
         // iteration time (scripts/micro/stage_rate.hip: the same ring staged with straight-line issue takes 625 / 890 cycles
         // per 16 / 32 KiB chunk on L2 hits, 1 150 / 1 540 on misses; the conv's iterations took 1 470 / 1 940).  Now: the number
-        // of items of THIS wave is one scalar (nw, nx), a switch falls through that many straight-line items, the weights go
+        // of items of THIS wave is one scalar (nw, nx), nested ifs run through that many straight-line items, the weights go
         // through a buffer descriptor too (offset register + scalar chunk offset: no address arithmetic per item), and the
         // lanes past the X tile are not masked: their offset is out of range, so they write zeros into the stage's padding.
         const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)wt_g, 0, (p.K + 1) * h.Mpad * h.Cpad * 2, 0x00020000);
@@ -354,26 +354,18 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         if (!HB_DBG(2)) {                                                                                       \
             char* Wd_ = smem + (buf_) * wbuf;                                                                   \
             const int so_ = (c_) * chunk_w;                                                                     \
-            switch (nw) {                                                                                       \
-                case 12: HB_W_IT(11) [[fallthrough]]; case 11: HB_W_IT(10) [[fallthrough]];                     \
-                case 10: HB_W_IT(9) [[fallthrough]];  case 9: HB_W_IT(8) [[fallthrough]];                       \
-                case 8: HB_W_IT(7) [[fallthrough]];   case 7: HB_W_IT(6) [[fallthrough]];                       \
-                case 6: HB_W_IT(5) [[fallthrough]];   case 5: HB_W_IT(4) [[fallthrough]];                       \
-                case 4: HB_W_IT(3) [[fallthrough]];   case 3: HB_W_IT(2) [[fallthrough]];                       \
-                case 2: HB_W_IT(1) [[fallthrough]];   case 1: HB_W_IT(0) [[fallthrough]];                       \
-                default: break;                                                                                 \
-            }                                                                                                   \
+            /* nested ifs on ONE scalar: compare + not-taken branch + M0 + load per item, one taken branch at the end */ \
+            if (nw > 0) { HB_W_IT(0) if (nw > 1) { HB_W_IT(1) if (nw > 2) { HB_W_IT(2) if (nw > 3) { HB_W_IT(3)         \
+            if (nw > 4) { HB_W_IT(4) if (nw > 5) { HB_W_IT(5) if (nw > 6) { HB_W_IT(6) if (nw > 7) { HB_W_IT(7)         \
+            if (nw > 8) { HB_W_IT(8) if (nw > 9) { HB_W_IT(9) if (nw > 10) { HB_W_IT(10) if (nw > 11) { HB_W_IT(11)     \
+            } } } } } } } } } } } }                                                                             \
         }
         static_assert(HW_MAX == 12 && HXD_MAX == 8, "the item switches of the lean DMA issue are written out for 12 / 8 items");
 #define HB_X_IT(i_, vo_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_h, (lds_ptr_t)(Xd_ + ((i_) * 256 + wave * 64) * 16), 16, vo_, sx_, 0, 0);
 #define HB_X_SW(VO_)                                                                                            \
-            switch (nx) {                                                                                       \
-                case 8: HB_X_IT(7, VO_(7)) [[fallthrough]]; case 7: HB_X_IT(6, VO_(6)) [[fallthrough]];         \
-                case 6: HB_X_IT(5, VO_(5)) [[fallthrough]]; case 5: HB_X_IT(4, VO_(4)) [[fallthrough]];         \
-                case 4: HB_X_IT(3, VO_(3)) [[fallthrough]]; case 3: HB_X_IT(2, VO_(2)) [[fallthrough]];         \
-                case 2: HB_X_IT(1, VO_(1)) [[fallthrough]]; case 1: HB_X_IT(0, VO_(0)) [[fallthrough]];         \
-                default: break;                                                                                 \
-            }
+            if (nx > 0) { HB_X_IT(0, VO_(0)) if (nx > 1) { HB_X_IT(1, VO_(1)) if (nx > 2) { HB_X_IT(2, VO_(2))          \
+            if (nx > 3) { HB_X_IT(3, VO_(3)) if (nx > 4) { HB_X_IT(4, VO_(4)) if (nx > 5) { HB_X_IT(5, VO_(5))          \
+            if (nx > 6) { HB_X_IT(6, VO_(6)) if (nx > 7) { HB_X_IT(7, VO_(7)) } } } } } } } }
 #define HB_VO_FULL(i_) (int)xd_voff[i_]
 #define HB_VO_RAG(i_) (xd_cb[i_] < live_ ? (int)xd_voff[i_] : (int)OOB)
 #define HB_DMA_X(c_, buf_)                                                                                      \

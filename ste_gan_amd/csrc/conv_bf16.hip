@@ -81,6 +81,10 @@ struct HP {
 __device__ __forceinline__ int vg(int s) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 __device__ __forceinline__ unsigned vg(unsigned s) { unsigned v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 
+#ifndef STEGAN_BF16_SCHED
+#define STEGAN_BF16_SCHED 1
+#endif
+constexpr bool SCHED_ON = STEGAN_BF16_SCHED != 0;
 constexpr int HXD_MAX = 8;     // X DMA wave-instructions per producer wave and chunk (8 x 256 pieces of 16 bytes = 32 KiB)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float a, float b, bool relu) {
@@ -397,7 +401,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         for (int j = 0; j < nch; ++j) {
             // chunk j must have landed before barrier j: the chunks issued after it may stay in flight
             const int younger = min(NS - 1, nch - j) - 1;            // chunks j + 1 .. issued so far
-            wait_vmcnt(younger * ipc);
+            if (NS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the common case without the switch of wait_vmcnt)
+            else wait_vmcnt(younger * ipc);
             if (j == 0) { PSTAMP(2) }                                // chunk 0 landed
             if (j == 5) { PSTAMP(5) }                                // chunk 5 landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -600,6 +605,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bj_, a_[i], acc[i][j], 0, 0, 0);                \
     }
     // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
+#define HB_SCHED if constexpr (TM * TN == 1 && SCHED_ON) __builtin_amdgcn_sched_barrier(0);
 #define HB_COMPUTE(c_)                                                                                          \
     if (!HB_DBG(4)) {                                                                                           \
         const char* Wcur = smem + stage_c * wbuf;                                                               \
@@ -609,9 +615,13 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         int s = 0;                                                                                              \
         for (; s + 1 < S; s += 2) {                                                                             \
             HB_LOAD(aB, bB, s + 1)                                                                              \
+            HB_SCHED      /* single-tile waves: the reads of step s + 1 go out BEFORE the MFMA of step s (hipcc sinks them behind it) */ \
             HB_MFMA(aA, bA)                                                                                     \
+            HB_SCHED                                                                                            \
             if (s + 2 < S) HB_LOAD(aA, bA, s + 2)                                                               \
+            HB_SCHED                                                                                            \
             HB_MFMA(aB, bB)                                                                                     \
+            HB_SCHED                                                                                            \
         }                                                                                                       \
         if (s < S) { HB_MFMA(aA, bA) }                                                                          \
     }
@@ -643,6 +653,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         stage_c = stage_c + 1 == NS ? 0 : stage_c + 1;
     }
 #undef HB_COMPUTE
+#undef HB_SCHED
 #undef HB_MFMA
 #undef HB_XFRAG
 #undef HB_LOAD

@@ -134,7 +134,9 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
     const int b_chunks = (b_end - b_begin + h.NB - 1) / h.NB;
     const int nchunks = b_chunks * h.u_chunks;
 
-    const int abuf = CBA * h.RSA * 16, xbuf = CBX * h.RSX * 16, bufsz = abuf + xbuf;
+    // (each image is padded to whole wave-instructions of 64 pieces: the image path's DMA lanes past the last plane are
+    // not masked, they write zeros there)
+    const int abuf = ((CBA * h.RSA + 63) & ~63) * 16, xbuf = ((CBX * h.RSX + 63) & ~63) * 16, bufsz = abuf + xbuf;
     const int xsh = XV ? 2 + h.ups : 0;
     const int xgm = (1 << xsh) - 1;
 
@@ -170,9 +172,8 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 const int seg = (int)fd_div((uint32_t)slot, h.fdRUp), uu = slot - seg * h.RUp;
                 a_seg[it] = seg; a_uu[it] = uu;
                 a_ldsb[it] = ii * 1024;
-                if (cg < CBA)
-                    a_lane[it] = (slot < h.R && cg < ylive && seg < h.NB && uu < h.RU)
-                                     ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : -2;
+                a_lane[it] = (cg < CBA && slot < h.R && cg < ylive && seg < h.NB && uu < h.RU)
+                                 ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : -2;
             }
             if (ii < nX) {
                 const int piece = ii * 64 + lane;
@@ -180,11 +181,27 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 const int seg = (int)fd_div((uint32_t)slot, h.fdSEG), sl = slot - seg * h.SEG;
                 x_seg[it] = seg; x_sl[it] = sl;
                 x_ldsb[it] = ii * 1024;
-                if (cg < CBX)
-                    x_lane[it] = (slot < h.xslots && cg < xlive) ? ((seg * CBx + ((g * h.Cin_g + ci0) >> 3) + cg) * h.Tin) * 16 : -2;
+                x_lane[it] = (cg < CBX && slot < h.xslots && cg < xlive) ? ((seg * CBx + ((g * h.Cin_g + ci0) >> 3) + cg) * h.Tin) * 16 : -2;
             }
         }
-        // -1: lane switched off (past the plane's staged slots); -2: staged as zeros
+        // -2: staged as zeros (padding slots, dead planes, and the lanes past the last plane: they land in the image's padding)
+        const int na_ = nA > wave ? (nA - wave + 3) >> 2 : 0, nx_ = nX > wave ? (nX - wave + 3) >> 2 : 0;
+        static_assert(WDI == 8, "WG_NEST is written out for 8 items");
+#define WG_NEST(n_, IT_) if (n_ > 0) { IT_(0) if (n_ > 1) { IT_(1) if (n_ > 2) { IT_(2) if (n_ > 3) { IT_(3)            \
+                         if (n_ > 4) { IT_(4) if (n_ > 5) { IT_(5) if (n_ > 6) { IT_(6) if (n_ > 7) { IT_(7) } } } } } } } }
+#define WG_A_IT(i_)                                                                                             \
+            {                                                                                                   \
+                const bool ok_ = a_lane[i_] >= 0 && b0_ + a_seg[i_] < b_end && u0_ + a_uu[i_] < h.Tout;         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr_t)(A_ + a_ldsb[i_]), 16,               \
+                                                         ok_ ? a_lane[i_] : (int)OOBW, so_y, 0, 0);             \
+            }
+#define WG_X_IT(i_)                                                                                             \
+            {                                                                                                   \
+                const int q_ = q0_ + x_sl[i_];                                                                  \
+                const bool ok_ = x_lane[i_] >= 0 && b0_ + x_seg[i_] < b_end && q_ >= 0 && q_ < h.Te;            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_ptr_t)(X_ + x_ldsb[i_]), 16,               \
+                                                         ok_ ? x_lane[i_] + (q_ >> h.ups) * 16 : (int)OOBW, so_x, 0, 0); \
+            }
 #define WG_DMA(c_, buf_)                                                                                        \
         {                                                                                                       \
             const int bc_ = (int)fd_div((uint32_t)(c_), h.fdUC), uc_ = (c_) - bc_ * h.u_chunks;                 \
@@ -193,21 +210,10 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
             char* A_ = smem + (buf_) * bufsz;                                                                   \
             char* X_ = A_ + abuf;                                                                               \
             const int so_y = (b0_ * CBy * h.Tout + u0_) * 16, so_x = b0_ * CBx * h.Tin * 16;                    \
-            _Pragma("unroll") for (int it = 0; it < WDI; ++it) {                                                \
-                if (a_ldsb[it] >= 0 && a_lane[it] != -1) {                                                      \
-                    const bool ok_ = a_lane[it] >= 0 && b0_ + a_seg[it] < b_end && u0_ + a_uu[it] < h.Tout;     \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr_t)(A_ + a_ldsb[it]), 16,           \
-                                                             ok_ ? a_lane[it] : (int)OOBW, so_y, 0, 0);         \
-                }                                                                                               \
-            }                                                                                                   \
-            _Pragma("unroll") for (int it = 0; it < WDI; ++it) {                                                \
-                if (x_ldsb[it] >= 0 && x_lane[it] != -1) {                                                      \
-                    const int q_ = q0_ + x_sl[it];                                                              \
-                    const bool ok_ = x_lane[it] >= 0 && b0_ + x_seg[it] < b_end && q_ >= 0 && q_ < h.Te;        \
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_ptr_t)(X_ + x_ldsb[it]), 16,           \
-                                                             ok_ ? x_lane[it] + (q_ >> h.ups) * 16 : (int)OOBW, so_x, 0, 0); \
-                }                                                                                               \
-            }                                                                                                   \
+            /* lean issue (conv_bf16.hip): the items of this wave are ONE scalar count each, nested ifs run through them in \
+               a straight line, no lane is masked */                                                           \
+            WG_NEST(na_, WG_A_IT)                                                                               \
+            WG_NEST(nx_, WG_X_IT)                                                                               \
         }
         // the blocks that share an operand slice walk its chunks from different starting points (conv_bf16.hip: at any moment
         // the sharers of a line fetch different chunks; all but the first touch are L2 hits); the sum is the same set of
@@ -230,6 +236,9 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
         return;
 #undef WG_CID
 #undef WG_DMA
+#undef WG_NEST
+#undef WG_A_IT
+#undef WG_X_IT
     } else {
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)h.x, 0, (int)h.x_bytes, 0x00020000);
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)h.dy, 0, (int)h.dy_bytes, 0x00020000);
@@ -730,7 +739,7 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
         if (img) {                                     // DMA pieces, not register items: <= WDI wave-instructions per wave
             if (ceil_div(ceil_div((BM / 8) * h.RSA, 64), 4) > WDI || ceil_div(ceil_div((BN / 8) * h.RSX, 64), 4) > WDI) return false;
         } else if (h.ait > (xv ? WSV_MAX : WS_MAX) || h.xit > (xv ? WSV_MAX : WS_MAX)) return false;
-        lds = 2 * ((size_t)(BM / 8) * h.RSA + (size_t)(BN / 8) * h.RSX) * 16;
+        lds = 2 * ((size_t)(((BM / 8) * h.RSA + 63) & ~63) + (size_t)(((BN / 8) * h.RSX + 63) & ~63)) * 16;
         return lds <= 160 * 1024;
     };
     if (!plan(RMAX0)) return 1;

@@ -20,7 +20,16 @@ def layer(Cin, Cout, K, d, p, relu, Tin):
 a = layer(768, 768, 1, 1, 0, False, 12)          # <1, 1, 3>
 b = layer(192, 192, 3, 9, 9, True, 192)          # <1, 2, 2>
 c = layer(768, 3072, 1, 1, 0, False, 12)         # <2, 2, 3>
+d = layer(512, 1024, 5, 1, 2, False, 48)         # another tile / chunk variant
+e = layer(384, 384, 3, 3, 3, True, 48)
+f = layer(768, 768, 3, 1, 1, True, 12)
 ta, tb, tc = timeit(a), timeit(b), timeit(c)
+td, te, tf = timeit(d), timeit(e), timeit(f)
+def six():
+    a(); b(); c(); d(); e(); f()
+t6 = timeit(six, n=5) / 6
+print(f"six layers alone: {ta:.2f} {tb:.2f} {tc:.2f} {td:.2f} {te:.2f} {tf:.2f} us (mean {(ta + tb + tc + td + te + tf) / 6:.2f}); in turn: {t6:.2f} us per launch")
+print("kernels:", [ops.LAST_CONV_KERNEL])
 def abc():
     a(); b(); c()
 def ab():

@@ -474,7 +474,7 @@ def main():
         # ordered teardown (ste_gan_amd.parallel.shutdown): every rank is done, drain the device, release the captured graphs
         # and the communication stream, then destroy the process group.  (Round 2 left through os._exit here: the abort it
         # dodged came from graph captures in the default "global" error mode racing the RCCL watchdog's event queries --
-        # fixed by capture_error_mode="thread_local" in GraphedTrainStep; scripts/teardown_probe.py reproduces both.)
+        # fixed by capture_error_mode="thread_local" in GraphedTrainStep, pinned by tests/test_host_logic.py.)
         from ste_gan_amd.parallel import shutdown
         dist.barrier()
         shutdown(step, eager_step)

@@ -538,8 +538,12 @@ int stegan_conv1d_fwd_skinny(const stegan_conv_desc* d, const float* x, const fl
                              const float* bias, const float* residual, float* y, void* stream);
 int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
                                   const float* mask_src, const float* add_src, float* dx, void* stream);
+/* (weight gradient: the blocks' partial sums go to `workspace` -- stegan_conv1d_bwd_weight_skinny_floats() floats at most
+ * -- and a second launch adds them into dw / db in a fixed order: no float atomics, reproducible gradients; returns 1
+ * when the workspace is missing or too small) */
 int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
-                                    void* stream);
+                                    float* workspace, int64_t workspace_floats, void* stream);
+int64_t stegan_conv1d_bwd_weight_skinny_floats(const stegan_conv_desc* d);
 /* The forward / input gradient of n <= 5 single-output-channel convs in ONE launch (the output convs of the period
  * discriminators, discriminator.py:31: one per sub-discriminator, own batch B * period and length each).  Arrays of n
  * HOST entries; returns 1 (nothing enqueued) unless stegan_conv1d_fwd_skinny would take every problem. */
@@ -550,7 +554,8 @@ int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const
                                         const float* const* w, const float* const* scale, float* const* dx, void* stream);
 /* ... and their weight gradients: dw[i] += raw direction gradient, db[i] (array or entries may be NULL) += sum of dy[i]. */
 int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
-                                          const float* const* dy, float* const* dw, float* const* db, void* stream);
+                                          const float* const* dy, float* const* dw, float* const* db, float* workspace,
+                                          int64_t workspace_floats, void* stream);
 
 int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, int32_t T, void* stream);
 

@@ -112,10 +112,10 @@ SIGNATURES = {
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
     "stegan_conv1d_fwd_skinny": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_skinny": [_P, _P, _P, _P, _P, _P, _P, _P],
-    "stegan_conv1d_bwd_weight_skinny": [_P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_weight_skinny": [_D, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_fwd_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P],
-    "stegan_conv1d_bwd_weight_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_weight_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add_multi": [_I32, _P, _P, _P, _P, _P, _I32, _P],
@@ -130,6 +130,7 @@ INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_conv_prep_bf16_elems": [_D, _I32],
                 "stegan_conv_prep_bf16_tiles": [_D],
                 "stegan_conv_workspace_floats": [_D, _I32],
+                "stegan_conv1d_bwd_weight_skinny_floats": [_D],
                 "stegan_kernel_timing_count": []}
 
 _lib = None

@@ -96,7 +96,9 @@ __device__ static inline float wave_sum(float v) {
 // db[c] += sum_{b,t} dy[b,c,t] for channel c over batch slice `slice` (per rows each).  The block's threads run over the
 // flattened (b, t) pairs of its slice -- 16 bytes per lane when rows are float4 aligned -- so short rows (T = 12) keep
 // every lane busy (the first version put the threads along t only: 12 of 256 lanes active, up to 119 us per call in the
-// round-2 profile).  256 threads; slices meet in an fp32 atomic.
+// round-2 profile).  256 threads.  ONE block per channel owns db[c] (bias_grad_slices() == 1 since round 4): the sum has a
+// fixed order and the add is a plain read-modify-write -- no float atomics anywhere in the gradient path, so two launches
+// of one train step give bit-identical parameters (launches that add into the same db are stream ordered).
 __device__ static inline void bias_grad_body(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int T,
                                              int per, FastDiv fdT, int vec, int c, int slice) {
     const int b0 = slice * per, b1 = min(B, b0 + per);
@@ -119,18 +121,15 @@ __device__ static inline void bias_grad_body(const float* __restrict__ dy, float
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) bias_part[threadIdx.x >> 6] = s;
     block_sync();
-    if (threadIdx.x == 0) atomicAdd(&db[c], bias_part[0] + bias_part[1] + bias_part[2] + bias_part[3]);
+    if (threadIdx.x == 0) db[c] += (bias_part[0] + bias_part[1]) + (bias_part[2] + bias_part[3]);
 }
 
-// batch slices per channel: enough blocks to fill the chip, each with >= 256 elements
+// batch slices per channel: one.  (Rounds 1-3 cut a channel's rows into slices that met in an fp32 atomic: the order of
+// those adds changed from launch to launch, and in bf16 mode a last-bit difference in a bias flips operand roundings two
+// layers on -- the step was not reproducible.  A channel's B x T values are at most a few 10^4: one block sums them.)
 static inline int bias_grad_slices(int B, int C, int T) {
-    int sl = 1024 / (C > 0 ? C : 1);
-    if (sl < 1) sl = 1;
-    const long per_ch = (long)B * T;
-    if (sl > per_ch / 256) sl = (int)(per_ch / 256);
-    if (sl < 1) sl = 1;
-    if (sl > B) sl = B;
-    return sl;
+    (void)B; (void)C; (void)T;
+    return 1;
 }
 
 // conv_wgrad.hip: direct weight-gradient kernel; returns 1 when the caller should use the generic implicit GEMM

@@ -33,8 +33,11 @@ struct ConvK {
     const float* bias;   // (Cout) or null           (FWD)
     const float* res;    // residual / add_src or null
     const float* mask;   // BWD_DATA: pre-activation input (B,Cin,Tin) or null
-    float* out;          // FWD: y, BWD_DATA: dx (B,Cin,Te), BWD_WEIGHT: dw (atomic accumulate)
-    float* db;           // BWD_WEIGHT: bias gradient (atomic accumulate) or null -- row sums of the dy tile
+    float* out;          // FWD: y, BWD_DATA: dx (B,Cin,Te), BWD_WEIGHT: dw (accumulated; with `partial` the slices' slabs)
+    float* db;           // BWD_WEIGHT: bias gradient (accumulated) or null -- row sums of the dy tile
+    float* partial;      // BWD_WEIGHT with > 1 slice of the reduction: [splits][dw numel] slabs + [splits][Cout] bias sums,
+                         // summed in a fixed order by igemm_wgrad_reduce_kernel (no float atomics: reproducible gradients)
+    long dw_numel;
     int B, Cin, Cout, K, stride, dil, pad, Tin, Tout, Te, ups;  // ups = log2(upsample)
     int in_act, out_act, out_btc;
     int Cin_g, Cout_g;
@@ -219,7 +222,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
         block_sync();
     }
 
-    if (do_bias && m0 + tid < p.M) atomicAdd(&p.db[g * p.Cout_g + m0 + tid], bsum);
+    if (do_bias && m0 + tid < p.M) {                     // (first N tile of every (M tile, slice): the channel's only writer)
+        const int ch = g * p.Cout_g + m0 + tid;
+        if (p.partial) p.partial[(size_t)gridDim.z * p.dw_numel + (size_t)blockIdx.z * p.Cout + ch] = bsum;
+        else p.db[ch] += bsum;
+    }
     // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -256,10 +263,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
                     if (p.res) v += p.res[idx];
                     p.out[idx] = v;
                 } else {
-                    atomicAdd(&p.out[((size_t)(g * p.Cout_g + m) * p.Cin_g + q0) * p.K + q1 + p.k_lo], v);
+                    const size_t idx = ((size_t)(g * p.Cout_g + m) * p.Cin_g + q0) * p.K + q1 + p.k_lo;
+                    if (p.partial) p.partial[(size_t)blockIdx.z * p.dw_numel + idx] = v;      // this slice's slab
+                    else p.out[idx] += v;                    // ONE slice: every element has a single writer
                 }
             }
         }
+    }
+}
+
+// dW += the slices' slabs, db += their bias sums, each in slice order (live taps only: dead taps were never written)
+__global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                 long numel, int splits, int K, int k_lo, int K_eff,
+                                                                 float* __restrict__ db, int Cout) {
+    if (db) {
+        const float* bp = partial + (size_t)splits * numel;
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < Cout; c += (long)gridDim.x * 256) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += bp[(size_t)s * Cout + c];
+            db[c] += v;
+        }
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        if (k < k_lo || k >= k_lo + K_eff) continue;
+        const float* src = partial + i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * numel];
+        }
+        for (; s < splits; ++s) v[0] += src[(size_t)s * numel];
+        dw[i] += (v[0] + v[1]) + (v[2] + v[3]);
     }
 }
 
@@ -305,6 +341,8 @@ int fill_common(const stegan_conv_desc* d, ConvK& p) {
     p.x = p.w = p.dy = p.scale = p.bias = p.res = p.mask = nullptr;
     p.out = nullptr;
     p.db = nullptr;
+    p.partial = nullptr;
+    p.dw_numel = (long)d->Cout * p.Cin_g * d->K;
     return STEGAN_OK;
 }
 
@@ -314,18 +352,18 @@ inline bool use_big_tile(const ConvK& p, int groups, int splits) {
     return tiles128 >= 512 && p.M >= 96;
 }
 
-inline int bwd_weight_splits(ConvK& p, int groups) {
-    // split the (b,t) reduction so the grid fills the chip; partial sums meet in fp32 atomics
+inline int bwd_weight_splits(ConvK& p, int groups, long max_splits = 1 << 30) {
+    // split the (b,t) reduction so the grid fills the chip; the slices write slabs that a second kernel sums in order
     const int chunks = ceil_div(p.R, KC);
     const long tiles = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * groups;
     static const char* env_tgt = getenv("STEGAN_WGRAD_TARGET");          // blocks to aim for (experiments)
     const long target = env_tgt ? atol(env_tgt) : 256;        // (1024 at first: 7.49 vs 7.46 ms/step -- these run beside other streams)
     int splits = (int)((target + tiles - 1) / tiles);
-    // every split ends in one atomic per output element, and same-address atomics serialise in L2 (~13 ns each): beyond a
-    // few hundred splits a tiny dw (8 -> 32 channels: ONE tile, 880 splits of one 16-deep chunk each) is atomics-bound
+    // every split costs a slab written and read back (these layers' dW are small: 8 -> 128 k15 is 61 KB)
     static const char* env_cap = getenv("STEGAN_WGRAD_SPLIT_CAP");
-    const int cap = env_cap ? atoi(env_cap) : 256;
+    const int cap = env_cap ? atoi(env_cap) : 64;
     if (splits > cap) splits = cap;
+    if (splits > max_splits) splits = (int)max_splits;
     if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
     p.r_chunks_per_split = ceil_div(chunks, splits);
@@ -389,8 +427,19 @@ static int bwd_weight_impl(const stegan_conv_desc* d, const float* x, const floa
     p.x = x; p.dy = dy; p.out = dw; p.db = db;
     p.M = p.Cout_g; p.N = p.Cin_g * p.K_eff; p.R = d->B * d->Tout;
     p.fdT = make_fastdiv((uint32_t)d->Tout);
-    const int splits = bwd_weight_splits(p, d->groups);
-    return launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
+    // slices of the reduction need slabs: without a workspace ONE slice adds straight into dW (slow, still deterministic)
+    const long per_slice = p.dw_numel + d->Cout;
+    const long max_splits = (workspace && workspace_floats >= 2 * per_slice) ? workspace_floats / per_slice : 1;
+    const int splits = bwd_weight_splits(p, d->groups, max_splits);
+    if (splits > 1) p.partial = workspace;
+    rc = launch<MODE_BWD_WEIGHT>(p, d->groups, splits, (hipStream_t)stream);
+    if (rc || splits == 1) return rc;
+    long rb = (p.dw_numel + 255) / 256;
+    if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(igemm_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, (hipStream_t)stream, p.partial, dw,
+                       p.dw_numel, splits, d->K, p.k_lo, p.K_eff, db, d->Cout);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
 }
 
 extern "C" int stegan_conv1d_bwd_weight(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,

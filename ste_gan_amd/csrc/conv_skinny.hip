@@ -13,8 +13,6 @@
 // Every entry point returns 1 for a shape it does not take (caller falls through to the general kernels).
 #include "common.h"
 
-extern "C" int stegan_bias_grad(const float* dy, float* db, int32_t B, int32_t C, int32_t T, void* stream);
-
 namespace {
 
 constexpr int SK_KMAX = 8;
@@ -29,6 +27,8 @@ struct SkP {
     int B, Cin, K, stride, dil, pad, Tin, Tout, out_act;
     int TT, CL;           // forward: time-tile width, channel lanes per block (TT * CL <= 256)
     int per;              // weight gradient: batch rows per block
+    int nqt;              // weight gradient: time tiles per batch slice (slab index = slice * nqt + time tile)
+    float* part;          // weight gradient: slabs [slices * nqt][Cin * K], then [slices] bias sums
     FastDiv fdTT, fdS, fdTin, fdCT, fdCL;
 };
 
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256) void conv_cout1_bwd_data_multi_kernel(const Sk
 // weight gradient: block = (CL channels, slice of `per` batch rows, tile of TT <= 64 input steps); thread = (input step
 // q, channel): it walks the batch rows of its slice with x[b, c, q] -- consecutive lanes consecutive addresses, the CL
 // rows of a block contiguous -- against the <= K dy values that pair with q, then the TT steps of a channel meet in LDS
-// and one thread per (channel, tap) adds the block's sum into dw with an fp32 atomic (as the split-K sums of the general
-// weight-gradient kernels do).  (A lane-per-channel version read x with a row stride between lanes: 64 cache lines per
+// and one thread per (channel, tap) stores the block's sum into the block's slab; conv_cout1_wgrad_reduce_kernel adds the
+// slabs into dw in a fixed order (rounds 1-3 met in dw through fp32 atomics, whose order changed from launch to launch).  (A lane-per-channel version read x with a row stride between lanes: 64 cache lines per
 // load instruction, 32 us.)
 __device__ __forceinline__ void conv_cout1_wgrad_body(const SkP& p, int bx, int by, int bz) {
     __shared__ float red[SK_KMAX][256];
@@ -191,19 +191,32 @@ __device__ __forceinline__ void conv_cout1_wgrad_body(const SkP& p, int bx, int 
         if (cc < p.Cin) {
             float s = 0.f;
             for (int j = 0; j < p.TT; ++j) s += red[k][cj * p.TT + j];
-            atomicAdd(&p.out[(size_t)cc * p.K + k], s);
+            p.part[(size_t)(by * p.nqt + bz) * p.Cin * p.K + (size_t)cc * p.K + k] = s;
         }
     }
-}
-
-__global__ __launch_bounds__(256) void conv_cout1_wgrad_kernel(const SkP p) {
-    conv_cout1_wgrad_body(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // the weight gradients of up to SK_MULTI problems in one launch; blockIdx.x runs over the problems' channel blocks
 // (first[]); the first channel block / first time tile of a problem also sums dy of its batch slice into the bias
 // gradient (one output channel: db is ONE number per problem)
-struct SkMultiW { int n; int first[SK_MULTI + 1]; SkP p[SK_MULTI]; float* db[SK_MULTI]; };
+struct SkMultiW { int n; int first[SK_MULTI + 1]; SkP p[SK_MULTI]; float* db[SK_MULTI]; int nsl[SK_MULTI]; };
+
+// dw[i] += sum over the slabs, db += sum over the slices' bias sums, both in slab order; blockIdx.y = problem
+__global__ __launch_bounds__(256) void conv_cout1_wgrad_reduce_kernel(const SkMultiW a) {
+    const SkP& p = a.p[blockIdx.y];
+    const int nslab = a.nsl[blockIdx.y] * p.nqt, n = p.Cin * p.K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float v = 0.f;
+        for (int j = 0; j < nslab; ++j) v += p.part[(size_t)j * n + i];
+        p.out[i] += v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.db[blockIdx.y]) {
+        const float* bp = p.part + (size_t)nslab * n;
+        float v = 0.f;
+        for (int j = 0; j < a.nsl[blockIdx.y]; ++j) v += bp[j];
+        *a.db[blockIdx.y] += v;
+    }
+}
 
 __global__ __launch_bounds__(256) void conv_cout1_wgrad_multi_kernel(const SkMultiW a) {
     int k = 0;
@@ -225,7 +238,8 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_multi_kernel(const SkMul
         float s = wave_sum(s0 + s1);
         if ((threadIdx.x & 63) == 0) bred[threadIdx.x >> 6] = s;
         block_sync();
-        if (threadIdx.x == 0) atomicAdd(a.db[k], (bred[0] + bred[1]) + (bred[2] + bred[3]));
+        if (threadIdx.x == 0)
+            p.part[(size_t)a.nsl[k] * p.nqt * p.Cin * p.K + blockIdx.y] = (bred[0] + bred[1]) + (bred[2] + bred[3]);
         block_sync();
     }
     conv_cout1_wgrad_body(p, bx, blockIdx.y, blockIdx.z);
@@ -246,7 +260,8 @@ int fill(const stegan_conv_desc* d, SkP& p) {
     p.fdS = make_fastdiv((uint32_t)d->stride);
     p.fdTin = make_fastdiv((uint32_t)d->Tin);
     p.fdCT = make_fastdiv((uint32_t)(d->Cin * d->Tin));
-    p.TT = p.CL = p.per = 1;
+    p.TT = p.CL = p.per = p.nqt = 1;
+    p.part = nullptr;
     p.fdTT = make_fastdiv(1); p.fdCL = make_fastdiv(1);
     p.x = p.w = p.dy = p.scale = p.bias = nullptr;
     p.out = nullptr;
@@ -355,23 +370,38 @@ static void sk_wgrad_geometry(const stegan_conv_desc* d, SkP& p, int& cblocks, i
     if (p.CL * d->K > 256) p.CL = 256 / d->K;
     p.fdTT = make_fastdiv((uint32_t)p.TT); p.fdCL = make_fastdiv((uint32_t)p.CL);
     cblocks = ceil_div(d->Cin, p.CL); qtiles = ceil_div(d->Tin, p.TT);
-    slices = ceil_div(512, cblocks * qtiles);             // ~2 blocks per CU; every slice ends in Cin x K atomics
+    slices = ceil_div(512, cblocks * qtiles);             // ~2 blocks per CU; every slice writes a slab of Cin x K sums
     if (slices > d->B) slices = d->B;
     if (slices > 64) slices = 64;
     p.per = ceil_div(d->B, slices);
     slices = ceil_div(d->B, p.per);
+    p.nqt = qtiles;
+}
+
+static int64_t sk_wgrad_floats(const stegan_conv_desc* d, int slices, int qtiles) {
+    return ((int64_t)slices * qtiles * d->Cin * d->K + slices + 3) & ~(int64_t)3;
+}
+
+extern "C" int64_t stegan_conv1d_bwd_weight_skinny_floats(const stegan_conv_desc* d) {
+    SkP p;
+    if (fill(d, p)) return 0;
+    int cb, sl, qt;
+    sk_wgrad_geometry(d, p, cb, sl, qt);
+    return sk_wgrad_floats(d, sl, qt);
 }
 
 // dw[i] (+ db[i], may be NULL) of n <= 5 single-output-channel convs in one launch; returns 1 (nothing enqueued) unless
 // stegan_conv1d_bwd_weight_skinny would take every problem
 extern "C" int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                                      const float* const* dy, float* const* dw, float* const* db,
-                                                     void* stream) {
+                                                     float* workspace, int64_t workspace_floats, void* stream) {
     STEGAN_CHECK_ARG(n >= 1 && descs && x && dy && dw);
-    if (n > SK_MULTI) return 1;
+    if (n > SK_MULTI || !workspace) return 1;
     SkMultiW a;
     a.n = n; a.first[0] = 0;
     int gy = 1, gz = 1;
+    int64_t used = 0;
+    int most = 1;
     for (int i = 0; i < n; ++i) {
         SkP& p = a.p[i];
         int rc = fill(descs[i], p);
@@ -382,28 +412,29 @@ extern "C" int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_con
         int cb, sl, qt;
         sk_wgrad_geometry(descs[i], p, cb, sl, qt);
         a.first[i + 1] = a.first[i] + cb;
+        a.nsl[i] = sl;
+        p.part = workspace + used;
+        used += sk_wgrad_floats(descs[i], sl, qt);
+        if (used > workspace_floats) return 1;              // (nothing enqueued yet)
         if (sl > gy) gy = sl;
         if (qt > gz) gz = qt;
+        if (descs[i]->Cin * descs[i]->K > most) most = descs[i]->Cin * descs[i]->K;
     }
-    for (int i = n; i < SK_MULTI; ++i) a.db[i] = nullptr;
+    for (int i = n; i < SK_MULTI; ++i) { a.db[i] = nullptr; a.nsl[i] = 0; }
     hipLaunchKernelGGL(conv_cout1_wgrad_multi_kernel, dim3((unsigned)a.first[n], (unsigned)gy, (unsigned)gz), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv_cout1_wgrad_reduce_kernel, dim3((unsigned)ceil_div(most, 256), (unsigned)n), dim3(256), 0,
                        (hipStream_t)stream, a);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
 
 extern "C" int stegan_conv1d_bwd_weight_skinny(const stegan_conv_desc* d, const float* x, const float* dy, float* dw,
-                                               float* db, void* stream) {
-    SkP p;
-    int rc = fill(d, p);
-    if (rc) return rc;
-    STEGAN_CHECK_ARG(x && dy && dw);
-    p.x = x; p.dy = dy; p.out = dw;
-    int cblocks, slices, qtiles;
-    sk_wgrad_geometry(d, p, cblocks, slices, qtiles);
-    hipLaunchKernelGGL(conv_cout1_wgrad_kernel, dim3((unsigned)cblocks, (unsigned)slices, (unsigned)qtiles),
-                       dim3(256), 0, (hipStream_t)stream, p);
-    STEGAN_LAUNCH_CHECK();
-    if (db) return stegan_bias_grad(dy, db, d->B, 1, d->Tout, stream);
-    return STEGAN_OK;
+                                               float* db, float* workspace, int64_t workspace_floats, void* stream) {
+    const stegan_conv_desc* descs[1] = {d};
+    const float* xs[1] = {x};
+    const float* dys[1] = {dy};
+    float* dws[1] = {dw};
+    float* dbs[1] = {db};
+    return stegan_conv1d_bwd_weight_skinny_multi(1, descs, xs, dys, dws, dbs, workspace, workspace_floats, stream);
 }

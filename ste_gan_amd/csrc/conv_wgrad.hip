@@ -12,7 +12,9 @@
 //     short sequences (T < 32) pack several batch items into one chunk, each with its own halo'd row segment;
 //   * v_mfma_f32_32x32x2_f32: A[m][r] = dy_s[m][r] (pitch 33: conflict free), B[r][ci] = x_s[ci][t(r)*s + k*d] (odd
 //     pitch: conflict free) -- one A read feeds KT MFMAs, the tap shift is an address offset into the halo'd row;
-//   * partial sums of the batch slices meet in dW through float atomics (dW is the zero-initialised gradient arena).
+//   * the batch slices write slabs of a workspace and a second kernel adds them into dW (and the slices' bias sums into
+//     db) in a fixed order; a single slice adds straight into dW with plain read-modify-writes (every element has one
+//     writer).  No float atomics: the gradient path is bit-reproducible from launch to launch (round 4).
 #include <stdlib.h>
 
 #include "common.h"
@@ -26,7 +28,7 @@ struct WgP {
     const float* dy;
     float* dw;
     float* db;
-    float* partial;              // [splits][dW numel] slabs (NULL: batch slices meet in dW through float atomics)
+    float* partial;              // [splits][dW numel] slabs, then [splits][Cout] bias sums (NULL: ONE slice, adds into dW / db)
     long dw_numel;
     int B, Cin, Cout, Cin_g, Cout_g, K, stride, dil, pad, Tin, Te, Tout, ups, relu;
     int k_lo, K_eff;             // live taps [k_lo, k_lo + K_eff)
@@ -224,11 +226,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 #undef WG_LOAD
 #undef WG_STORE
 
-    if (do_bias && m0 + tid < p.Cout_g) atomicAdd(&p.db[g * p.Cout_g + m0 + tid], bsum);
-    // ---- epilogue.  Float atomics cost one memory transaction per touched 64-byte line, so the block first folds its
-    // two reduction-parity halves together in LDS and then adds its 64 x (32 ci x ktaps) tile with lanes running along
-    // the (ci, k) axis of dW -- contiguous floats -- instead of one strided element per lane straight out of the MFMA
-    // registers.  C/D map of the 32x32 MFMA: col = lane & 31 (ci), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (co).
+    if (do_bias && m0 + tid < p.Cout_g) {            // one block per (channel tile, slice) holds the bias sum: single writer
+        const int ch = g * p.Cout_g + m0 + tid;
+        if (p.partial) p.partial[(size_t)gridDim.z * p.dw_numel + (size_t)blockIdx.z * p.Cout + ch] = bsum;
+        else p.db[ch] += bsum;
+    }
+    // ---- epilogue.  The block first folds its two reduction-parity halves together in LDS and then writes its
+    // 64 x (32 ci x ktaps) tile with lanes running along the (ci, k) axis of dW -- contiguous floats -- instead of one
+    // strided element per lane straight out of the MFMA registers.  C/D map of the 32x32 MFMA: col = lane & 31 (ci), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (co).
     constexpr int OP = 32 * KT + 1;
     float* out_s = smem;                                  // [64][OP], column = kt * 32 + ci  (staging buffers are dead)
     if (wn == 1) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
             if (ci0 + cil < p.Cin_g) {
                 const float v = out_s[row * OP + kt * 32 + cil];
                 if (p.partial) drow[cil * p.K + kt] = v;
-                else atomicAdd(drow + cil * p.K + kt, v);
+                else drow[cil * p.K + kt] += v;           // single slice: this block is the element's only writer
             }
         }
     }
@@ -269,7 +274,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgP p) {
 
 // dW += sum over the batch slices' slabs (fixed order: deterministic); dead taps were never written and are skipped
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                long numel, int splits, int K, int k_lo, int K_eff) {
+                                                                long numel, int splits, int K, int k_lo, int K_eff,
+                                                                float* __restrict__ db, int Cout) {
+    if (db) {                                             // the slices' bias sums: [splits][Cout] behind the slabs
+        const float* bp = partial + (size_t)splits * numel;
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < Cout; c += (long)gridDim.x * 256) {
+            float v = 0.f;
+            for (int s = 0; s < splits; ++s) v += bp[(size_t)s * Cout + c];
+            db[c] += v;
+        }
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < numel; i += (long)gridDim.x * 256) {
         const int k = (int)(i % K);
         if (k < k_lo || k >= k_lo + K_eff) continue;
@@ -344,12 +358,12 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
     // Slices of the reduction (whole chunks, not whole items, so any slice count works): aim at two co-resident blocks
     // per CU -- a multiple of the CU count keeps the CUs evenly loaded -- with at least 3 chunks per block.  The slices
     // write slabs of `workspace` (plain stores + one deterministic reduction pass); with a short workspace use fewer,
-    // longer slices; without one fall back to float atomics (one memory transaction per element: slow).
+    // longer slices; without one run ONE slice (slow, still deterministic).
     p.total_chunks = p.nct ? d->B * p.nct : ceil_div(d->B, p.nbc);
     long max_splits = 1;
     p.partial = nullptr;
-    if (workspace && workspace_floats >= 2 * p.dw_numel) {
-        max_splits = workspace_floats / p.dw_numel;
+    if (workspace && workspace_floats >= 2 * (p.dw_numel + d->Cout)) {
+        max_splits = workspace_floats / (p.dw_numel + d->Cout);
         p.partial = workspace;
     }
     static const char* env_cap = getenv("STEGAN_WG_MAX_SPLITS");         // experiments
@@ -399,7 +413,7 @@ int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* 
         long rb = (p.dw_numel + 255) / 256;
         if (rb > 2048) rb = 2048;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, stream, p.partial, dw, p.dw_numel,
-                           splits, d->K, p.k_lo, p.K_eff);
+                           splits, d->K, p.k_lo, p.K_eff, db, d->Cout);
     }
 #undef WG_LAUNCH
     STEGAN_LAUNCH_CHECK();

@@ -557,7 +557,7 @@ __device__ __forceinline__ void wg_bias_block(const BiasW& ba, int j) {
     if (threadIdx.x == 0) {
         float tot = 0.f;
         for (int w = 0; w < 8; ++w) tot += part[w];
-        atomicAdd(&ba.db[c], tot);
+        ba.db[c] += tot;               // ba.slices == 1: this block is the only writer of db[c] (fixed order, no atomics)
     }
 }
 

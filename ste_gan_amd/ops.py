@@ -247,13 +247,24 @@ IMG_STATS: Optional[dict] = None      # diagnostics (scripts/image_coverage.py):
 
 
 def _image_of(t: Optional[Tensor], channels: int, length: int) -> Optional[Tensor]:
-    """The bf16 image attached to ``t`` when it matches (B, ceil(C/8), T, 8), else None."""
+    """The bf16 image attached to ``t`` when it matches (B, ceil(C/8), T, 8) AND ``t`` has not been written in place since
+    the image was attached (autograd's gradient buffers add_ into the tensor they hold when it is the last reference; a
+    user's in-place op does the same): the image would then show the old values.  Else None."""
     h = getattr(t, "h", None) if (t is not None and IMAGES and COMPUTE_DTYPE == "bf16") else None
     if h is None or h.dtype != torch.bfloat16 or not h.is_contiguous():
         return None
     if tuple(h.shape) != (t.shape[0], (channels + 7) // 8, length, 8) or h.device != t.device:
         return None
+    if getattr(t, "h_version", None) != t._version:
+        return None
     return h
+
+
+def _attach_image(t: Tensor, h: Optional[Tensor]) -> None:
+    """Hang the bf16 image ``h`` on ``t`` together with the in-place version of ``t`` it mirrors (see _image_of)."""
+    if h is not None:
+        t.h = h
+        t.h_version = t._version
 
 
 def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optional[Tensor]:
@@ -268,26 +279,57 @@ def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optiona
 # The step needs ~30 zero-initialised buffers (loss words, counters, the spectral-norm layers' raw weight gradients): one
 # torch.zeros() -- one fill launch -- each.  Inside GANTrainStep they are carved from ONE pool that a single fill zeroes at
 # the start of the step (zero_pool_begin); outside a step pooled_zeros() is torch.zeros().
-_ZPOOL = {"buf": None, "off": 0, "active": False}
+#
+# Invariants (round 4, after the advisor's review):
+#   * everything beyond a buffer's high-water mark ``dirty`` (the most bytes any step has handed out of it since it was
+#     last filled whole) is zero; zero_pool_begin() clears [0, dirty) -- so a step that needs MORE than the one before it
+#     still gets zeros, whether the earlier step ran eagerly, was captured, or is being replayed;
+#   * a captured step bakes the size of that fill into its graph: zero_pool_end() raises when the capture handed out more
+#     than its own fill covered (a replay would then reuse bytes nobody clears);
+#   * a step that dies leaves the pool through zero_pool_abort(): closed, and marked dirty as a whole;
+#   * two buffers alternate between eager steps, so the scalars a step returns (views of its pool) stay valid while the
+#     NEXT step runs; a replayed graph owns the buffer it was captured with (static outputs, as with any hipGraph).
+#   * ``floor``: what captured steps take of a buffer -- their replays dirty it behind the host's back, any number of times.
+_ZPOOL = {"bufs": [None, None], "dirty": [0, 0], "floor": [0, 0], "cur": 0, "off": 0, "active": False, "filled": 0}
 ZERO_POOL_BYTES = int(os.environ.get("STEGAN_ZERO_POOL_MB", "48")) << 20
 
 
 def zero_pool_begin(device) -> None:
     if ZERO_POOL_BYTES <= 0:
         return
-    if _ZPOOL["buf"] is None or _ZPOOL["buf"].device != torch.device(device):
-        _ZPOOL["buf"] = torch.empty(ZERO_POOL_BYTES, device=device, dtype=torch.uint8)
-        _ZPOOL["used"] = ZERO_POOL_BYTES
-    # zero what the previous step handed out (the whole pool the first time)
-    n = min(ZERO_POOL_BYTES, (_ZPOOL.get("used", ZERO_POOL_BYTES) + 255) & ~255)
-    _ZPOOL["buf"][:n].zero_()
-    _ZPOOL["off"], _ZPOOL["active"] = 0, True
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:
+        _ZPOOL["cur"] ^= 1                     # (a capture keeps the buffer of the eager step before it: its dirty mark
+    i = _ZPOOL["cur"]                          #  is that step's usage, which is what the captured step will use)
+    buf = _ZPOOL["bufs"][i]
+    if buf is None or buf.device != torch.device(device):
+        buf = _ZPOOL["bufs"][i] = torch.empty(ZERO_POOL_BYTES, device=device, dtype=torch.uint8)
+        _ZPOOL["dirty"][i] = ZERO_POOL_BYTES
+    n = min(ZERO_POOL_BYTES, (max(_ZPOOL["dirty"][i], _ZPOOL["floor"][i], 256) + 255) & ~255)
+    buf[:n].zero_()
+    if not capturing:
+        _ZPOOL["dirty"][i] = 0                 # (a captured fill executes at replay time: the mark stays)
+    _ZPOOL["off"], _ZPOOL["active"], _ZPOOL["filled"] = 0, True, n
 
 
 def zero_pool_end() -> None:
-    if _ZPOOL["active"]:
-        _ZPOOL["used"] = max(_ZPOOL["off"], 256)
+    if not _ZPOOL["active"]:
+        return
     _ZPOOL["active"] = False
+    i, off = _ZPOOL["cur"], _ZPOOL["off"]
+    _ZPOOL["dirty"][i] = max(_ZPOOL["dirty"][i], off)
+    if torch.cuda.is_current_stream_capturing():
+        _ZPOOL["floor"][i] = max(_ZPOOL["floor"][i], off)
+    if torch.cuda.is_current_stream_capturing() and off > _ZPOOL["filled"]:
+        raise RuntimeError(f"ste_gan_amd: the captured step takes {off} bytes of zeroed scratch but its fill covers "
+                           f"{_ZPOOL['filled']}: run the step eagerly once before capturing it")
+
+
+def zero_pool_abort() -> None:
+    """Exception path of a step: close the pool and treat the whole buffer as dirty."""
+    if _ZPOOL["active"]:
+        _ZPOOL["active"] = False
+        _ZPOOL["dirty"][_ZPOOL["cur"]] = ZERO_POOL_BYTES
 
 
 def pooled_zeros(shape, device, dtype=torch.float32) -> Tensor:
@@ -298,11 +340,11 @@ def pooled_zeros(shape, device, dtype=torch.float32) -> Tensor:
         n *= int(d_)
     nbytes = n * torch.empty((), dtype=dtype).element_size()
     off = (_ZPOOL["off"] + 15) & ~15
-    if not _ZPOOL["active"] or _ZPOOL["buf"] is None or _ZPOOL["buf"].device != torch.device(device) or \
-            off + nbytes > ZERO_POOL_BYTES:
+    buf = _ZPOOL["bufs"][_ZPOOL["cur"]] if _ZPOOL["active"] else None
+    if buf is None or buf.device != torch.device(device) or off + nbytes > ZERO_POOL_BYTES:
         return torch.zeros(shape, device=device, dtype=dtype)
     _ZPOOL["off"] = off + nbytes
-    return _ZPOOL["buf"][off:off + nbytes].view(dtype).view(shape)
+    return buf[off:off + nbytes].view(dtype).view(shape)
 
 
 # ---- diagnostics: time marks inside the (captured) step, scripts/step_marks.py -----------------------------------------
@@ -421,8 +463,7 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
                     "bf16")
         if rc != 1:
             check(rc, "stegan_conv1d_fwd_hx")
-            if yh is not None:
-                y.h = yh
+            _attach_image(y, yh)
             return y
     if wf is not None and COMPUTE_DTYPE != "bf16":       # (bf16 mode does not maintain the fp32 copies: prep_weights)
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
@@ -467,8 +508,7 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
                     "bf16")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_hx")
-            if dxh is not None:
-                dx.h = dxh
+            _attach_image(dx, dxh)
             return dx
     if wb is not None and COMPUTE_DTYPE != "bf16":
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
@@ -520,8 +560,9 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
     if cfg.cout == 1 and SKINNY:
+        ws = _workspace(x.device, int(_lib.lib().stegan_conv1d_bwd_weight_skinny_floats(C.byref(d))))
         rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_skinny(C.byref(d), _p(x), _p(dy), _p(dw), _p(db),
-                                                                             _stream()), "skinny")
+                                                                             _p(ws), ws.numel(), _stream()), "skinny")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_weight_skinny")
             return
@@ -640,6 +681,18 @@ def wgrad_join() -> None:
     _wgrad_reduce_flush()          # behind every weight-gradient launch of the phase: their slabs' sums, one launch
 
 
+def wgrad_abort() -> None:
+    """Exception path of a train step: forget the weight gradients queued for / running on side streams and the streams to
+    join (the device is drained first, so dropping the operand references cannot free memory a queued kernel reads)."""
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+    _WG_ON[0] = False
+    _WG_PENDING.clear(); _WG_KEEP.clear(); _WG_USED.clear(); _SINK_STREAMS.clear(); _WG_DEFERRED.clear()
+    for st in _WG_ARENA.values():
+        st[1] = 0
+    fm_fold_abort()
+
+
 def wn_scale(v: Tensor, g: Tensor) -> Tensor:
     v = _gpu_f32(v, "weight_v")
     g = _gpu_f32(g, "weight_g")
@@ -655,8 +708,7 @@ def fold_upsample2(dxe: Tensor) -> Tensor:
     dxh = _new_image(dx, Cc, 1, Te // 2)
     check(_lib.lib().stegan_fold_upsample2_img(_p(dxe), _p(dx), _p(dxh), B * Cc, Cc, Te // 2, _stream()),
           "stegan_fold_upsample2_img")
-    if dxh is not None:
-        dx.h = dxh
+    _attach_image(dx, dxh)
     return dx
 
 
@@ -789,8 +841,7 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases, raws=None):
         if rc != 1:
             check(rc, "stegan_conv1d_fwd_multi_hx")
             for y, yh in zip(ys, yhs):
-                if yh is not None:
-                    y.h = yh
+                _attach_image(y, yh)
             return ys
         return None                     # per-problem launches (each picks bf16 or fp32 on its own)
     if COMPUTE_DTYPE == "bf16":
@@ -831,8 +882,7 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_multi_hx")
             for t, th in zip(dxs, dxhs):
-                if th is not None:
-                    t.h = th
+                _attach_image(t, th)
             return dxs
         return None
     if COMPUTE_DTYPE == "bf16":
@@ -891,8 +941,7 @@ class _WNConvMultiFn(torch.autograd.Function):
                 (C.c_int32 * n)(*[o.shape[2] if o.dim() == 3 else 0 for o in outs]), acts.pop(), _stream()),
                 "stegan_act_bwd_add_multi_img")
             for o, oh in zip(outs, ohs):
-                if oh is not None:
-                    o.h = oh
+                _attach_image(o, oh)
             gs = outs
         else:
             gs = [act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g
@@ -904,9 +953,11 @@ class _WNConvMultiFn(torch.autograd.Function):
                 # the single-output-channel output convs: all problems' weight (and bias) gradients in one launch
                 descs = [_desc(l[3], x.shape[0], x.shape[2], g.shape[2]) for x, g, l in zip(xs, gs, layers)]
                 dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+                ws = _workspace(xs[0].device, sum(int(_lib.lib().stegan_conv1d_bwd_weight_skinny_floats(C.byref(d_)))
+                                                  for d_ in descs))
                 rc = _lib.lib().stegan_conv1d_bwd_weight_skinny_multi(
                     n, dptr, _ptr_array(xs), _ptr_array(gs), _ptr_array([l[5][0] for l in layers]),
-                    _ptr_array([l[5][1] if l[2] is not None else None for l in layers]), _stream())
+                    _ptr_array([l[5][1] if l[2] is not None else None for l in layers]), _p(ws), ws.numel(), _stream())
                 if rc != 1:
                     check(rc, "stegan_conv1d_bwd_weight_skinny_multi")
                     done = True
@@ -964,8 +1015,7 @@ def act_bwd(dy: Tensor, y: Tensor, act: int, add: Optional[Tensor] = None) -> Te
     Cc, T = (dy.shape[1], dy.shape[2]) if outh is not None else (0, 0)
     check(_lib.lib().stegan_act_bwd_add_img(_p(dy), _p(add), _p(y), _p(out), _p(outh), dy.numel(), Cc, T, act, _stream()),
           "stegan_act_bwd_add_img")
-    if outh is not None:
-        out.h = outh
+    _attach_image(out, outh)
     return out
 
 
@@ -1656,8 +1706,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         outh = _new_image(out, Cm, 1, T)
         check(_lib.lib().stegan_relpos_attention_fwd_img(_p(qkv), _p(rel_emb), _p(probs), _p(out), _p(outh), B, H, A, T, max_rel,
                                                          _stream()), "stegan_relpos_attention_fwd_img")
-        if outh is not None:
-            out.h = outh
+        _attach_image(out, outh)
         ctx.dims = (B, H, A, T, max_rel)
         ctx.save_for_backward(qkv, rel_emb, probs)
         return out
@@ -1672,8 +1721,7 @@ class _RelPosAttnFn(torch.autograd.Function):
         dqkvh = _new_image(dqkv, 3 * H * A, 1, T)
         check(_lib.lib().stegan_relpos_attention_bwd_img(_p(qkv), _p(rel_emb), _p(probs), _p(dout), _p(ws), _p(dqkv), _p(dqkvh),
                                                          B, H, A, T, max_rel, _stream()), "stegan_relpos_attention_bwd_img")
-        if dqkvh is not None:
-            dqkv.h = dqkvh
+        _attach_image(dqkv, dqkvh)
         return dqkv, None, None, None
 
 
@@ -1694,8 +1742,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         yh = _new_image(y, Cm, 1, T)
         check(_lib.lib().stegan_add_layernorm_fwd_img(_p(x), _p(residual), _p(gamma), _p(beta), _p(y), _p(yh), _p(xhat), _p(rstd),
                                                       B, Cm, T, eps, _stream()), "stegan_add_layernorm_fwd_img")
-        if yh is not None:
-            y.h = yh
+        _attach_image(y, yh)
         ctx.save_for_backward(xhat, rstd, gamma)
         return y
 
@@ -1708,8 +1755,7 @@ class _AddLayerNormFn(torch.autograd.Function):
         dzh = _new_image(dz, Cm, 1, T)
         check(_lib.lib().stegan_add_layernorm_bwd_img(_p(dy), _p(xhat), _p(rstd), _p(gamma), _p(dz), _p(dzh), B, Cm, T, _stream()),
               "stegan_add_layernorm_bwd_img")
-        if dzh is not None:
-            dz.h = dzh
+        _attach_image(dz, dzh)
         hand = ctx.hand[1] if ctx.hand is not None and ctx.hand[0] == PARK_DX else None
         if hand is not None and not hand.taken and ctx.needs_input_grad[0]:
             hand.parked = dz                       # the conv that also reads x adds it inside its input-gradient kernel

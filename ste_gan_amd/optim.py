@@ -54,10 +54,14 @@ class FlatParams:
                 m._owner = self
 
     zero_in_step = False       # the optimiser kernels zero the arena as they consume it (FusedAdamW.zero_in_step)
+    clean = False              # the arena is known to be all zero: set by a consuming AdamW launch (or a fill), cleared by
+                               # zero_grad() -- which skips its fill only while this holds, so gradients a dead step left
+                               # behind are never added into the next one
 
     def zero_grad(self):
-        if not self.zero_in_step:
+        if not (self.zero_in_step and self.clean):
             self.grad.zero_()
+        self.clean = False                                   # the backward pass about to run writes into the arena
         for p, o in zip(self.params, self.offsets):          # autograd may have swapped the tensor: re-attach the view
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
@@ -198,10 +202,12 @@ class ConvPack:
         self.prepared_version = key
 
     zero_in_step = False
+    clean = False              # as FlatParams.clean, for the raw dW arena (consumed by stegan_wn_backward_z)
 
     def zero(self):
-        if not self.zero_in_step:
+        if not (self.zero_in_step and self.clean):
             self.dw.zero_()
+        self.clean = False
 
     def finalize_grads(self):
         """raw dw -> (dv, dg) for every conv, written into the .grad views (1 launch)."""
@@ -212,6 +218,7 @@ class ConvPack:
         check(_lib.lib().stegan_wn_backward_z(self.n, P(self.t_v), P(self.t_g), P(self.t_dw), P(self.t_dv), P(self.t_dg),
                                               P(self.t_rows), P(self.t_cols), self.max_rows, int(self.zero_in_step), s),
               "stegan_wn_backward_z")
+        self.clean = bool(self.zero_in_step)
 
 
 class FusedAdamW:
@@ -243,12 +250,18 @@ class FusedAdamW:
         (two fills of 47 + 94 MB sat at the start of every step).  Switching it on zeroes the arenas once, eagerly."""
         on = bool(on)
         if on and not self.flat.zero_in_step:
-            self.flat.grad.zero_()
-            if self.pack is not None:
-                self.pack.dw.zero_()
+            self.discard_grads()
         self.flat.zero_in_step = on
         if self.pack is not None:
             self.pack.zero_in_step = on
+
+    def discard_grads(self) -> None:
+        """Zero both gradient arenas with fills, now (switching zero-on-consume on; the exception path of a train step)."""
+        self.flat.grad.zero_()
+        self.flat.clean = True
+        if self.pack is not None:
+            self.pack.dw.zero_()
+            self.pack.clean = True
 
     def finalize_grads(self):
         """Call between backward() and step() / the gradient all-reduce: joins the streams on which backward nodes wrote
@@ -291,6 +304,7 @@ class FusedAdamW:
             C.c_void_p(self.exp_avg_sq.data_ptr()), f.numel, C.c_void_p(self._hyper.data_ptr()),
             self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, int(f.zero_in_step),
             C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step_z")
+        self.flat.clean = bool(f.zero_in_step)      # (zero-on-consume: .grad reads 0 from here on, see set_zero_in_step)
         self.flat.epoch += 1           # parameters changed behind torch's back: this network's prepared copies are stale
         if self.pack is not None:
             self.pack.invalidate()

@@ -106,11 +106,24 @@ class GANTrainStep:
         """One train step = three phases with the two gradient exchanges between them (no-ops in a single process).  The
         phases keep their state in ``self._st`` so that GraphedTrainStep can capture each of them as its own hipGraph under
         torch.distributed (collectives stay outside the graphs)."""
-        self.phase_d(batch_dict)
-        self.exchange_d()
-        self.phase_g()
-        self.exchange_g()
-        return self.phase_opt()
+        try:
+            self.phase_d(batch_dict)
+            self.exchange_d()
+            self.phase_g()
+            self.exchange_g()
+            return self.phase_opt()
+        except BaseException:
+            self.abort()
+            raise
+
+    def abort(self) -> None:
+        """A phase raised: leave no state behind that a later step would trust (the open zero pool, gradients already
+        accumulated into the arenas, weight gradients parked for side streams)."""
+        ops.zero_pool_abort()
+        ops.wgrad_abort()
+        self._st = None
+        for opt in (self.optG, self.optD):
+            opt.discard_grads()
 
     def exchange_d(self):
         """SUM all-reduce of the discriminator's gradient arena (side stream, RCCL); awaited in phase_g."""
@@ -405,6 +418,8 @@ class GraphedTrainStep:
     launch overhead against 8.8 ms of GPU time).
     """
 
+    CAPTURE_ERROR_MODE = "thread_local"      # pinned by tests/test_host_logic.py (see __init__)
+
     def __init__(self, step: GANTrainStep, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
         self.step = step
         self.static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in example_batch.items()}
@@ -431,8 +446,7 @@ class GraphedTrainStep:
         # capture_error_mode "thread_local": with a process group alive, the RCCL watchdog THREAD polls its work events with
         # hipEventQuery at any time; in the default "global" mode such a call from another thread invalidates a capture in
         # progress (hipErrorStreamCaptureInvalidated, then the watchdog aborts the process) -- seen once in three runs.
-        # (STEGAN_CAPTURE_ERROR_MODE=global: diagnostic hook of scripts/teardown_probe.py, which reproduces that abort)
-        mode = dict(capture_error_mode=os.environ.get("STEGAN_CAPTURE_ERROR_MODE", "thread_local"))
+        mode = dict(capture_error_mode=self.CAPTURE_ERROR_MODE)
         if os.environ.get("STEGAN_MAIN_PRIORITY"):            # experiment hook: capture on a stream with a priority
             mode["stream"] = torch.cuda.Stream(priority=int(os.environ["STEGAN_MAIN_PRIORITY"]))
         if step.comm is None:
@@ -515,6 +529,9 @@ class GraphedTrainStep:
         self.graphs = None
         self.out = self.last = None
         self.static = {}
+        # eager users of the optimisers get torch.optim semantics back (.grad kept until zero_grad())
+        self.step.optG.set_zero_in_step(False)
+        self.step.optD.set_zero_in_step(False)
         self.step.close()
         torch.cuda.synchronize()
 

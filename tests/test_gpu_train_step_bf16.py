@@ -88,8 +88,11 @@ def test_multi_problem_launch_matches_single_launches(bf16_mode):
 
 def test_generator_weight_gradients_on_side_streams_equal_inline(bf16_mode):
     """ops._wgrad_sink: during the generator's backward pass the weight-gradient launches of the sink (ConvPack) mode run on
-    side streams beside the chain of input gradients and are joined in finalize_grads -- same gradients and parameters as
-    running them inline (one step: later steps diverge chaotically from the fp32-atomics noise alone)."""
+    side streams beside the chain of input gradients and are joined in finalize_grads -- the same kernels with the same
+    plans, so the same BITS as running them inline.  (Rounds 1-3 compared to 2e-5: with float atomics in the discriminator's
+    gradients the two runs started the generator's backward from discriminators that differed in their last bits, and the
+    bound was crossed on a fresh box -- GPUTEST_r03.  The gradient path has no atomics since round 4;
+    tests/test_gpu_reproducible.py holds the general statement.)"""
     name = next(iter(cases.STEP_CASES))
     res = []
     for streams in (4, 0):
@@ -101,14 +104,16 @@ def test_generator_weight_gradients_on_side_streams_equal_inline(bf16_mode):
             torch.cuda.synchronize()
             assert not bf16_mode._WG_KEEP                       # joined: operands released
             res.append(([p.grad.clone() for p in netG.parameters()], [p.detach().clone() for p in netG.parameters()],
-                        float(out["generator"])))
+                        [p.detach().clone() for p in netD.parameters()], out["x_pred"].clone()))
         finally:
             bf16_mode.WGRAD_STREAMS = old
-    for a, b in zip(res[0][0], res[1][0]):
-        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-12
+    assert torch.equal(res[0][3], res[1][3]), "x_pred differs between two launches of the generator forward"
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        assert torch.equal(a, b), f"discriminator parameter {i} differs after the step: the D update is not reproducible"
+    for i, (a, b) in enumerate(zip(res[0][0], res[1][0])):
+        assert torch.equal(a, b), f"generator gradient {i}: max |delta| {float((a - b).abs().max()):.3e}"
     for a, b in zip(res[0][1], res[1][1]):
-        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9
-    assert abs(res[0][2] - res[1][2]) <= 1e-6 * abs(res[1][2])
+        assert torch.equal(a, b)
 
 
 def test_sink_gradients_written_on_side_streams_are_joined(bf16_mode):

@@ -124,3 +124,123 @@ def test_train_step_phases_exist_for_segmented_capture():
     src = inspect.getsource(GANTrainStep.__call__)
     order = [src.index(s) for s in ("self.phase_d(", "self.exchange_d(", "self.phase_g(", "self.exchange_g(", "self.phase_opt(")]
     assert order == sorted(order)
+
+
+def test_graph_capture_error_mode_is_thread_local():
+    """Round 2's teardown abort: a capture in the default "global" error mode is invalidated by the RCCL watchdog thread's
+    hipEventQuery.  The fix is pinned here (CPU) instead of by re-running the abort on a GPU box."""
+    import inspect
+    from ste_gan_amd.train import GraphedTrainStep
+    assert GraphedTrainStep.CAPTURE_ERROR_MODE == "thread_local"
+    src = inspect.getsource(GraphedTrainStep.__init__)
+    assert "capture_error_mode=self.CAPTURE_ERROR_MODE" in src and "environ.get(\"STEGAN_CAPTURE" not in src
+
+
+def test_zero_pool_invariants_on_cpu(monkeypatch):
+    """ops.pooled_zeros(): zeros whatever happened before -- a step that died (abort), a later step that needs more than the
+    one before it, two alternating buffers so that a step's returned scalars survive the next step's fill."""
+    from ste_gan_amd import ops
+    monkeypatch.setattr(ops, "ZERO_POOL_BYTES", 1 << 16)
+    monkeypatch.setattr(ops, "_ZPOOL", {"bufs": [None, None], "dirty": [0, 0], "floor": [0, 0], "cur": 0, "off": 0,
+                                        "active": False, "filled": 0})
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    dev = torch.device("cpu")
+    # outside a step: plain torch.zeros, the pool is not touched
+    a = ops.pooled_zeros(8, dev)
+    assert a.sum() == 0 and ops._ZPOOL["bufs"] == [None, None]
+    # step 1 (small), its scalar survives step 2's begin (other buffer)
+    ops.zero_pool_begin(dev)
+    s1 = ops.pooled_zeros((), dev); s1.fill_(7.0)
+    ops.zero_pool_end()
+    ops.zero_pool_begin(dev)
+    assert float(s1) == 7.0
+    t = ops.pooled_zeros(1000, dev); t.fill_(3.0)
+    # ... dies half way: the pool is closed and wholly dirty
+    ops.zero_pool_abort()
+    assert not ops._ZPOOL["active"]
+    assert ops.pooled_zeros(4, dev).data_ptr() not in range(ops._ZPOOL["bufs"][ops._ZPOOL["cur"]].data_ptr(),
+                                                            ops._ZPOOL["bufs"][ops._ZPOOL["cur"]].data_ptr() + (1 << 16))
+    # steps 3 and 4 reuse both buffers and need MORE than any step before: still zeros
+    for _ in range(2):
+        ops.zero_pool_begin(dev)
+        big = ops.pooled_zeros(8000, dev)
+        assert float(big.abs().sum()) == 0.0
+        big.fill_(1.0)
+        ops.zero_pool_end()
+    for _ in range(2):
+        ops.zero_pool_begin(dev)
+        bigger = ops.pooled_zeros(12000, dev)
+        assert float(bigger.abs().sum()) == 0.0
+        bigger.fill_(2.0)
+        ops.zero_pool_end()
+    # a request that does not fit falls back to a fresh fill
+    ops.zero_pool_begin(dev)
+    assert ops.pooled_zeros(1 << 20, dev).numel() == 1 << 20
+    ops.zero_pool_end()
+
+
+def test_zero_pool_capture_must_be_covered_by_its_fill(monkeypatch):
+    from ste_gan_amd import ops
+    monkeypatch.setattr(ops, "ZERO_POOL_BYTES", 1 << 16)
+    monkeypatch.setattr(ops, "_ZPOOL", {"bufs": [None, None], "dirty": [0, 0], "floor": [0, 0], "cur": 0, "off": 0,
+                                        "active": False, "filled": 0})
+    capturing = [False]
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
+    dev = torch.device("cpu")
+    ops.zero_pool_begin(dev); ops.pooled_zeros(100, dev); ops.zero_pool_end()          # eager warm-up: 400 bytes
+    ops.zero_pool_begin(dev); ops.pooled_zeros(100, dev); ops.zero_pool_end()
+    capturing[0] = True
+    cur = ops._ZPOOL["cur"]
+    ops.zero_pool_begin(dev)
+    assert ops._ZPOOL["cur"] == cur                        # a capture keeps the last eager step's buffer
+    ops.pooled_zeros(100, dev)
+    ops.zero_pool_end()                                    # covered
+    assert ops._ZPOOL["floor"][cur] >= 400
+    ops.zero_pool_begin(dev)
+    ops.pooled_zeros(5000, dev)
+    with pytest.raises(RuntimeError, match="run the step eagerly once"):
+        ops.zero_pool_end()
+    capturing[0] = False
+    # an eager step on the captured step's buffer clears at least what the replays dirty
+    ops._ZPOOL["cur"] = cur ^ 1
+    ops.zero_pool_begin(dev)
+    assert ops._ZPOOL["cur"] == cur and ops._ZPOOL["filled"] >= ops._ZPOOL["floor"][cur]
+    ops.zero_pool_end()
+
+
+def test_bf16_image_is_dropped_after_an_in_place_write(monkeypatch):
+    """ops._image_of: autograd's gradient buffers (and users) may add_ into a tensor that carries a bf16 image; the image
+    then shows the old values, so the in-place version recorded when it was attached must still match."""
+    from ste_gan_amd import ops
+    monkeypatch.setattr(ops, "COMPUTE_DTYPE", "bf16")
+    monkeypatch.setattr(ops, "IMAGES", True)
+    t = torch.zeros(2, 16, 12)
+    h = torch.zeros(2, 2, 12, 8, dtype=torch.bfloat16)
+    ops._attach_image(t, h)
+    assert ops._image_of(t, 16, 12) is h
+    assert ops._image_of(t, 16, 11) is None and ops._image_of(t, 24, 12) is None
+    t.add_(1.0)
+    assert ops._image_of(t, 16, 12) is None
+    u = torch.zeros(2, 16, 12)
+    u.h = h                                               # attached by hand, no version: not trusted
+    assert ops._image_of(u, 16, 12) is None
+
+
+def test_zero_on_consume_flags():
+    """FlatParams / ConvPack skip their fill in zero_grad() only while the arena is known to be clean (the optimiser launch
+    consumed it); anything else -- a fresh arena, a step that died after backward -- gets a real fill."""
+    from ste_gan_amd.optim import FlatParams
+
+    class _Flat(FlatParams):
+        def __init__(self):
+            self.grad = torch.ones(8)
+            self.params, self.offsets = [], []
+    f = _Flat()
+    f.zero_in_step = True
+    f.zero_grad()                                          # not known clean: filled
+    assert float(f.grad.abs().sum()) == 0 and f.clean is False
+    f.grad.fill_(1.0); f.clean = True                      # (as after a consuming AdamW launch, whose kernel zeroes it)
+    f.zero_grad()
+    assert float(f.grad.sum()) == 8.0 and f.clean is False           # skipped: trusts the kernel
+    f.zero_grad()                                          # a second call without a consuming launch in between: filled
+    assert float(f.grad.abs().sum()) == 0

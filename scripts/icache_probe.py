@@ -14,7 +14,7 @@ def layer(Cin, Cout, K, d, p, relu, Tin):
     c = ops.ConvCfg(Cin, Cout, K, 1, d, p, 1, 1, 1 if relu else 0)
     x = torch.randn(B, Cin, Tin, device="cuda"); w = torch.randn(Cout, Cin, K, device="cuda") * 0.05
     sc = torch.rand(Cout, device="cuda") + 0.5; bias = torch.randn(Cout, device="cuda")
-    x.h = make_image(x)
+    ops._attach_image(x, make_image(x))
     wf, wb = ops.prep_weights(w, c, None, sc)
     return lambda: ops.conv1d_fwd(x, w, sc, bias, None, c, wf)
 a = layer(768, 768, 1, 1, 0, False, 12)          # <1, 1, 3>

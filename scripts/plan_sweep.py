@@ -38,7 +38,7 @@ def main():
         x = torch.randn(B, Cin, Tin, device="cuda"); w = torch.randn(Cout, Cin // g, K, device="cuda") * 0.05
         sc = torch.rand(Cout, device="cuda") + 0.5; bias = torch.randn(Cout, device="cuda")
         dy = torch.randn(B, Cout, Tout, device="cuda")
-        x.h, dy.h = make_image(x), make_image(dy)
+        ops._attach_image(x, make_image(x)); ops._attach_image(dy, make_image(dy))
         wf, wb = ops.prep_weights(w, c, None, sc)
         gf = 2.0 * B * Tout * Cout * (Cin // g) * K / 1e9
         res = {0: [], 1: []}

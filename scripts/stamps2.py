@@ -20,7 +20,7 @@ for (name, Cin, Cout, K, s, d, p, g, up, relu, Tin) in LAYERS:
     Tout = c.tout(Tin)
     x = torch.randn(B, Cin, Tin, device="cuda"); w = torch.randn(Cout, Cin // g, K, device="cuda") * 0.05
     sc = torch.rand(Cout, device="cuda") + 0.5; bias = torch.randn(Cout, device="cuda"); dy = torch.randn(B, Cout, Tout, device="cuda")
-    x.h, dy.h = make_image(x), make_image(dy)
+    ops._attach_image(x, make_image(x)); ops._attach_image(dy, make_image(dy))
     wf, wb = ops.prep_weights(w, c, None, sc)
     for mode in ("fwd", "bwd"):
         run = (lambda: ops.conv1d_fwd(x, w, sc, bias, None, c, wf)) if mode == "fwd" else \

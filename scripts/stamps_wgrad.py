@@ -18,7 +18,7 @@ for (name, B, Cin, Cout, K, s, d, p, g, up, relu, Tin) in LAYERS:
     c = ops.ConvCfg(Cin, Cout, K, s, d, p, g, up, 1 if relu else 0)
     Tout = c.tout(Tin)
     x = torch.randn(B, Cin, Tin, device="cuda"); dy = torch.randn(B, Cout, Tout, device="cuda")
-    x.h, dy.h = make_image(x), make_image(dy)
+    ops._attach_image(x, make_image(x)); ops._attach_image(dy, make_image(dy))
     dw = torch.zeros(Cout, Cin // g, K, device="cuda"); db = torch.zeros(Cout, device="cuda")
     run = lambda: ops.conv1d_bwd_weight(x, dy, c, dw, db)
     t = timeit(run)

@@ -31,7 +31,7 @@ def setup():
         c = ops.ConvCfg(Cin, Cout, K, s, d, p, g, up, 1 if relu else 0)
         x = torch.randn(B, Cin, Tin, device="cuda"); w = torch.randn(Cout, Cin // g, K, device="cuda") * 0.05
         sc = torch.rand(Cout, device="cuda") + 0.5; bias = torch.randn(Cout, device="cuda")
-        x.h = make_image(x)
+        ops._attach_image(x, make_image(x))
         wf, wb = ops.prep_weights(w, c, None, sc)
         out.append((name, lambda x=x, w=w, sc=sc, bias=bias, c=c, wf=wf: ops.conv1d_fwd(x, w, sc, bias, None, c, wf),
                     (2 * x.numel() + 2 * w.numel(), 6 * B * Cout * c.tout(Tin))))

@@ -255,16 +255,22 @@ def _image_of(t: Optional[Tensor], channels: int, length: int) -> Optional[Tenso
         return None
     if tuple(h.shape) != (t.shape[0], (channels + 7) // 8, length, 8) or h.device != t.device:
         return None
-    if getattr(t, "h_version", None) != t._version:
+    if getattr(t, "h_version", None) != _version_of(t):
         return None
     return h
+
+
+def _version_of(t: Tensor) -> int:
+    """In-place version of ``t``; inference tensors (EMGGenerator.generate runs under inference_mode) keep no counter --
+    nothing of this package writes into an activation in place, so they count as never modified."""
+    return -1 if t.is_inference() else t._version
 
 
 def _attach_image(t: Tensor, h: Optional[Tensor]) -> None:
     """Hang the bf16 image ``h`` on ``t`` together with the in-place version of ``t`` it mirrors (see _image_of)."""
     if h is not None:
         t.h = h
-        t.h_version = t._version
+        t.h_version = _version_of(t)
 
 
 def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optional[Tensor]:

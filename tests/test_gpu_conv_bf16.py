@@ -95,7 +95,7 @@ def test_conv_bf16_fwd_bwd_data(cfg, images=False):
         wf, wb = ops.prep_weights(wg, c, None, sg)
         assert wf.h.dtype == torch.bfloat16 and wb.h is not None
         if images:
-            xg.h, dyg.h = make_image(xg), make_image(dyg)
+            ops._attach_image(xg, make_image(xg)); ops._attach_image(dyg, make_image(dyg))
             assert ops._image_of(xg, Cin, Tin) is not None
         y = ops.conv1d_fwd(xg, wg, sg, bg, rg, c, wf)
         k_fwd = ops.LAST_CONV_KERNEL
@@ -162,7 +162,7 @@ def test_conv_bf16_bwd_weight(cfg, images=False):
     try:
         xg, dyg = x.cuda(), dy.cuda()
         if images:
-            xg.h, dyg.h = make_image(xg), make_image(dyg)
+            ops._attach_image(xg, make_image(xg)); ops._attach_image(dyg, make_image(dyg))
         ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
         kern = ops.LAST_CONV_KERNEL
     finally:
@@ -209,3 +209,37 @@ def test_prep_bf16_layout():
         want_b[gi, :K, :cig, :cog] = (blk * sc[gi * cog:(gi + 1) * cog].view(-1, 1, 1)).permute(2, 1, 0)
     assert torch.equal(wfh, want_f.to(torch.bfloat16))
     assert torch.equal(wbh, want_b.to(torch.bfloat16))
+
+
+def test_gradients_summed_by_autograd_do_not_use_a_stale_image():
+    """Two convs read the same activation x WITHOUT the gradient hand-over: each backward returns an input gradient that
+    carries a bf16 image, and autograd's gradient buffer adds the second into the first IN PLACE -- the tensor object (and
+    its image of the first summand) survives the sum.  ops._image_of must see the in-place version move and fall back to
+    staging from the fp32 sum; the producer's gradients then equal a run with images switched off (both round the same
+    fp32 sum to bf16)."""
+    from ste_gan_amd import ops
+    from ste_gan_amd.layers.conv import WNConv1d
+    torch.manual_seed(11)
+    ops.set_compute_dtype("bf16")
+    try:
+        conv0 = WNConv1d(64, 64, 3, padding=1).cuda()
+        conv1 = WNConv1d(64, 96, 3, padding=1).cuda()
+        conv2 = WNConv1d(64, 32, 1).cuda()
+        inp = torch.randn(4, 64, 48, device="cuda")
+        g1, g2 = torch.randn(4, 96, 48, device="cuda"), torch.randn(4, 32, 48, device="cuda")
+        res = []
+        for images in (True, False):
+            ops.IMAGES = images
+            for c in (conv0, conv1, conv2):
+                for p in c.parameters():
+                    p.grad = None
+            a = inp.clone().requires_grad_(True)
+            x = conv0(a)
+            assert (ops._image_of(x, 64, 48) is not None) == images
+            torch.autograd.backward([conv1(x), conv2(x)], [g1, g2])
+            res.append([a.grad.clone()] + [p.grad.clone() for p in conv0.parameters()])
+        for got, want in zip(*res):
+            assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-7
+    finally:
+        ops.IMAGES = True
+        ops.set_compute_dtype("f32")

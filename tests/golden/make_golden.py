@@ -334,9 +334,21 @@ def step_cases():
             g_gn, g_gh = grad_summary([(k, p.grad) for k, p in netG.named_parameters()])
             optG.step()
             margin_g = min(relu_in); relu_in.clear()
-            margin_d = min(float(fm.detach().abs().min()) for out in (D_fake, D_real) for sc in out for fm in sc[:-1])
-            print(f"  step {step}: kink margins  G relu inputs {margin_g:.2e}   D lrelu outputs {margin_d:.2e}")
+            d_maps = [fm.detach() for out in (D_fake, D_real) for sc in out for fm in sc[:-1]]
+            margin_d = min(float(fm.abs().min()) for fm in d_maps)
+            # The discriminator's widths are fixed (discriminator.py:54-60,76-81), so even this 3 x 80-sample fixture has
+            # ~10^6 leaky-ReLU units per pass with outputs of scale ~0.05: the smallest |output| is ~scale / units ~ 1e-8
+            # whatever the seed -- a 1e-6 margin cannot be had for D.  What CAN be asserted: the units close enough to the
+            # kink for an fp32 summation order to flip their slope are a vanishing share, so a flip moves a gradient NORM
+            # by far less than the tests' bounds (the tests bound norms and L2 errors, never single entries); and the
+            # build's own step is bit-reproducible (tests/test_gpu_reproducible.py), so a flip cannot come and go.
+            d_units = sum(fm.numel() for fm in d_maps)
+            d_near = sum(int((fm.abs() < 1e-6).sum()) for fm in d_maps)
+            print(f"  step {step}: kink margins  G relu inputs {margin_g:.2e}   D lrelu outputs {margin_d:.2e} "
+                  f"({d_near} of {d_units} D units within 1e-6 of the kink)")
             assert margin_g > 1e-6, "a generator pre-activation sits on the ReLU kink: pick another case"
+            assert d_near <= 1e-4 * d_units, "too many discriminator units on the leaky-ReLU kink: pick another case"
+            rec[f"s{step}.kink"] = np.array([margin_g, margin_d, d_near, d_units], np.float64)
             tag = f"s{step}."
             rec[tag + "losses"] = np.array([loss_D.item(), loss_G.item(), adv.item(), td.item(),
                                             eo.speech_unit_loss.item(), eo.phoneme_loss.item(), fm.item()], np.float64)

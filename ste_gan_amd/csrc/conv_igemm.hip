@@ -288,14 +288,24 @@ __global__ __launch_bounds__(256) void igemm_wgrad_reduce_kernel(const float* __
         const int k = (int)(i % K);
         if (k < k_lo || k >= k_lo + K_eff) continue;
         const float* src = partial + i;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 4 <= splits; s += 4) {
+        // 16 independent loads in flight per round (these dW are tiny -- a few blocks -- so the kernel is a chain of load
+        // round trips: 64 slabs in 4 rounds); fixed summation order
+        float v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * numel];
+        for (int u = 0; u < 16; ++u) v[u] = 0.f;
+        int s = 0;
+        for (; s + 16 <= splits; s += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = src[(size_t)(s + u) * numel];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] += t[u];
         }
         for (; s < splits; ++s) v[0] += src[(size_t)s * numel];
-        dw[i] += (v[0] + v[1]) + (v[2] + v[3]);
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) a += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+        dw[i] += a;
     }
 }
 

@@ -5,8 +5,8 @@ namespace {
 
 // add != nullptr: a second gradient of the same tensor (the feature-matching term of a discriminator feature map, known
 // since the forward pass) is summed in here instead of by a separate elementwise kernel in front of this one
-// out_h != nullptr: the result is also written as a bf16 activation image [B][C / 8][T][8] (C % 8 == 0, T % 4 == 0: a
-// thread's four values lie in one row) for the conv kernels that consume this gradient next
+// out_h != nullptr: the result is also written as a bf16 activation image [B][C / 8][T][8] (C % 8 == 0; any T since round 4)
+// for the conv kernels that consume this gradient next
 __device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const float* __restrict__ add,
                                              const float* __restrict__ y, float* __restrict__ out, long n, int act,
                                              unsigned short* __restrict__ out_h = nullptr, int Cc = 0, int T = 0) {
@@ -32,14 +32,29 @@ __device__ __forceinline__ void act_bwd_body(const float* __restrict__ dy, const
             if (out_h) {
                 const long r = i / T;
                 const int t = (int)(i - r * T), b = (int)(r / Cc), c = (int)(r - (long)b * Cc);
-                img_store(out_h, Cc >> 3, T, b, c, t, d.x); img_store(out_h, Cc >> 3, T, b, c, t + 1, d.y);
-                img_store(out_h, Cc >> 3, T, b, c, t + 2, d.z); img_store(out_h, Cc >> 3, T, b, c, t + 3, d.w);
+                if (t + 3 < T) {                           // the four values lie in one row (always when T % 4 == 0)
+                    img_store(out_h, Cc >> 3, T, b, c, t, d.x); img_store(out_h, Cc >> 3, T, b, c, t + 1, d.y);
+                    img_store(out_h, Cc >> 3, T, b, c, t + 2, d.z); img_store(out_h, Cc >> 3, T, b, c, t + 3, d.w);
+                } else {                                   // ragged rows (the period discriminators' lengths): they straddle
+                    const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const long re = (i + e) / T;
+                        const int te = (int)(i + e - re * T), be = (int)(re / Cc), ce = (int)(re - (long)be * Cc);
+                        img_store(out_h, Cc >> 3, T, be, ce, te, dv[e]);
+                    }
+                }
             }
         } else {
             for (long j = i; j < n; ++j) {
                 const float v = y[j];
                 const float ns = act == STEGAN_ACT_LRELU ? 0.1f : 0.f;
-                out[j] = (dy[j] + (add ? add[j] : 0.f)) * (act == STEGAN_ACT_TANH ? (1.f - v * v) : (v > 0.f ? 1.f : ns));
+                const float o = (dy[j] + (add ? add[j] : 0.f)) * (act == STEGAN_ACT_TANH ? (1.f - v * v) : (v > 0.f ? 1.f : ns));
+                out[j] = o;
+                if (out_h) {
+                    const long rj = j / T;
+                    img_store(out_h, Cc >> 3, T, (int)(rj / Cc), (int)(rj % Cc), (int)(j - rj * T), o);
+                }
             }
         }
     }
@@ -68,7 +83,7 @@ __global__ __launch_bounds__(256) void act_bwd_multi_kernel(const ActMulti a, in
 extern "C" int stegan_act_bwd_add_img(const float* dy, const float* add, const float* y, float* out, uint16_t* out_h,
                                       int64_t n, int32_t C, int32_t T, int32_t act, void* stream) {
     STEGAN_CHECK_ARG(dy && y && out && n > 0);
-    if (out_h) STEGAN_CHECK_ARG(C > 0 && T > 0 && C % 8 == 0 && T % 4 == 0 && n % ((int64_t)C * T) == 0);
+    if (out_h) STEGAN_CHECK_ARG(C > 0 && T > 0 && C % 8 == 0 && n % ((int64_t)C * T) == 0);
     STEGAN_CHECK_ARG(act == STEGAN_ACT_LRELU || act == STEGAN_ACT_TANH || act == STEGAN_ACT_RELU);
     STEGAN_CHECK_ARG(((uintptr_t)dy | (uintptr_t)add | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
     long blocks = (n + 1023) / 1024;
@@ -96,7 +111,7 @@ extern "C" int stegan_act_bwd_add_multi_img(int32_t m, const float* const* dy, c
         STEGAN_CHECK_ARG(dy[k] && y[k] && out[k] && n[k] > 0);
         a.dy[k] = dy[k]; a.add[k] = add ? add[k] : nullptr; a.y[k] = y[k]; a.out[k] = out[k]; a.n[k] = (long)n[k];
         a.out_h[k] = out_h ? out_h[k] : nullptr; a.Cc[k] = out_h ? Cs[k] : 0; a.T[k] = out_h ? Ts[k] : 0;
-        if (a.out_h[k]) STEGAN_CHECK_ARG(a.Cc[k] > 0 && a.T[k] > 0 && a.Cc[k] % 8 == 0 && a.T[k] % 4 == 0 && n[k] % ((int64_t)a.Cc[k] * a.T[k]) == 0);
+        if (a.out_h[k]) STEGAN_CHECK_ARG(a.Cc[k] > 0 && a.T[k] > 0 && a.Cc[k] % 8 == 0 && n[k] % ((int64_t)a.Cc[k] * a.T[k]) == 0);
         STEGAN_CHECK_ARG(((uintptr_t)a.dy[k] | (uintptr_t)a.add[k] | (uintptr_t)a.y[k] | (uintptr_t)a.out[k]) % 16 == 0);
         const long b = ((long)n[k] + 1023) / 1024;
         if (b > blocks) blocks = b;

@@ -316,8 +316,11 @@ class GANTrainStep:
         try:
             D_fake = netD(x_pred_t)
             ops.mark("G step: D(fake) done")
-            with torch.no_grad():
-                D_real = netD(x_t)
+            if "no_dreal_g" in _ops.WHATIF:          # what-if (scripts/whatif.py): the pass skipped, WRONG values
+                D_real = [[f.detach() for f in sc] for sc in D_fake]
+            else:
+                with torch.no_grad():
+                    D_real = netD(x_t)
             ops.mark("G step: D(real) done")
             loss_main = None
             if t.loss_adversarial:

@@ -243,3 +243,22 @@ def test_gradients_summed_by_autograd_do_not_use_a_stale_image():
     finally:
         ops.IMAGES = True
         ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("shape", [(6, 32, 13), (4, 256, 34), (10, 24, 7), (3, 16, 48)], ids=str)
+def test_activation_backward_writes_the_image_for_any_row_length(shape):
+    """stegan_act_bwd_add_img / _multi_img: (dy + add) * lrelu'(y) and its bf16 image, rows of any length (the period
+    discriminators fold the signal into rows of 97 / p, 34, 12 ... steps: not multiples of 4)."""
+    from ste_gan_amd import ops
+    from ste_gan_amd._lib import ACT_LRELU
+    torch.manual_seed(sum(shape))
+    ops.set_compute_dtype("bf16")
+    try:
+        dy, add, y = (torch.randn(*shape, device="cuda") for _ in range(3))
+        want = (dy + add) * torch.where(y > 0, 1.0, 0.1)
+        out = ops.act_bwd(dy, y, ACT_LRELU, add)
+        torch.testing.assert_close(out, want, rtol=1e-6, atol=1e-7)
+        h = ops._image_of(out, shape[1], shape[2])
+        assert h is not None and torch.equal(h.view(torch.int16), make_image(out).view(torch.int16))
+    finally:
+        ops.set_compute_dtype("f32")

@@ -234,15 +234,26 @@ int stegan_add_layernorm_fwd_img(const float* x, const float* residual, const fl
                                  void* stream);
 int stegan_add_layernorm_bwd_img(const float* dy, const float* xhat, const float* rstd, const float* gamma, float* dz,
                                  uint16_t* dz_h, int32_t B, int32_t C, int32_t T, void* stream);
-/* weight gradient with both operands as images (nullable; taken only when BOTH are given): as stegan_conv1d_bwd_weight_h.
- * TICKETED WORKSPACE (round 4; also stegan_conv1d_fwd_hx / _bwd_data_hx and their _h forms): the first 4096 32-bit words
- * of `workspace` are per-tile arrival counters, the slabs follow.  The caller zeroes the counters ONCE; every launch leaves
- * them at zero (the block that draws a tile's last ticket sums the slabs in slice order -- bit-reproducible -- finishes the
- * tile and resets the counter), so one workspace serves any number of stream-ordered launches.  No second "reduce" /
- * "split-K epilogue" launch. */
+/* weight gradient with both operands as images (nullable; taken only when BOTH are given): as stegan_conv1d_bwd_weight_h */
 int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
                                 const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
                                 void* stream);
+/* the same with the sum of the batch-slice slabs DEFERRED: when the launch sliced the batch, *deferred describes the pending sum
+ * (dw[r * K + k_lo + kk] += sum over slices of partial[slice][r * K_eff + kk]; used_floats of the workspace hold the slabs and must
+ * stay untouched until it ran) and no reduce kernel is launched; slices == 0: nothing is pending (dW was accumulated directly, or
+ * the shape went elsewhere: return 1 as stegan_conv1d_bwd_weight_hx).  stegan_wgrad_reduce_multi runs the pending sums of any number of
+ * layers as one launch per 48 (same summation order per element as the per-layer kernel: identical results); the caller orders it
+ * after every weight-gradient launch it covers (ops.wgrad_join). */
+typedef struct stegan_wgrad_reduce {
+    const float* partial;
+    float* dw;
+    int64_t per_tap, used_floats;
+    int32_t slices, K, k_lo, K_eff;
+} stegan_wgrad_reduce;
+int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                 const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
+                                 stegan_wgrad_reduce* deferred, void* stream);
+int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream);
 int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
                                const float* const* bias, const float* const* residual, float* const* y,
@@ -263,8 +274,7 @@ int stegan_conv1d_bwd_data_multi_h(int32_t n, const stegan_conv_desc* const* des
  * bf16-operand variant of stegan_conv1d_bwd_weight_ws (same accumulate-into-dw contract, fp32 accumulation, fp32 bias
  * gradient): both operands are rounded to bf16 while they are staged and read with the transposing LDS load, so any tap
  * shift / stride is a per-lane address.  The batch is cut into slices that write slabs of `workspace`
- * ([slice][Cout][Cin/groups][live tap] floats behind the ticket words, see stegan_conv1d_bwd_weight_hx) and the last slice
- * of a tile to arrive adds them into dw in slice order.  Returns 1 (nothing
+ * ([slice][live tap][Cout][Cin/groups] floats) and a second kernel adds them into dw in a fixed order.  Returns 1 (nothing
  * enqueued) for shapes left to the fp32 kernels: fewer than 16 channels per group on either side, or no room for one slab.
  */
 int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,

@@ -80,35 +80,6 @@ __device__ __forceinline__ void block_sync() {
     __syncthreads();
 }
 
-// ---- arrival tickets of a split reduction (round 4) ----------------------------------------------------------------------
-// A reduction cut into n slices (split-K of a conv, batch slices of a weight gradient) has every slice's block store its raw
-// partial tile to a slab and then take a ticket of the tile's counter; the block that draws the LAST ticket sums the slabs in
-// slice order -- a fixed order whichever block arrives last, so the result is bit-reproducible -- and finishes the tile
-// (epilogue, dW +=).  That replaces the second launch of rounds 1-3 (conv_splitk_epilogue_kernel, conv_wgrad_bf16_reduce_kernel:
-// 78 launches of a train step) and its re-read of the slabs from a cold cache.
-// Counters: TICKET_WORDS 32-bit words at the START of the launch's workspace, zero between launches (the caller zeroes them
-// once; the last block of a tile puts its counter back to zero).  Memory order: every wave drains its stores (vmcnt(0)) in
-// front of the barrier, thread 0 then takes the ticket with an agent-scope acquire-release RMW -- the release writes this
-// XCD's L2 back (buffer_wbl2: the other slices' blocks run on other XCDs, whose L2s are not coherent with this one), the
-// acquire invalidates what the reading block may hold of the slabs from an earlier launch.
-constexpr int TICKET_WORDS = 4096;
-
-__device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned n, void* lds_word) {
-    volatile unsigned* flag = (volatile unsigned*)lds_word;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    block_sync();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == n - 1) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = old;
-    }
-    block_sync();
-    const bool last = *flag == n - 1;
-    block_sync();                                   // the flag has been read by every wave: its LDS word may be reused
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
-}
-
 // one element of a bf16 activation image [B][CB = ceil(C / 8)][T][8 channels] (include/stegan_hip.h, "ACTIVATION IMAGES"): what
 // the elementwise producers write beside their fp32 output so that the conv kernel behind them stages it by LDS-DMA
 __device__ __forceinline__ void img_store(unsigned short* __restrict__ img, int CB, int T, int b, int c, int t, float v) {

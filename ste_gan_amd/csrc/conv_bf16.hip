@@ -674,55 +674,16 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     }
     const size_t out_elems = (size_t)p.B * p.Cdst * p.Tdst;
     const bool vec4 = h.vec_out != 0;                          // host: os == 1, U % 4 == 0, Tdst % 4 == 0, aligned pointers
-    const bool raw = nsplits > 1;                              // split-K: raw partial sums meet in slabs (below)
-    const int mode = p.mode, ups = p.ups, Cdst = p.Cdst, Tdst = p.Tdst, Tmask = p.Tmask, M_g = p.M_g;
-    // ---- split-K (round 4: in-kernel).  Every split stores its raw partial tile to its slab of the workspace and takes a
-    // ticket of the tile's counter; the split that arrives LAST sums the slabs in split order (fixed, whoever is last: the
-    // result is bit-reproducible) and goes on to the fused epilogue below, the others leave.  Rounds 1-3 ran a second
-    // kernel for the sum + epilogue: 26 launches of a train step, each re-reading the slabs from a cold cache.
-    if (raw) {
-        float* const slab = p.partial + (size_t)split * out_elems;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + l31;
-            const bool m_ok = m < M_g;
-            const int ch = g * M_g + (m_ok ? m : M_g - 1);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nb0 = n0 + (wn * TN + j) * 32 + 4 * hl;
-                if (vec4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = nb0 + 8 * q;
-                        if (m_ok && n < N) {
-                            const int b = (int)fd_div((uint32_t)n, fdU), u = n - b * U;
-                            *(f32x4*)(slab + (b * Cdst + ch) * Tdst + (mode == 0 ? u : phase + u)) =
-                                (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int n = nb0 + 8 * (e >> 2) + (e & 3);
-                        if (m_ok && n < N) {
-                            const int b = (int)fd_div((uint32_t)n, fdU), u = n - b * U;
-                            slab[(b * Cdst + ch) * Tdst + (mode == 0 ? u : phase + u * os)] = acc[i][j][e];
-                        }
-                    }
-                }
-            }
-        }
-        const unsigned tile = (unsigned)((phase * p.nbx + bx) * p.ny + by);
-        if (!ticket_is_last(p.tickets + tile, (unsigned)nsplits, smem)) return;
-    }
-    float* const outp = p.out;
+    const bool raw = nsplits > 1;                              // split-K: raw partial sums, the epilogue kernel fuses the rest
+    float* const outp = raw ? p.partial + (size_t)split * out_elems : p.out;
     // every launch-uniform condition is resolved ONCE here (a single wave per SIMD pays every branch and scalar load
     // of the epilogue in full: the first version, with the conditions inside the element loops, took 20k cycles)
-    const int act = p.out_act;
-    const float* const resp = p.res;
-    const float* const maskp = p.mode != 1 ? nullptr : p.mask;
-    const float* const scalep = p.scale;
-    const float* const biasp = p.mode != 0 ? nullptr : p.bias;
+    const int act = raw ? STEGAN_ACT_NONE : p.out_act;
+    const float* const resp = raw ? nullptr : p.res;
+    const float* const maskp = (raw || p.mode != 1) ? nullptr : p.mask;
+    const float* const scalep = raw ? nullptr : p.scale;
+    const float* const biasp = (raw || p.mode != 0) ? nullptr : p.bias;
+    const int mode = p.mode, ups = p.ups, Cdst = p.Cdst, Tdst = p.Tdst, Tmask = p.Tmask, M_g = p.M_g;
 #define HB_ACT16(v_)                                                                                            \
     if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
     else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = fmaxf(v_[e], 0.f); }      \
@@ -733,7 +694,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // block) pieces, consecutive lanes on consecutive columns: 512 contiguous bytes of the image per store instruction.
     // The scratch reuses the W ring: the producers have left, the consumer waves meet at one more barrier (a wave that has
     // ended is not waited for) so that no wave overwrites operands another one still reads.
-    unsigned short* const outh = p.out_h;
+    unsigned short* const outh = raw ? nullptr : p.out_h;
     char* const scr = smem + wave * 2048;
     if (outh) block_sync();
 #define HB_IMAGE_TILE(v_, i_, j_, m_ok_)                                                                        \
@@ -767,8 +728,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nb0 = n0 + (wn * TN + j) * 32 + 4 * hl;
-            f32x16 v;
-            if (!raw) v = acc[i][j];
+            f32x16 v = acc[i][j];
             if (vec4) {
                 int oidx[4], midx[4];
                 bool ok[4];
@@ -780,18 +740,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                     const int b = (int)fd_div((uint32_t)nn, fdU), u = nn - b * U;
                     oidx[q] = (b * Cdst + ch) * Tdst + (mode == 0 ? u : phase + u);
                     midx[q] = (b * Cdst + ch) * Tmask + (u >> 1);
-                }
-                if (raw) {                                 // last split of the tile: the slabs' sum in split order
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] = 0.f;
-                    for (int s2 = 0; s2 < nsplits; ++s2) {
-                        const float* sl = p.partial + (size_t)s2 * out_elems;
-                        f32x4 t4[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) t4[q] = *(const f32x4*)(sl + oidx[q]);   // (clamped index: in bounds)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] += t4[e >> 2][e & 3];
-                    }
                 }
                 if (maskp) {
                     if (ups == 0) {
@@ -833,16 +781,11 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                     const int b = (int)fd_div((uint32_t)nn, fdU), u = nn - b * U;
                     const int to = mode == 0 ? u : phase + u * os;
                     oi[e] = (b * Cdst + ch) * Tdst + to;
-                    if (raw) {
-                        float a = 0.f;
-                        for (int s2 = 0; s2 < nsplits; ++s2) a += p.partial[(size_t)s2 * out_elems + oi[e]];
-                        v[e] = a;
-                    }
                     if (maskp) {
                         const float xv = maskp[(b * Cdst + ch) * Tmask + (to >> ups)];
                         v[e] = xv > 0.f ? v[e] : 0.f;
                     }
-                    if (p.out_btc) oi[e] = (b * Tdst + to) * Cdst + ch;       // (B, T, C) store; never with a residual
+                    if (!raw && p.out_btc) oi[e] = (b * Tdst + to) * Cdst + ch;       // (B, T, C) store; never with a residual
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = v[e] * sc + bi;
@@ -1228,10 +1171,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     int cch_max = env_cch ? atoi(env_cch) : 64;
     if (mc && mc->mh.n > 0) cch_max = 8 << mc->logNCB;            // later problems of a multi launch: the first one's variant
     const int64_t out_elems = (int64_t)d->B * p.Cdst * p.Tdst;
-    // (the first TICKET_WORDS words of the workspace are the tiles' arrival counters, zero between launches; slabs behind)
-    const int64_t slab_floats = workspace_floats - TICKET_WORDS;
-    const int max_splits = (workspace && !mc && slab_floats >= out_elems)
-                               ? (int)(slab_floats / out_elems < 16 ? slab_floats / out_elems : 16) : 1;
+    const int max_splits = (workspace && !mc) ? (int)(workspace_floats / out_elems < 16 ? workspace_floats / out_elems : 16) : 1;
     int TM = 0, TN = 0, splits = 1;
     GeoH gm;
     gm.ok = false;
@@ -1322,9 +1262,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     p.splits = splits;
     p.chunks_per_split = ceil_div(nchunks, splits);
     p.splits = ceil_div(nchunks, p.chunks_per_split);
-    p.partial = workspace ? workspace + TICKET_WORDS : nullptr;
-    p.tickets = (unsigned*)workspace;
-    if (base > TICKET_WORDS && p.splits > 1) { p.splits = 1; p.chunks_per_split = nchunks; }      // (split-K is for FEW tiles)
+    p.partial = workspace;
     p.mix_S = 0; p.mix_full = 0; p.mix_cps = 0; p.nbx = (int)nb; p.ny = p.m_tiles * d->groups;
     { const char* se = getenv("STEGAN_STAMP_PTR"); p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }
     p.fdMT = make_fastdiv((uint32_t)p.m_tiles); p.fdSP = make_fastdiv((uint32_t)p.splits);
@@ -1391,6 +1329,12 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     else if (TN == 2) HB_GO(1, 2)
     else HB_GO(1, 1)
 #undef HB_GO
+    static const int whatif = getenv("STEGAN_WHATIF_C") ? atoi(getenv("STEGAN_WHATIF_C")) : 0;     // diagnostics: WRONG results
+    if (p.splits > 1 && !(whatif & 1)) {
+        long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;
+        if (eb > 4096) eb = 4096;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)eb), dim3(256), 0, s, p);
+    }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

@@ -47,8 +47,6 @@ struct DirP {
     int mix_S, mix_full, mix_cps, nbx, ny;
     int tile_m, tile_n;                 // block tile (rows, columns) of the launching kernel: what a tail tile covers
     float* partial;                     // splits > 1: raw accumulators [split][B*Cdst*Tdst], epilogue runs separately
-    unsigned* tickets = nullptr;        // bf16 kernels: per-tile arrival counters (common.h, ticket_is_last): the last split of a
-                                        // tile to arrive sums the slabs and runs the epilogue itself -- no second launch
     unsigned long long* stamps;         // diagnostic builds only (STEGAN_STAMPS): 8 s_memtime stamps per block
     FastDiv fdS;
     FastDiv fdXROW, fdSEG, fdU0, fdU1;  // magic division by XROW, SEG, U0 and U0-1 (the two per-phase column counts)

@@ -19,9 +19,8 @@
 //     no LDS-DMA in the loop, so hipcc's counted vmcnt waits stay exact.
 //   * planes are padded to (slots = 4 mod 16) so that the 32 lanes of a half-wave, which read 4 slots x 2 halves x 2
 //     planes x 2 channel groups, cover all 64 banks once.
-//   * the batch is cut into slices (grid dimension); every slice writes its partial dW to a slab [slice][co][ci][k]
-//     with plain coalesced stores, and the slice that arrives LAST at a tile's ticket counter adds the slabs into dW in
-//     slice order (deterministic; no second launch since round 4).
+//   * the batch is cut into slices (grid dimension); every slice writes its partial dW to a slab [slice][k][co][ci]
+//     with plain coalesced stores and a second kernel adds the slabs into dW in a fixed order (deterministic).
 //
 // Numerics: bf16-rounded operands, fp32 accumulation; the bias gradient stays fp32 (stegan_bias_grad).
 #include "conv_direct_common.h"
@@ -44,9 +43,7 @@ constexpr unsigned OOBW = 0x7ffff000u;
 struct WH {
     const float* x;            // (B, Cin, Tin)
     const float* dy;           // (B, Cout, Tout)
-    float* partial;            // slabs [slices][Cout][Cin_g][K_eff]
-    float* dw = nullptr;       // sliced launches: where the last slice of a tile adds the slabs' sum
-    unsigned* tickets = nullptr;               // per-tile arrival counters (common.h, ticket_is_last)
+    float* partial;            // slabs [slices][K_eff][Cout][Cin_g]
     int B, Cin, Cout, Cin_g, Cout_g, K, stride, dil, pad, Tin, Te, Tout, ups, relu;
     int k_lo, K_eff, NTG;      // live taps, tap groups of KT
     int NB, RU, RUp, R, NST;   // chunk: batch elements, output positions (and padded), columns, k-steps
@@ -472,39 +469,6 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
     float* const dst0 = dw_direct ? dw_direct + h.k_lo + kq0
                                   : h.partial + (size_t)slice * h.K_eff * h.Cout * h.Cin_g + kq0;
     const auto rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)dst0, 0, 0x7ffffff0, 0x00020000);
-    // KT consecutive floats at byte offset off_ of descriptor rs_: the widest dword-aligned accesses
-#define WG_LDK(o_, rs_, off_)                                                                                   \
-    {                                                                                                           \
-        int k_ = 0;                                                                                             \
-        if constexpr (KT >= 4) {                                                                                \
-            _Pragma("unroll") for (; k_ + 4 <= KT; k_ += 4) {                                                   \
-                const u32x4 t4_ = __builtin_amdgcn_raw_buffer_load_b128(rs_, (off_) + 4 * k_, 0, 0);            \
-                _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) o_[k_ + q_] = __builtin_bit_cast(float, t4_[q_]); \
-            }                                                                                                   \
-        }                                                                                                       \
-        if constexpr ((KT & 3) >= 2) {                                                                          \
-            const u32x2 t2_ = __builtin_amdgcn_raw_buffer_load_b64(rs_, (off_) + 4 * k_, 0, 0);                 \
-            o_[k_] = __builtin_bit_cast(float, t2_[0]); o_[k_ + 1] = __builtin_bit_cast(float, t2_[1]); k_ += 2; \
-        }                                                                                                       \
-        if constexpr (KT & 1) o_[k_] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_, (off_) + 4 * k_, 0, 0)); \
-    }
-#define WG_STK(v_, rs_, off_)                                                                                   \
-    {                                                                                                           \
-        int k_ = 0;                                                                                             \
-        if constexpr (KT >= 4) {                                                                                \
-            _Pragma("unroll") for (; k_ + 4 <= KT; k_ += 4) {                                                   \
-                const u32x4 t4_ = {__builtin_bit_cast(unsigned, v_[k_]), __builtin_bit_cast(unsigned, v_[k_ + 1]), \
-                                   __builtin_bit_cast(unsigned, v_[k_ + 2]), __builtin_bit_cast(unsigned, v_[k_ + 3])}; \
-                __builtin_amdgcn_raw_buffer_store_b128(t4_, rs_, (off_) + 4 * k_, 0, 0);                        \
-            }                                                                                                   \
-        }                                                                                                       \
-        if constexpr ((KT & 3) >= 2) {                                                                          \
-            const u32x2 t2_ = {__builtin_bit_cast(unsigned, v_[k_]), __builtin_bit_cast(unsigned, v_[k_ + 1])}; \
-            __builtin_amdgcn_raw_buffer_store_b64(t2_, rs_, (off_) + 4 * k_, 0, 0);                             \
-            k_ += 2;                                                                                            \
-        }                                                                                                       \
-        if constexpr (KT & 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v_[k_]), rs_, (off_) + 4 * k_, 0, 0); \
-    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + (wn * TN + j) * 32 + l31;
@@ -521,12 +485,33 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 for (int k = 0; k < KT; ++k) v[k] = acc[i][j][k][e];
                 if (nk == KT) {
                     if (dw_direct) {                        // read-modify-write: all loads first, then the stores
+                        // (dword loads: a (co, ci) group is only dword aligned, and a buffer_load_dwordx2 at a 4-byte-but-
+                        // not-8-byte aligned offset returned its FIRST DWORD TWICE on gfx950 -- found in round 4 when an
+                        // experiment read slabs back this way (tap 1 == tap 0); every accumulating call so far had met a
+                        // zeroed or constant dW, which hides it.  The wide STORES are fine: the slabs they write have always
+                        // been read back correctly by the reduce kernel.)
                         float o[KT];
-                        WG_LDK(o, rs_o, off)
+#pragma unroll
+                        for (int k = 0; k < KT; ++k)
+                            o[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_o, off + 4 * k, 0, 0));
 #pragma unroll
                         for (int q = 0; q < KT; ++q) v[q] += o[q];
                     }
-                    WG_STK(v, rs_o, off)
+                    int k = 0;
+                    if constexpr (KT >= 4) {
+#pragma unroll
+                        for (; k + 4 <= KT; k += 4) {
+                            const u32x4 t4 = {__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + 1]),
+                                              __builtin_bit_cast(unsigned, v[k + 2]), __builtin_bit_cast(unsigned, v[k + 3])};
+                            __builtin_amdgcn_raw_buffer_store_b128(t4, rs_o, off + 4 * k, 0, 0);
+                        }
+                    }
+                    if constexpr ((KT & 3) >= 2) {
+                        const u32x2 t2 = {__builtin_bit_cast(unsigned, v[k]), __builtin_bit_cast(unsigned, v[k + 1])};
+                        __builtin_amdgcn_raw_buffer_store_b64(t2, rs_o, off + 4 * k, 0, 0);
+                        k += 2;
+                    }
+                    if constexpr (KT & 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[k]), rs_o, off + 4 * k, 0, 0);
                 } else {                                    // ragged last tap group
                     float* ptr = dst0 + (off >> 2);
 #pragma unroll
@@ -537,65 +522,6 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
         }
     }
     WSTAMP(5)
-    if (dw_direct) return;
-    // ---- sliced reduction (round 4: summed in-kernel).  The slice that is LAST to arrive at the tile's ticket counter adds
-    // the slabs of all slices into dW, in slice order -- a fixed order whoever is last -- with the element mapping of the
-    // store above; the other slices' blocks leave.  (Rounds 1-3: conv_wgrad_bf16_reduce_kernel, one more launch per layer,
-    // 52 a train step, reading every slab back from a cold cache.)
-    {
-        const unsigned tiles = (unsigned)(h.co_tiles * h.ci_tiles * G * h.NTG);
-        if (!ticket_is_last(h.tickets + (tile_id - (unsigned)slice * tiles), (unsigned)h.slices, smem)) return;
-    }
-    {
-        const size_t slab_b = (size_t)h.K_eff * h.Cout * h.Cin_g * 4;             // bytes per slice
-        const auto rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)(h.partial + kq0), 0, 0x7ffffff0, 0x00020000);
-        float* const dw0 = h.dw + h.k_lo + kq0;
-        const auto rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)dw0, 0, 0x7ffffff0, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ci = ci0 + (wn * TN + j) * 32 + l31;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int cob = co0 + (wm * TM + i) * 32 + 4 * hl;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int co = cob + (e & 3) + 8 * (e >> 2);
-                    if (ci >= h.Cin_g || co >= h.Cout_g) continue;
-                    const size_t elem = (size_t)(g * h.Cout_g + co) * h.Cin_g + ci;
-                    const int off_s = (int)(elem * h.K_eff * 4), off_d = (int)(elem * h.K * 4);
-                    float v[KT];
-#pragma unroll
-                    for (int k = 0; k < KT; ++k) v[k] = 0.f;
-                    if (nk == KT) {
-                        for (int s2 = 0; s2 < h.slices; ++s2) {
-                            float o[KT];
-                            WG_LDK(o, rs_p, off_s + (int)(s2 * slab_b))
-#pragma unroll
-                            for (int q = 0; q < KT; ++q) v[q] += o[q];
-                        }
-                        float o[KT];
-                        WG_LDK(o, rs_d, off_d)
-#pragma unroll
-                        for (int q = 0; q < KT; ++q) v[q] += o[q];
-                        WG_STK(v, rs_d, off_d)
-                    } else {
-                        for (int s2 = 0; s2 < h.slices; ++s2) {
-                            const float* ps = h.partial + kq0 + (size_t)s2 * (slab_b >> 2) + (off_s >> 2);
-#pragma unroll
-                            for (int k = 0; k < KT; ++k)
-                                if (k < nk) v[k] += ps[k];
-                        }
-                        float* pd = dw0 + (off_d >> 2);
-#pragma unroll
-                        for (int k = 0; k < KT; ++k)
-                            if (k < nk) pd[k] += v[k];
-                    }
-                }
-            }
-        }
-    }
-#undef WG_LDK
-#undef WG_STK
 }
 
 // bias-gradient blocks of the weight-gradient grid (512 threads): db[c] += sum over a batch slice of dy[b, c, :]
@@ -661,6 +587,36 @@ __global__ __launch_bounds__(512) WG_OCC void conv_wgrad_bf16_img_kernel(const W
     conv_wgrad_bf16_body<TM, TN, KT, false, 1, true>(h, dw_direct, t);
 }
 
+// dW[co][ci][k_lo + kk] += sum over slices of slab[slice][kk][co][ci]   (fixed order: deterministic)
+// The bias gradient rides in the same launch: blocks past the first `rb` are bias_grad_body (channel, batch slice) blocks
+// over the fp32 dy (one launch less per layer: 52 a step).
+struct BiasArgs { const float* dy; float* db; int B, C, T, per, slices, vec; FastDiv fdT; };
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                     long per_tap, int slices, int K, int k_lo, int K_eff,
+                                                                     int rb, const BiasArgs ba) {
+    if ((int)blockIdx.x >= rb) {
+        const int j = (int)blockIdx.x - rb;                  // channel-major: the slices of a channel are neighbours
+        bias_grad_body(ba.dy, ba.db, ba.B, ba.C, ba.T, ba.per, ba.fdT, ba.vec, j / ba.slices, j % ba.slices);
+        return;
+    }
+    // slabs are [co][ci][kk] (kk over the K_eff live taps): element i = r * K_eff + kk adds into dw[r * K + k_lo + kk]
+    const long total = per_tap * K_eff;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
+        const long r = i / K_eff;                          // co * Cin_g + ci
+        const int kk = (int)(i - r * K_eff);
+        const float* src = partial + i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= slices; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * total];
+        }
+        for (; s < slices; ++s) v[0] += src[(size_t)s * total];
+        dw[r * K + k_lo + kk] += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+}
+
 int wgh_live_taps(const stegan_conv_desc* d, int& k_lo) {
     const int Te = d->Tin * d->upsample;
     int lo = d->K, hi = -1;
@@ -698,7 +654,10 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
 // Accumulates into dw (and db, through the fp32 bias-gradient kernel).  Returns 1 (nothing enqueued) for shapes left to
 // the fp32 kernels: fewer than 16 channels per group on either side, or a workspace too small for one slab.
 static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy, const uint16_t* dyh,
-                   float* dw, float* db, float* workspace, int64_t workspace_floats, void* stream) {
+                   float* dw, float* db, float* workspace, int64_t workspace_floats, stegan_wgrad_reduce* deferred,
+                   void* stream) {
+    if (deferred) { deferred->partial = nullptr; deferred->dw = nullptr; deferred->per_tap = 0; deferred->slices = 0;
+                    deferred->K = 0; deferred->k_lo = 0; deferred->K_eff = 0; deferred->used_floats = 0; }
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
@@ -792,24 +751,19 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
     // costs a slab written and read back (7 MB for a 768 x 768 x 3 layer) and the weight gradients run beside other streams
     // (the generator's backward chain, the other discriminators), so HALF a chip of longer blocks beats two blocks per CU:
     // train step 8.37 / 8.09 / 7.95 / 7.85 / 7.92 ms for a target of 1024 / 512 / 256 / 128 / 64 blocks (10.4 unsliced)
-    // (workspace: TICKET_WORDS arrival counters -- zero between launches -- then the slabs)
     const int64_t slab = (int64_t)h.K_eff * h.Cout * h.Cin_g;
-    const int64_t slab_room = workspace ? workspace_floats - TICKET_WORDS : 0;
-    if (slab_room < slab) return 1;
+    if (!workspace || workspace_floats < slab) return 1;
     const int b_chunks = ceil_div(h.B, h.NB);
     static const char* env_t = getenv("STEGAN_BF16_WGRAD_TARGET");       // blocks to aim for (experiments)
     const long target = env_t ? atol(env_t) : 128;
     long want = (target + tiles - 1) / tiles;
     if (const char* es = getenv("STEGAN_BF16_WGRAD_SLICES")) want = atol(es);
     if (want > b_chunks) want = b_chunks;
-    if (want > slab_room / slab) want = slab_room / slab;
-    if (tiles > TICKET_WORDS) want = 1;                  // (one counter per tile: sliced launches have few tiles)
+    if (want > workspace_floats / slab) want = workspace_floats / slab;
     if (want < 1) want = 1;
     h.bps = ceil_div(b_chunks, (int)want) * h.NB;
     h.slices = ceil_div(h.B, h.bps);
-    h.partial = workspace + TICKET_WORDS;
-    h.tickets = (unsigned*)workspace;
-    h.dw = dw;
+    h.partial = workspace;
     { const char* e1 = getenv("STEGAN_BF16_WGRAD_XCD"); h.xcd = e1 ? atoi(e1) : 1; }
     { const char* e2 = getenv("STEGAN_BF16_WGRAD_ROT"); h.rot = e2 ? atoi(e2) : 1; }
     h.fdNGA = make_fastdiv((uint32_t)h.NGA); h.fdNGX = make_fastdiv((uint32_t)h.NGX);
@@ -854,6 +808,21 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
         else wgh_launch<1, 1, 3>(xv, grid, lds, s, h, dw_direct, bw);
     } else if (KT == 5) wgh_launch<1, 1, 5>(xv, grid, lds, s, h, dw_direct, bw);
     else wgh_launch<1, 1, 8>(xv, grid, lds, s, h, dw_direct, bw);
+    if (!dw_direct && deferred) {
+        // the caller sums the slabs later, together with those of other layers (stegan_wgrad_reduce_multi)
+        deferred->partial = h.partial; deferred->dw = dw; deferred->per_tap = (int64_t)h.Cout * h.Cin_g;
+        deferred->slices = h.slices; deferred->K = d->K; deferred->k_lo = h.k_lo; deferred->K_eff = h.K_eff;
+        deferred->used_floats = slab * h.slices;
+    } else if (!dw_direct && !(getenv("STEGAN_WHATIF_C") && (atoi(getenv("STEGAN_WHATIF_C")) & 2))) {   // (diagnostics)
+        const long per_tap = (long)h.Cout * h.Cin_g;
+        long rb = (per_tap * h.K_eff + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        BiasArgs ba;
+        ba.dy = dy; ba.db = nullptr; ba.B = d->B; ba.C = d->Cout; ba.T = d->Tout; ba.slices = 0; ba.per = 1; ba.vec = 0;
+        ba.fdT = make_fastdiv(1u);
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s,
+                           h.partial, dw, per_tap, h.slices, d->K, h.k_lo, h.K_eff, (int)rb, ba);
+    }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
@@ -861,7 +830,76 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
 extern "C" int stegan_conv1d_bwd_weight_hx(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
                                            const uint16_t* dyh, float* dw, float* db, float* workspace,
                                            int64_t workspace_floats, void* stream) {
-    return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, stream);
+    return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, nullptr, stream);
+}
+
+extern "C" int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                            const uint16_t* dyh, float* dw, float* db, float* workspace,
+                                            int64_t workspace_floats, stegan_wgrad_reduce* deferred, void* stream) {
+    STEGAN_CHECK_ARG(deferred);
+    return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, deferred, stream);
+}
+
+// ---- the deferred slab sums of up to WRM_MAX layers in ONE launch (52 reduce launches a step become one per phase)
+namespace {
+constexpr int WRM_MAX = 48;
+struct WRMulti {
+    const float* partial[WRM_MAX];
+    float* dw[WRM_MAX];
+    long per_tap[WRM_MAX];
+    int slices[WRM_MAX], K[WRM_MAX], k_lo[WRM_MAX], K_eff[WRM_MAX];
+    int first[WRM_MAX + 1];           // first block of every item; first[n] = grid size
+    int n;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_multi_kernel(const WRMulti a) {
+    int it = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n; ++i)
+        if ((int)blockIdx.x >= a.first[i]) it = i;
+    const int rb = a.first[it + 1] - a.first[it], blk = (int)blockIdx.x - a.first[it];
+    const float* __restrict__ partial = a.partial[it];
+    float* __restrict__ dw = a.dw[it];
+    const int K_eff = a.K_eff[it], K = a.K[it], k_lo = a.k_lo[it], slices = a.slices[it];
+    const long total = a.per_tap[it] * K_eff;
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
+        const long r = i / K_eff;
+        const int kk = (int)(i - r * K_eff);
+        const float* src = partial + i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 4 <= slices; s += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] += src[(size_t)(s + u) * total];
+        }
+        for (; s < slices; ++s) v[0] += src[(size_t)s * total];
+        dw[r * K + k_lo + kk] += (v[0] + v[1]) + (v[2] + v[3]);       // the summation order of the per-layer reduce kernel
+    }
+}
+}  // namespace
+
+extern "C" int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream) {
+    STEGAN_CHECK_ARG(n >= 0 && (n == 0 || items));
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += WRM_MAX) {
+        WRMulti a;
+        a.n = 0; a.first[0] = 0;
+        for (int i = base; i < n && a.n < WRM_MAX; ++i) {
+            const stegan_wgrad_reduce& it = items[i];
+            if (it.slices <= 0) continue;
+            STEGAN_CHECK_ARG(it.partial && it.dw && it.per_tap > 0 && it.K_eff > 0);
+            long rb = (it.per_tap * it.K_eff + 255) / 256;
+            if (rb > 1024) rb = 1024;
+            const int j = a.n++;
+            a.partial[j] = it.partial; a.dw[j] = it.dw; a.per_tap[j] = (long)it.per_tap; a.slices[j] = it.slices;
+            a.K[j] = it.K; a.k_lo[j] = it.k_lo; a.K_eff[j] = it.K_eff;
+            a.first[j + 1] = a.first[j] + (int)rb;
+        }
+        if (a.n == 0) continue;
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_multi_kernel, dim3((unsigned)a.first[a.n]), dim3(256), 0, s, a);
+    }
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
 }
 
 extern "C" int stegan_conv1d_bwd_weight_h(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,

@@ -136,7 +136,7 @@ class ConvProfiler:
 
 PROFILER: Optional[ConvProfiler] = None
 
-# What-if switches (scripts/whatif.py): parts of the step skipped to see what they cost it -- RESULTS ARE WRONG when set.
+# What-if switches (scripts/whatif2.py): parts of the step skipped to see what they cost it -- RESULTS ARE WRONG when set.
 WHATIF = set(filter(None, os.environ.get("STEGAN_WHATIF", "").split(",")))
 
 
@@ -190,33 +190,25 @@ _WORKSPACES = {}
 _WORKSPACES_RETIRED = []      # outgrown workspaces stay allocated: captured graphs hold their addresses (see _workspace)
 
 
-TICKET_WORDS = 4096      # common.h: arrival counters of the in-kernel split reductions, at the start of a ticketed workspace
-
-
-def _workspace(device, floats: int, tickets: bool = False) -> Tensor:
-    """Split-K / batch-slice scratch shared by all conv launches of a (device, stream): launches are stream ordered, and a
-    launch's partial sums are consumed by that launch (its last-arriving blocks) or by the kernel enqueued right behind it.
-
-    The buffer starts with TICKET_WORDS counters (32-bit, zeroed when it is allocated, left at zero by every launch that
-    uses them: csrc/common.h ``ticket_is_last``) followed by the slab area.  ``tickets=True`` returns the whole buffer (the
-    bf16 conv / weight-gradient kernels, which count arrivals); otherwise only the slab area is handed out.
+def _workspace(device, floats: int) -> Tensor:
+    """Split-K scratch shared by all conv launches of a (device, stream): launches are stream ordered, and the
+    epilogue kernel that consumes the partial sums is enqueued right behind the conv that produced them.
 
     A workspace that has to grow is RETIRED, never freed: a captured hipGraph bakes the address of the workspace it was
     recorded with into its kernel nodes, so freeing an outgrown buffer would leave every earlier capture (an earlier kernel
     of the same capture, or the graph of another batch shape in train()) writing its partial sums into memory the allocator
     hands to someone else -- seen as a GPU memory fault in train()'s second graph.  Growth is geometric and capped at
     512 MiB, so a stream retires at most a few buffers."""
-    floats = min(floats, 1 << 27) + TICKET_WORDS           # cap at 512 MiB; the kernels lower their split to fit
+    floats = min(floats, 1 << 27)                      # cap at 512 MiB; the kernel lowers the split to fit
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < floats:
         if ws is not None:
             _WORKSPACES_RETIRED.append(ws)
         size = max(floats, 1 << 22, 2 * ws.numel() if ws is not None else 0)
-        ws = torch.empty(min(size, (1 << 27) + TICKET_WORDS), device=device, dtype=torch.float32)
-        ws[:TICKET_WORDS].zero_()
+        ws = torch.empty(min(size, 1 << 27), device=device, dtype=torch.float32)
         _WORKSPACES[key] = ws
-    return ws if tickets else ws[TICKET_WORDS:]
+    return ws
 
 
 WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
@@ -470,7 +462,7 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
             return y
     wfh = _bf16_of(wf)
     if wfh is not None:
-        ws = _workspace(x.device, y.numel() * _SPLITK_MAX, tickets=True)
+        ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
         xh = _image_of(x, cfg.cin, tin)
         if IMG_STATS is not None:
             IMG_STATS.setdefault((0, xh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
@@ -513,7 +505,7 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
             return dx
     wbh = _bf16_of(wb)
     if wbh is not None:
-        ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX, tickets=True)
+        ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
         dyh = _image_of(dy, cfg.cout, tout)
         if IMG_STATS is not None:
@@ -542,9 +534,38 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
     return dx
 
 
+class WgradReduce(C.Structure):       # mirrors struct stegan_wgrad_reduce
+    _fields_ = [("partial", C.c_void_p), ("dw", C.c_void_p), ("per_tap", C.c_int64), ("used_floats", C.c_int64),
+                ("slices", C.c_int32), ("K", C.c_int32), ("k_lo", C.c_int32), ("K_eff", C.c_int32)]
+
+
+# Deferred slab sums of the sliced weight gradients (sink mode: dW is a view of a gradient arena that nothing reads before
+# ConvPack.finalize_grads -> wgrad_join): the slabs of a phase's layers live side by side in one arena and ONE multi-problem
+# launch per phase adds them into the arenas (52 reduce launches a step otherwise).  The arena is a fixed buffer per device
+# (captured graphs hold its address); a layer that does not fit any more sums its slabs at once, the round-2 way.
+# MEASURED AND SWITCHED OFF: 6.97 ms per step against 6.87 with the per-layer reduce launches -- those are spread over the
+# backward pass and fill gaps on busy streams, the batched sum sits alone between the last weight gradient and the optimiser.
+# Kept as an option (STEGAN_WGRAD_DEFER=1; tests/test_gpu_train_step.py runs the golden step through it).
+WGRAD_DEFER = os.environ.get("STEGAN_WGRAD_DEFER", "0") == "1"
+_WG_ARENA_FLOATS = int(os.environ.get("STEGAN_WGRAD_ARENA_MB", "1024")) * (1 << 18)
+_WG_ARENA: dict = {}           # device -> [arena, floats in use]
+_WG_DEFERRED: list = []        # (WgradReduce, dw tensor kept alive)
+
+
+def _wgrad_reduce_flush() -> None:
+    """The pending slab sums as one launch on the CURRENT stream (which the caller has ordered behind every weight-gradient
+    launch: wgrad_join), and the arena is free again for the launches ordered behind this one."""
+    if _WG_DEFERRED:
+        arr = (WgradReduce * len(_WG_DEFERRED))(*[it for it, _ in _WG_DEFERRED])
+        check(_lib.lib().stegan_wgrad_reduce_multi(len(_WG_DEFERRED), arr, _stream()), "stegan_wgrad_reduce_multi")
+        _WG_DEFERRED.clear()
+    for st in _WG_ARENA.values():
+        st[1] = 0
+
+
 def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor], defer: bool = False) -> None:
-    """Accumulates into dw (and db).  (``defer``: unused since round 4 -- the batch slices' slabs are summed inside the
-    launch, by the last slice of each tile to arrive; kept for the call sites.)"""
+    """Accumulates into dw (and db).  ``defer``: the caller promises that dw is read only after ops.wgrad_join() (gradient
+    sinks); the sum over the batch slices may then be postponed to that call."""
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
     if cfg.cout == 1 and SKINNY:
@@ -558,7 +579,26 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
         xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
         if IMG_STATS is not None:
             IMG_STATS.setdefault((2, xh is not None and dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
-        ws = _workspace(x.device, dw.numel() * 64, tickets=True)      # ticket counters + slabs of the batch slices
+        if defer and WGRAD_DEFER and PROFILER is None and x.is_cuda:
+            st = _WG_ARENA.get(x.device)
+            if st is None:
+                st = _WG_ARENA[x.device] = [torch.empty(_WG_ARENA_FLOATS, device=x.device, dtype=torch.float32), 0]
+            arena, used = st
+            room = arena.numel() - used
+            if room >= dw.numel() * 8:                    # room for at least 8 slices: worth a deferred launch
+                item = WgradReduce()
+                ws = arena[used:]
+                rc = _lib.lib().stegan_conv1d_bwd_weight_hxd(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw), _p(db),
+                                                             _p(ws), min(room, dw.numel() * 64), C.byref(item), _stream())
+                if rc != 1:
+                    check(rc, "stegan_conv1d_bwd_weight_hxd")
+                    global LAST_CONV_KERNEL
+                    LAST_CONV_KERNEL = "bf16"
+                    if item.slices > 0:
+                        st[1] = used + ((int(item.used_floats) + 63) & ~63)
+                        _WG_DEFERRED.append((item, dw))
+                    return
+        ws = _workspace(x.device, dw.numel() * 64)            # slabs for the batch slices of the reduction
         rc = _timed(d, 2, lambda: _lib.lib().stegan_conv1d_bwd_weight_hx(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw),
                                                                          _p(db), _p(ws), ws.numel(), _stream()), "bf16")
         if rc != 1:
@@ -590,7 +630,6 @@ def wgrad_async(on: bool) -> None:
 
 F32_STREAMS = os.environ.get("STEGAN_F32_STREAMS", "1") == "1"      # the discriminator fork and the generator's weight-gradient
                                                                      # streams in fp32 mode too: 19.2 -> 17.1 ms/step
-MULTI_WGRAD_ASYNC = os.environ.get("STEGAN_MULTI_WGRAD_ASYNC", "0") == "1"   # period discriminators' weight gradients aside
 WGRAD_BATCH = int(os.environ.get("STEGAN_WGRAD_BATCH", "5"))        # weight gradients launched per fork (8.14 ms/step; 8.30 with 1, 8.21 with 2, 8.17 with 3, 8.16 with 4, 8.20 with 8)
 _WG_PENDING: list = []
 _WG_USED: dict = {}            # side streams forked since the last wgrad_join() (only those are joined: waiting on a
@@ -648,6 +687,7 @@ def wgrad_join() -> None:
         if key != cur.cuda_stream:
             cur.wait_stream(s_)
     _SINK_STREAMS.clear()
+    _wgrad_reduce_flush()          # behind every weight-gradient launch of the phase: their slabs' sums, one launch
 
 
 def wgrad_abort() -> None:
@@ -656,7 +696,9 @@ def wgrad_abort() -> None:
     if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         torch.cuda.synchronize()
     _WG_ON[0] = False
-    _WG_PENDING.clear(); _WG_KEEP.clear(); _WG_USED.clear(); _SINK_STREAMS.clear()
+    _WG_PENDING.clear(); _WG_KEEP.clear(); _WG_USED.clear(); _SINK_STREAMS.clear(); _WG_DEFERRED.clear()
+    for st in _WG_ARENA.values():
+        st[1] = 0
     fm_fold_abort()
 
 
@@ -929,23 +971,9 @@ class _WNConvMultiFn(torch.autograd.Function):
                     check(rc, "stegan_conv1d_bwd_weight_skinny_multi")
                     done = True
             if not done:
-                # the problems' weight gradients are independent of each other and of the input-gradient chain: beside it,
-                # on the weight-gradient side streams (MULTI_WGRAD_ASYNC), or inline
-                aside = MULTI_WGRAD_ASYNC and WGRAD_STREAMS > 0 and PROFILER is None
-                was = _WG_ON[0]
-                if aside:
-                    _WG_ON[0] = True
-                try:
-                    for x, g, l in zip(xs, gs, layers):
-                        if l[5] is not None:
-                            if aside:
-                                _wgrad_sink(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None)
-                            else:
-                                conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None, defer=True)
-                    if aside:
-                        _wgrad_flush()
-                finally:
-                    _WG_ON[0] = was
+                for x, g, l in zip(xs, gs, layers):
+                    if l[5] is not None:
+                        conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None, defer=True)
         dxs = [None] * n
         need = [ctx.needs_input_grad[2 + i] for i in range(n)]
         if any(need):

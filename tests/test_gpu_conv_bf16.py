@@ -262,3 +262,35 @@ def test_activation_backward_writes_the_image_for_any_row_length(shape):
         assert h is not None and torch.equal(h.view(torch.int16), make_image(out).view(torch.int16))
     finally:
         ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("slices", ["1", "2"])
+def test_weight_gradient_accumulates_onto_a_non_constant_dw(slices, monkeypatch):
+    """dW += ...: two accumulating calls onto a RANDOM dW, sliced (slabs + ordered sum) and unsliced (read-modify-write in the
+    kernel's epilogue).  Every other test starts from a constant dW, which hid a wrong wide load in the unsliced path: a
+    buffer_load_dwordx2 at a 4-but-not-8-byte aligned offset returned its first dword twice (tap 1 == tap 0 for k = 3)."""
+    from ste_gan_amd import ops
+    monkeypatch.setenv("STEGAN_BF16_WGRAD_SLICES", slices)
+    B, Cin, Cout, K, Tin = 2, 96, 48, 3, 24
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(B, Cin, Tin, generator=gen)
+    c = ops.ConvCfg(Cin, Cout, K, 1, 1, 1, 1, 2, 1)                 # k3, nearest x2, input ReLU
+    dy = torch.randn(B, Cout, c.tout(Tin), generator=gen)
+    hx = F.interpolate(F.relu(x), scale_factor=2.0, mode="nearest")
+    w0 = torch.zeros(Cout, Cin, K, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv1d(bf16r(hx), w0, None, padding=1), w0, bf16r(dy))
+    ops.set_compute_dtype("bf16")
+    try:
+        for images in (False, True):
+            init = torch.randn(Cout, Cin, K, generator=gen)
+            dw, db = init.cuda().clone(), torch.zeros(Cout, device="cuda")
+            xg, dyg = x.cuda(), dy.cuda()
+            if images:
+                ops._attach_image(xg, make_image(xg)); ops._attach_image(dyg, make_image(dyg))
+            ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
+            ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
+            assert ops.LAST_CONV_KERNEL == "bf16"
+            err = (dw.double().cpu() - init.double() - 2 * ref).abs()
+            assert float(err.max()) <= 3e-5 * float(ref.abs().max()), err.amax((0, 1)).tolist()
+    finally:
+        ops.set_compute_dtype("f32")

@@ -292,6 +292,16 @@ def test_three_graph_replay_with_process_group_matches_golden(split_side, monkey
     assert not dist.is_initialized()
 
 
+def test_deferred_weight_gradient_sums_match_golden(monkeypatch, golden):
+    """ops.WGRAD_DEFER (off by default): the batch-slice slabs of a phase's weight gradients summed by ONE multi-problem launch in
+    wgrad_join instead of one reduce launch per layer -- same summation order per element, so the golden step holds unchanged."""
+    from ste_gan_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
+    name = next(iter(cases.STEP_CASES))
+    test_train_step_vs_golden(name, golden)
+    assert not ops._WG_DEFERRED
+
+
 def test_feature_matching_fold_equals_autograd_accumulation():
     """The feature-matching gradients added inside the discriminator convs' activation backward (ops.fm_fold_begin) give
     the generator the same gradients as returning them to autograd: every feature map is parked and collected, and the

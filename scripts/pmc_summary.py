@@ -60,6 +60,13 @@ def main():
                      "three passes (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE); "
                      "summarised by scripts/pmc_summary.py; raw rows: the .csv.gz files beside this file",
            "steps_in_run": steps, "families": {}}
+    # provenance: the kernel sources these counters were measured on (bench.py refuses counter-derived fields when the tree
+    # has moved on) and when
+    import datetime, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from ste_gan_amd.build import source_hash
+    res["csrc_sha"] = source_hash()
+    res["measured_utc"] = datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ")
     tot_bytes = 0.0
     for fam in sorted(agg, key=lambda k: -agg[k].get("GRBM_GUI_ACTIVE", 0)):
         c = agg[fam]

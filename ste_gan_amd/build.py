@@ -51,5 +51,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, *.h, the C-ABI header): what a committed profile was measured on.  bench.py
+    prints counter-derived fields only when the profile's hash equals the tree's."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "stegan_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -30,19 +30,46 @@ def test_gpus_n_without_enough_gpus_is_refused_before_any_rank_starts():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-def test_step_rooflines_use_the_committed_counter_summary():
+def test_step_rooflines_are_algorithmic_and_counters_carry_their_provenance(monkeypatch, tmp_path):
+    """``hbm_frac`` is algorithmic bytes / time / peak (SURVEY's models, never bytes moved); the bytes the
+    kernels moved are separate ``moved_*`` fields that name the profile they came from and are refused when that profile was
+    measured on other kernel sources."""
     import bench
-    r = bench.step_rooflines(6.75e-3, "bf16")
-    assert r["algorithmic_gflop"] == bench.STEP_GFLOP and abs(r["mfma_frac"] - 1016.9 / 6.75 / 2500.0) < 1e-3
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")))
-    moved = summary["hbm_bytes_per_step"]
-    assert r["moved_gbytes_per_step_pmc"] == round(moved / 1e9, 3)
-    assert abs(r["hbm_frac"] - moved / 1e9 / 6.75e-3 / 8000.0) < 1e-3          # on the bytes the kernels moved
-    assert r["hbm_frac_layer_boundary_model"] < r["hbm_frac"]
-    # every family the summary names carries the fields bench.py reads
-    for fam in summary["families"].values():
-        assert {"hbm_bytes_per_launch", "hbm_bytes_per_step", "mfma_busy_frac", "launches"} <= set(fam)
-    assert 0.0 < summary["families"]["conv_bf16_kernel"]["mfma_busy_frac"] < 1.0
+    from ste_gan_amd.build import source_hash
+    t, fps = 6.0e-3, 12288 / 6.0e-3
+    monkeypatch.setattr(bench, "PMC", {})
+    monkeypatch.setattr(bench, "PMC_STALE", "stale: test")
+    r = bench.step_rooflines(t, "bf16", fps)
+    assert r["algorithmic_gflop"] == bench.STEP_GFLOP and abs(r["mfma_frac"] - 1016.9 / 6.0 / 2500.0) < 1e-3
+    assert abs(r["hbm_frac"] - 3.79 / t / 8000.0) < 1e-4 and abs(r["hbm_frac_fp32_model"] - 6.58 / t / 8000.0) < 1e-4
+    assert abs(r["frames_frac_of_hbm_bound"] - fps / 26.0e6) < 1e-4 and abs(r["frames_frac_of_mfma_bound"] - fps / 30.4e6) < 1e-4
+    assert abs(r["frac_of_target"] - fps / 13.0e6) < 1e-4
+    assert r["moved_gbytes_per_step_pmc"] is None and r["moved_profile"] == "stale: test"
+    # a profile measured on THESE sources is used, one measured on others is not
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (prof / "r09_pmc_summary.json").write_text(json.dumps({"csrc_sha": "0" * 16, "hbm_bytes_per_step": 1e10, "families": {}}))
+    pmc, why = bench.load_pmc()
+    assert pmc == {} and "measured on kernel sources" in why
+    (prof / "r10_pmc_summary.json").write_text(json.dumps({"csrc_sha": source_hash(), "measured_utc": "2026-10-05T00:00Z",
+                                                           "hbm_bytes_per_step": 1.2e10, "families": {}}))
+    pmc, why = bench.load_pmc()
+    assert why is None and pmc["_file"].endswith("r10_pmc_summary.json")
+    monkeypatch.setattr(bench, "PMC", pmc)
+    r = bench.step_rooflines(t, "bf16", fps)
+    assert r["moved_gbytes_per_step_pmc"] == 12.0 and abs(r["moved_over_algorithmic"] - 12.0 / 3.79) < 0.01
+    assert r["moved_profile"]["csrc_sha"] == source_hash()
+    assert abs(r["hbm_frac"] - 3.79 / t / 8000.0) < 1e-4             # unchanged by the counters
+
+
+def test_committed_counter_summaries_carry_the_fields_bench_reads():
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")):
+        summary = json.load(open(f))
+        for fam in summary["families"].values():
+            assert {"hbm_bytes_per_launch", "hbm_bytes_per_step", "mfma_busy_frac", "launches"} <= set(fam)
+        assert 0.0 < summary["families"]["conv_bf16_kernel"]["mfma_busy_frac"] < 1.0
 
 
 def test_conv_profiler_algorithmic_bytes():

@@ -362,7 +362,7 @@ def main():
     # batch is placed there once (a training loop's batch-assembly kernel writes into them directly)
     run_batch = batch
     if graphed:
-        step(batch)
+        step.load_batch(batch)
         run_batch = None
     for _ in range(args.warmup):
         step(run_batch)
@@ -507,7 +507,9 @@ def main():
                                        ("bf16 conv operands, fp32 accumulation / activations / weights (BASELINE config 3)"
                                         if args.dtype == "bf16" else "fp32 parity path"),
                            "global_batch": world * B, "parallelism": f"dp{world}",
-                           "launch": ("hipGraph replay" if world == 1 else "3 hipGraphs per step around 2 eager RCCL all-reduces") if graphed else "eager"},
+                           "launch": ("eager" if not graphed else "hipGraph replay" if world == 1 else
+                                      "1 hipGraph per step, the 2 RCCL all-reduces captured inside it" if getattr(step, "ddp_mode", None) == "single"
+                                      else "3 hipGraphs per step around 2 eager RCCL all-reduces")},
                 "roofline": roof,
                 # whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds)
                 "step_rooflines": step_rooflines(dt / args.steps, args.dtype, frames / dt),

@@ -91,6 +91,9 @@ class GANTrainStep:
         # step (phase_d), backward beside the D update and the generator-side discriminator passes (phase_g).  Set by
         # GraphedTrainStep under torch.distributed, where the phases are separate hipGraphs around the gradient exchanges
         self.split_side = False
+        # torch.distributed with the exchanges INSIDE one captured graph (GraphedTrainStep, "single"): the side branch is not
+        # joined at the end of phase_d -- it runs on beside the D-gradient exchange, which only the main stream awaits
+        self.join_side_after_phase_d = True
 
     def _side_stream(self):
         if self._side is None:
@@ -173,7 +176,7 @@ class GANTrainStep:
                 if side_w > 0:
                     ops.plan_hint(0.0)
         self._p_disc()
-        if side is not None and (self.comm is not None or split):
+        if side is not None and ((self.comm is not None and self.join_side_after_phase_d) or split):
             # under torch.distributed this phase ends with the side stream joined: the gradient exchange that follows is
             # issued from the main stream, and a captured phase (GraphedTrainStep) must end with every forked stream joined.
             # The branch's BACKWARD pass then runs beside the first half of phase_g (split_side); without the split the
@@ -452,33 +455,65 @@ class GraphedTrainStep:
         mode = dict(capture_error_mode=self.CAPTURE_ERROR_MODE)
         if os.environ.get("STEGAN_MAIN_PRIORITY"):            # experiment hook: capture on a stream with a priority
             mode["stream"] = torch.cuda.Stream(priority=int(os.environ["STEGAN_MAIN_PRIORITY"]))
+        self.ddp_mode = None
         if step.comm is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, **mode):
                 self.out = step(self.static)
             self.graphs = None
         else:
-            step._d_handle = step._g_handle = None            # nothing to await inside the captures
-            # THREE graphs: phase_d | phase_g | phase_opt around the two exchanges.  The side branch (multi-TD + frozen
-            # encoder, forward and backward: 2.5 ms, the longest arm of the step) would make the first graph end 1.3 ms after
-            # the discriminator's gradients are ready if it ran there as a whole (round 2), so it is cut in two: forward +
-            # losses in the first graph beside the discriminator step, backward in the second beside the D update and the
-            # generator-side discriminator passes (GANTrainStep.split_side).  Measured on one GPU with a 1-rank RCCL group
-            # (scripts/ddp_graph_timing.py): see DESIGN.md.  (Tried and dropped: the branch as a FOURTH graph replayed on its own
-            # stream across the exchange -- 8.5 ms/step: streams map onto 4 hardware queues, the replay stream shared one with
-            # the discriminator graph's internal fork streams and the two ran one after the other.)
-            step.split_side = os.environ.get("STEGAN_SPLIT_SIDE", "1") != "0"
-            g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, **mode):
-                step.phase_d(self.static)
-            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
-                step.phase_g()
-            with torch.cuda.graph(g3, pool=g1.pool(), **mode):
-                self.out = step.phase_opt()
-            self.graphs = (g1, g2, g3)
+            self.graph, self.graphs = None, None
+            # ---- torch.distributed.  "single" (default with RCCL): ONE graph for the whole step with the two gradient
+            # all-reduces CAPTURED inside it, on the communication stream (RCCL collectives are capturable like NCCL's:
+            # scripts/rccl_capture_probe.py).  No graph boundary drains the streams (0.45 ms of a 6.8 ms step with three
+            # graphs), and the exchanges overlap whatever does not depend on them by construction: the D-gradient exchange
+            # runs beside the tail of the side branch (multi-TD + frozen encoder), which only the generator's backward pass
+            # awaits.  "three": the phases as three graphs around two eagerly launched exchanges -- the arrangement of
+            # rounds 2-3, kept for backends whose collectives cannot be captured (gloo) and as the fallback when the
+            # single capture raises.  STEGAN_DDP_GRAPH=single|three forces one.
+            want = os.environ.get("STEGAN_DDP_GRAPH", "single" if dist.get_backend(step.comm.group) == "nccl" else "three")
+            if want == "single":
+                try:
+                    step._d_handle = step._g_handle = None
+                    step.join_side_after_phase_d = False
+                    step.split_side = False
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, **mode):
+                        self.out = step(self.static)
+                    self.graph, self.ddp_mode = g, "single"
+                except Exception as e:                           # noqa: BLE001 -- reported; the three-graph path follows
+                    logging.warning(f"single-graph capture with RCCL collectives failed ({type(e).__name__}: {e}); "
+                                    "falling back to three graphs around eager exchanges")
+                    step.abort()
+                    torch.cuda.synchronize()
+                    self.graph = None
+            if self.graph is None:
+                self._capture_three(step, mode)
+                self.ddp_mode = "three"
         # capture ran the Python side once without executing kernels: undo its optimiser step counts
         step.optG.step_count, step.optD.step_count = self._counts
         self.last = self.out
+
+    def _capture_three(self, step: GANTrainStep, mode) -> None:
+        step._d_handle = step._g_handle = None            # nothing to await inside the captures
+        step.join_side_after_phase_d = True
+        # THREE graphs: phase_d | phase_g | phase_opt around the two exchanges.  The side branch (multi-TD + frozen
+        # encoder, forward and backward: 2.5 ms, the longest arm of the step) would make the first graph end 1.3 ms after
+        # the discriminator's gradients are ready if it ran there as a whole (round 2), so it is cut in two: forward +
+        # losses in the first graph beside the discriminator step, backward in the second beside the D update and the
+        # generator-side discriminator passes (GANTrainStep.split_side).  Measured on one GPU with a 1-rank RCCL group
+        # (scripts/ddp_graph_timing.py): see DESIGN.md.  (Tried and dropped: the branch as a FOURTH graph replayed on its own
+        # stream across the exchange -- 8.5 ms/step: streams map onto 4 hardware queues, the replay stream shared one with
+        # the discriminator graph's internal fork streams and the two ran one after the other.)
+        step.split_side = os.environ.get("STEGAN_SPLIT_SIDE", "1") != "0"
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, **mode):
+            step.phase_d(self.static)
+        with torch.cuda.graph(g2, pool=g1.pool(), **mode):
+            step.phase_g()
+        with torch.cuda.graph(g3, pool=g1.pool(), **mode):
+            self.out = step.phase_opt()
+        self.graphs = (g1, g2, g3)
 
     def _weights_signature(self):
         return sum(p._version for p in self.step.netD.parameters()) + sum(b._version for b in self.step.netD.buffers())
@@ -499,14 +534,18 @@ class GraphedTrainStep:
         opt.step_count += 1          # host mirror of the device-side counter the captured advance kernel increments
         opt.sync_lr()
 
+    def load_batch(self, batch_dict: Dict[str, torch.Tensor]) -> None:
+        """Copy a batch into the graph's static input buffers (stream ordered, no step)."""
+        for k, v in batch_dict.items():
+            if torch.is_tensor(v) and v is not self.static[k]:
+                self.static[k].copy_(v, non_blocking=True)
+
     def __call__(self, batch_dict: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         """``batch_dict`` is copied into the graph's static input buffers; None (or ``self.static`` itself): the batch is
         already there -- a producer that writes into ``self.static`` (the batch-assembly kernel, a benchmark whose
-        synthetic batch is resident) saves the five device-to-device copies in front of every replay."""
+        synthetic batch is resident: ``load_batch``) saves the five device-to-device copies in front of every replay."""
         if batch_dict is not None and batch_dict is not self.static:
-            for k, v in batch_dict.items():
-                if torch.is_tensor(v) and v is not self.static[k]:
-                    self.static[k].copy_(v, non_blocking=True)
+            self.load_batch(batch_dict)
         self._stage(self.step.optD)
         self._stage(self.step.optG)
         if self._weights_signature() != self._d_sig or self.step.optD.pack is None or \

@@ -1,4 +1,6 @@
-"""The three-graph replay (side branch split over the first two; STEGAN_SPLIT_SIDE=0: whole in the first) under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
+"""The graph replay under torch.distributed -- ONE graph with the two RCCL all-reduces captured inside it (STEGAN_DDP_GRAPH=single,
+the default with RCCL) or three graphs around eager exchanges (=three; side branch split over the first two, STEGAN_SPLIT_SIDE=0:
+whole in the first) -- under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
 (``parallel.shutdown``); run in-process by test_gpu_train_step.py::test_multi_graph_replay_with_process_group_matches_golden
 and usable as a script."""
 import os
@@ -28,7 +30,9 @@ def main():
     sdG = {k: v.clone() for k, v in netG.state_dict().items()}
     sdD = {k: v.clone() for k, v in netD.state_dict().items()}
     gs = GraphedTrainStep(step, to_batch(cases.step_batch(name, 0)), warmup=2)
-    assert gs.graphs is not None and len(gs.graphs) == 3
+    want = os.environ.get("STEGAN_DDP_GRAPH", "single")
+    assert gs.ddp_mode == want, f"captured as {gs.ddp_mode!r}, wanted {want!r} (a silent fallback would hide a capture failure)"
+    assert (gs.graphs is not None and len(gs.graphs) == 3) if want == "three" else (gs.graph is not None and gs.graphs is None)
     netG.load_state_dict(sdG); netD.load_state_dict(sdD)
     for opt in (optG, optD):
         opt.reset_state()

@@ -28,6 +28,9 @@ def main():
     assert step.comm is not None and step.comm.world_size == world
     shards = [to_device_batch(shard_batch(full_batch(s), rank, world)) for s in range(STEPS)]
     runner = step
+    if mode == "eager_overlap":
+        # the schedule of the single-graph capture, eagerly: the side branch is NOT joined before the D-gradient exchange
+        step.join_side_after_phase_d = False
     if mode == "graph":
         sdG = {k: v.clone() for k, v in netG.state_dict().items()}
         sdD = {k: v.clone() for k, v in netD.state_dict().items()}

@@ -1,7 +1,10 @@
 """-m gpu: the data-parallel train step on the GPU kernels (VERDICT r02 "multi-rank correctness").
 
-Two ranks (gloo, both on the box's one card) each run ``GANTrainStep`` on HALF of a detfill batch -- eagerly, and as the
-three replayed hipGraphs (the side branch split over the first two) around the two gradient exchanges -- for two optimiser steps.  Checked: the replicas' parameters
+Two ranks (gloo, both on the box's one card) each run ``GANTrainStep`` on HALF of a detfill batch -- eagerly, eagerly with the
+overlapped schedule of the single-graph capture (the side branch runs on across the D-gradient exchange), and as the three
+replayed hipGraphs (the side branch split over the first two) around the two gradient exchanges -- for two optimiser steps.
+(The single graph with CAPTURED collectives needs RCCL, one rank per GPU: its replay is checked against the golden
+fixture with a 1-rank group, tests/test_gpu_train_step.py.)  Checked: the replicas' parameters
 are bit-identical, and equal the single-process step on the WHOLE batch (every loss is a batch mean; the exchange
 averages the gradients) to 2e-5 in every tensor's norm and 2e-4 element-wise.  The ranks end through
 ``parallel.shutdown`` and must exit with code 0 (no os._exit escape)."""
@@ -67,9 +70,9 @@ def _run_ranks(tmp_path, mode, port):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("mode", ["eager", "eager_overlap", "graph"])
 def test_two_gpu_step_replicas_equal_the_full_batch_step(tmp_path, mode):
-    r0, r1 = _run_ranks(tmp_path, mode, 29771 if mode == "eager" else 29772)
+    r0, r1 = _run_ranks(tmp_path, mode, {"eager": 29771, "graph": 29772, "eager_overlap": 29773}[mode])
     netG, netD, optG, optD, step = build_nets()
     assert step.comm is None
     for s in range(STEPS):

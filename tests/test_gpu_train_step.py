@@ -275,31 +275,24 @@ def test_graph_replay_matches_golden(golden):
         close(norms(netD.state_dict().values()), g[f"s{s}.d_param_norm"], 2e-5, f"s{s}.d_param_norm")
 
 
-@pytest.mark.parametrize("split_side", ["1", "0"])
-def test_three_graph_replay_with_process_group_matches_golden(split_side, monkeypatch):
-    """Under torch.distributed GraphedTrainStep captures the step's three phases as three hipGraphs (one memory pool) and
-    launches the two gradient all-reduces eagerly between them; the side branch (multi-TD + frozen encoder) is cut in two --
-    forward in the first graph, backward in the second (STEGAN_SPLIT_SIDE=0: whole in the first, the round-2 arrangement).
-    With a 1-rank RCCL group the replay must reproduce the golden two-step fixture like the single-graph and the eager
-    paths -- IN THIS PROCESS, ending in the ordered teardown (parallel.shutdown: drain, drop graphs + pool + comm stream,
+@pytest.mark.parametrize("mode,split_side", [("single", "1"), ("three", "1"), ("three", "0")])
+def test_graph_replay_with_process_group_matches_golden(mode, split_side, monkeypatch):
+    """Under torch.distributed GraphedTrainStep captures the step as ONE hipGraph with the two RCCL gradient all-reduces
+    inside it, on the communication stream ("single": no graph boundary drains the streams, the D-gradient exchange runs
+    beside the tail of the side branch), or as three hipGraphs (one memory pool) with the all-reduces launched eagerly
+    between them ("three"; the side branch -- multi-TD + frozen encoder -- cut in two, forward in the first graph, backward
+    in the second; STEGAN_SPLIT_SIDE=0: whole in the first, the round-2 arrangement).  With a 1-rank RCCL group every
+    arrangement must reproduce the golden two-step fixture like the single-process graph and the eager path -- IN THIS
+    PROCESS, ending in the ordered teardown (parallel.shutdown: drain, drop graphs + pool + comm stream,
     destroy_process_group).  Round 2 ran this in a child that left through os._exit: the abort it dodged was the
-    capture-mode race fixed since (GraphedTrainStep, thread_local)."""
+    capture-mode race fixed since (GraphedTrainStep.CAPTURE_ERROR_MODE, pinned in tests/test_host_logic.py)."""
     import torch.distributed as dist
     import ddp_graph_worker
+    monkeypatch.setenv("STEGAN_DDP_GRAPH", mode)
     monkeypatch.setenv("STEGAN_SPLIT_SIDE", split_side)
     assert not dist.is_initialized()
     ddp_graph_worker.main()
     assert not dist.is_initialized()
-
-
-def test_deferred_weight_gradient_sums_match_golden(monkeypatch, golden):
-    """ops.WGRAD_DEFER (off by default): the batch-slice slabs of a phase's weight gradients summed by ONE multi-problem launch in
-    wgrad_join instead of one reduce launch per layer -- same summation order per element, so the golden step holds unchanged."""
-    from ste_gan_amd import ops
-    monkeypatch.setattr(ops, "WGRAD_DEFER", True)
-    name = next(iter(cases.STEP_CASES))
-    test_train_step_vs_golden(name, golden)
-    assert not ops._WG_DEFERRED
 
 
 def test_feature_matching_fold_equals_autograd_accumulation():

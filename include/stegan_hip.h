@@ -536,8 +536,13 @@ int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2, void* str
  */
 int stegan_conv1d_fwd_skinny(const stegan_conv_desc* d, const float* x, const float* w, const float* scale,
                              const float* bias, const float* residual, float* y, void* stream);
+/* (input gradient with d->in_act == STEGAN_ACT_LRELU, round 4 -- also stegan_conv1d_bwd_data_hx / _multi_hx: x is the
+ * leaky-ReLU(0.1) OUTPUT of the layer before (discriminator.py:38,64,90,116), and the launch applies that layer's
+ * activation derivative itself: dx = (conv_T(dy) * scale + add_src) * (mask_src > 0 ? 1 : 0.1), mask_src = x, add_src =
+ * the feature-matching gradient of x or NULL (train.py:257-262); dxh (nullable): dx as a bf16 activation image.  The
+ * separate activation-backward launch per layer goes away.) */
 int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
-                                  const float* mask_src, const float* add_src, float* dx, void* stream);
+                                  const float* mask_src, const float* add_src, float* dx, uint16_t* dxh, void* stream);
 /* (weight gradient: the blocks' partial sums go to `workspace` -- stegan_conv1d_bwd_weight_skinny_floats() floats at most
  * -- and a second launch adds them into dw / db in a fixed order: no float atomics, reproducible gradients; returns 1
  * when the workspace is missing or too small) */
@@ -551,7 +556,8 @@ int stegan_conv1d_fwd_skinny_multi(int32_t n, const stegan_conv_desc* const* des
                                    const float* const* w, const float* const* scale, const float* const* bias,
                                    float* const* y, void* stream);
 int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
-                                        const float* const* w, const float* const* scale, float* const* dx, void* stream);
+                                        const float* const* w, const float* const* scale, const float* const* mask_src,
+                                        const float* const* add_src, float* const* dx, uint16_t* const* dxh, void* stream);
 /* ... and their weight gradients: dw[i] += raw direction gradient, db[i] (array or entries may be NULL) += sum of dy[i]. */
 int stegan_conv1d_bwd_weight_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                           const float* const* dy, float* const* dw, float* const* db, float* workspace,

@@ -111,10 +111,10 @@ SIGNATURES = {
     "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
     "stegan_conv1d_fwd_skinny": [_P, _P, _P, _P, _P, _P, _P, _P],
-    "stegan_conv1d_bwd_data_skinny": [_P, _P, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_data_skinny": [_D, _P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_weight_skinny": [_D, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_fwd_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
-    "stegan_conv1d_bwd_data_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P],
+    "stegan_conv1d_bwd_data_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_weight_skinny_multi": [_I32, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_act_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],

@@ -260,16 +260,17 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // are stored [g][k][cb][m][8 channels], so the 64 lanes of a wave-instruction copy 1 KiB of CONTIGUOUS global memory
     const int CB = h.Cpad >> 3;
     int w_off[HW_MAX];            // byte offset inside the group's weights, without the chunk's channel-block term; -1: no piece
+    /* BRANCH-FREE on purpose (round 4).  The first form guarded every item with `if (it < h.wit)`: hipcc keeps w_off[] as  \
+       ONE 12-register tuple, so every guarded write became a phi of whole tuples -- ~300 v_mov copies of 12-register       \
+       groups and 72-144 spilled registers (scratch round trips) in front of the first DMA.  Items past the tile are never \
+       issued (HB_DMA_W2 counts), so their offsets may hold anything: computing all twelve costs ~100 VALU instructions. */ \
 #define HB_W_OFFSETS                                                                                            \
     _Pragma("unroll") for (int it = 0; it < HW_MAX; ++it) {                                                     \
-        w_off[it] = 0;                                                                                          \
-        if (it < h.wit) {                                    /* (items past the tile: not computed -- index setup is */ \
-            const int piece = it * 256 + tid;                /*  on the path to the first DMA)                      */ \
-            const int m = piece & (BM - 1), r = piece / BM;                                                     \
-            const int cb = r & (NCB - 1), tap = r >> LOGNCB;                                                    \
-            const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;        /* dead tap of an odd pair: the zero plane */ \
-            w_off[it] = tap < ntapsW ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      /* (unused pieces: whole waves, skipped) */ \
-        }                                                                                                       \
+        const int piece = it * 256 + tid;                                                                       \
+        const int m = piece & (BM - 1), r = piece / BM;                                                         \
+        const int cb = r & (NCB - 1), tap = r >> LOGNCB;                                                        \
+        const int k = tap < ntaps ? tp.kbase + tap * tp.kstep : p.K;        /* dead tap of an odd pair: the zero plane */ \
+        w_off[it] = tap < ntapsW ? ((k * CB + cb) * h.Mpad + m0 + m) * 16 : 0;      /* (unused pieces: whole waves, skipped) */ \
     }
     if (!cw0) { HB_W_OFFSETS }   // cw0: chunk 0's weights are the consumers' business; the offsets follow the first X DMAs
 #define HB_DMA_W(c_, buf_)                                                                                      \
@@ -324,20 +325,16 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             const int rowcb = vg(h.xh_cb), cb0 = vg(cbg0), tsrc = vg(p.Tsrc), npc = vg(npieces);
             const int upsh = vg(p.mode == 0 ? p.ups : 0);
 #pragma unroll
-            for (int it = 0; it < HXD_MAX; ++it) {
-                xd_cb[it] = -1;                                   // -1: lane switched off
-                xd_voff[it] = OOB;
-                if (it < h.xnit) {
-                    const unsigned piece = (unsigned)(it * 256 + tid);
-                    const unsigned cb = (__umulhi(piece, xr_mul) + piece) >> xr_sh, slot = piece - cb * xrow;
-                    const unsigned sg = (__umulhi(slot, sg_mul) + slot) >> sg_sh, sl = slot - sg * seg;
-                    const int b = blo + (int)sg;
-                    const int q = (sg == 0 ? q0 : qN) + (int)sl;
-                    const bool in = (int)piece < npc;
-                    const bool ok = in & ((int)sg < nseg) & (b < nb) & (q >= 0) & (q < tq);
-                    xd_cb[it] = in ? (int)cb : -1;
-                    xd_voff[it] = ok ? (unsigned)(((b * rowcb + cb0 + (int)cb) * tsrc + (q >> upsh)) * 16) : OOB;
-                }
+            for (int it = 0; it < HXD_MAX; ++it) {              // branch-free, as HB_W_OFFSETS: items past h.xnit are never issued
+                const unsigned piece = (unsigned)(it * 256 + tid);
+                const unsigned cb = (__umulhi(piece, xr_mul) + piece) >> xr_sh, slot = piece - cb * xrow;
+                const unsigned sg = (__umulhi(slot, sg_mul) + slot) >> sg_sh, sl = slot - sg * seg;
+                const int b = blo + (int)sg;
+                const int q = (sg == 0 ? q0 : qN) + (int)sl;
+                const bool in = (int)piece < npc;
+                const bool ok = in & ((int)sg < nseg) & (b < nb) & (q >= 0) & (q < tq);
+                xd_cb[it] = in ? (int)cb : -1;                  // -1: lane switched off
+                xd_voff[it] = ok ? (unsigned)(((b * rowcb + cb0 + (int)cb) * tsrc + (q >> upsh)) * 16) : OOB;
             }
         }
         const int chunk_x = NCB * p.Tsrc * 16;                    // bytes between the image planes of neighbouring chunks
@@ -684,6 +681,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     const float* const scalep = raw ? nullptr : p.scale;
     const float* const biasp = (raw || p.mode != 0) ? nullptr : p.bias;
     const int mode = p.mode, ups = p.ups, Cdst = p.Cdst, Tdst = p.Tdst, Tmask = p.Tmask, M_g = p.M_g;
+    const bool mlr = p.mask_lrelu != 0;                        // the mask is a leaky-ReLU output: factor AFTER scale and add
 #define HB_ACT16(v_)                                                                                            \
     if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
     else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = fmaxf(v_[e], 0.f); }      \
@@ -741,7 +739,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                     oidx[q] = (b * Cdst + ch) * Tdst + (mode == 0 ? u : phase + u);
                     midx[q] = (b * Cdst + ch) * Tmask + (u >> 1);
                 }
-                if (maskp) {
+                if (maskp && !mlr) {
                     if (ups == 0) {
                         f32x4 mk[4];
 #pragma unroll
@@ -765,6 +763,13 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] += rs[e >> 2][e & 3];
                 }
+                if (maskp && mlr) {                        // leaky-ReLU derivative of the layer before (host: ups == 0)
+                    f32x4 mk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] *= mk[e >> 2][e & 3] > 0.f ? 1.f : 0.1f;
+                }
                 HB_ACT16(v)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -781,7 +786,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                     const int b = (int)fd_div((uint32_t)nn, fdU), u = nn - b * U;
                     const int to = mode == 0 ? u : phase + u * os;
                     oi[e] = (b * Cdst + ch) * Tdst + to;
-                    if (maskp) {
+                    if (maskp && !mlr) {
                         const float xv = maskp[(b * Cdst + ch) * Tmask + (to >> ups)];
                         v[e] = xv > 0.f ? v[e] : 0.f;
                     }
@@ -792,6 +797,10 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                 if (resp) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] += resp[oi[e]];
+                }
+                if (maskp && mlr) {                        // (ups == 0, no (B, T, C) store: the mask sits at the output's index)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) v[e] *= maskp[oi[e]] > 0.f ? 1.f : 0.1f;
                 }
                 HB_ACT16(v)
 #pragma unroll
@@ -1436,11 +1445,14 @@ extern "C" int stegan_conv1d_bwd_data_hx(const stegan_conv_desc* d, const float*
     int rc = check_desc(d);
     if (rc) return rc;
     STEGAN_CHECK_ARG(dy && wbh && dx);
-    STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mask_src);
+    const bool lrelu_mask = d->in_act == STEGAN_ACT_LRELU;         // x is a leaky-ReLU output: its derivative rides here
+    STEGAN_CHECK_ARG((d->in_act != STEGAN_ACT_RELU && !lrelu_mask) || mask_src);
+    STEGAN_CHECK_ARG(!lrelu_mask || d->upsample == 1);
     HP h;
     DirP& p = h.d;
     p.src = dy; p.wt = nullptr; p.scale = scale; p.bias = nullptr; p.res = add_src; p.out = dx;
-    p.mask = d->in_act == STEGAN_ACT_RELU ? mask_src : nullptr;
+    p.mask = (d->in_act == STEGAN_ACT_RELU || lrelu_mask) ? mask_src : nullptr;
+    p.mask_lrelu = lrelu_mask ? 1 : 0;
     p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
     p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
     p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = 0; p.zero_off = 0;
@@ -1524,11 +1536,14 @@ extern "C" int stegan_conv1d_bwd_data_multi_hx(int32_t n, const stegan_conv_desc
         if (rc) return rc;
         STEGAN_CHECK_ARG(dy[i] && wbh[i] && dx[i]);
         const float* mk = mask_src ? mask_src[i] : nullptr;
-        STEGAN_CHECK_ARG(d->in_act != STEGAN_ACT_RELU || mk);
+        const bool lrelu_mask = d->in_act == STEGAN_ACT_LRELU;
+        STEGAN_CHECK_ARG((d->in_act != STEGAN_ACT_RELU && !lrelu_mask) || mk);
+        STEGAN_CHECK_ARG(!lrelu_mask || d->upsample == 1);
         HP h;
         DirP& p = h.d;
         p.src = dy[i]; p.wt = nullptr; p.scale = nullptr; p.bias = nullptr; p.res = add_src ? add_src[i] : nullptr; p.out = dx[i];
-        p.mask = d->in_act == STEGAN_ACT_RELU ? mk : nullptr;
+        p.mask = (d->in_act == STEGAN_ACT_RELU || lrelu_mask) ? mk : nullptr;
+        p.mask_lrelu = lrelu_mask ? 1 : 0;
         p.Csrc = d->Cout; p.Cdst = d->Cin; p.Tsrc = d->Tout; p.Tq = d->Tout; p.Tdst = d->Tin * d->upsample;
         p.Tmask = d->Tin; p.ups = d->upsample == 2 ? 1 : 0;
         p.C2_g = d->Cout / d->groups; p.M_g = d->Cin / d->groups; p.LD = 0; p.zero_off = 0;

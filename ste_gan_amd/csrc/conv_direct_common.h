@@ -23,7 +23,7 @@ struct DirP {
                           // are folded into wb by stegan_conv_prep)
     const float* bias;    // FWD
     const float* res;     // FWD residual / BWD add_src
-    const float* mask;    // BWD relu mask source (B, Cdst, Tmask)
+    const float* mask;    // BWD relu mask source (B, Cdst, Tmask); with mask_lrelu: the leaky-ReLU OUTPUT the gradient passes
     float* out;
     int B, Csrc, Cdst, Tsrc, Tq;        // Tq = valid source extent in q units (FWD: Tin*up, BWD: Tout)
     int Tdst;                           // stored output length per (b, channel)  (FWD: Tout, BWD: Te)
@@ -58,6 +58,10 @@ struct DirP {
     // kernels stage by LDS-DMA); null = not wanted.  Written beside the fp32 output by the fused epilogues.
     unsigned short* out_h = nullptr;
     int out_cb = 0;
+    // round 4: BWD with in_act == STEGAN_ACT_LRELU -- the conv's input is the leaky-ReLU(0.1) output of the layer before it, and
+    // this launch also applies THAT layer's activation derivative: dx = (acc * scale + res) * (mask > 0 ? 1 : 0.1), `res`
+    // being the feature-matching gradient of the same tensor.  (The separate act_bwd launch per layer goes away.)
+    int mask_lrelu = 0;
 };
 
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
@@ -77,13 +81,16 @@ __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, in
         else p.out[idx] = v;
         if (p.out_h) p.out_h[(((size_t)b * p.out_cb + (ch >> 3)) * p.Tdst + to) * 8 + (ch & 7)] = f32_to_bf16_bits(v);
     } else {
+        float lr = 1.f;
         if (p.mask) {
             const float xv = p.mask[((size_t)b * p.Cdst + ch) * p.Tmask + (to >> p.ups)];
-            if (!(xv > 0.f)) v = 0.f;
+            if (p.mask_lrelu) lr = xv > 0.f ? 1.f : 0.1f;
+            else if (!(xv > 0.f)) v = 0.f;
         }
         if (p.scale) v *= p.scale[0];
         const size_t idx = ((size_t)b * p.Cdst + ch) * p.Tdst + to;
         if (p.res) v += p.res[idx];
+        v *= lr;
         p.out[idx] = v;
         if (p.out_h) p.out_h[(((size_t)b * p.out_cb + (ch >> 3)) * p.Tdst + to) * 8 + (ch & 7)] = f32_to_bf16_bits(v);
     }

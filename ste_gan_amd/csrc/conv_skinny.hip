@@ -29,6 +29,12 @@ struct SkP {
     int per;              // weight gradient: batch rows per block
     int nqt;              // weight gradient: time tiles per batch slice (slab index = slice * nqt + time tile)
     float* part;          // weight gradient: slabs [slices * nqt][Cin * K], then [slices] bias sums
+    // input gradient (round 4): x is the leaky-ReLU output of the layer before -- dx = (conv_T(dy) * scale + add) * lrelu'(mask)
+    // applies that layer's activation derivative here (`add`: the feature-matching gradient of x, may be null), and the
+    // result also goes out as a bf16 activation image [B][Cin / 8][Tin][8] for the layer's own backward kernels
+    const float* mask;
+    const float* add;
+    unsigned short* out_h;
     FastDiv fdTT, fdS, fdTin, fdCT, fdCL;
 };
 
@@ -132,7 +138,13 @@ __device__ __forceinline__ void conv_cout1_bwd_data_body(const SkP& p, long n, i
             if (t * p.stride != a || t >= p.Tout) continue;
             s += wc[k] * dyb[t];
         }
-        p.out[e] = s * sc;
+        float v = s * sc;
+        if (p.mask) {
+            if (p.add) v += p.add[e];
+            v *= p.mask[e] > 0.f ? 1.f : 0.1f;
+        }
+        p.out[e] = v;
+        if (p.out_h) img_store(p.out_h, p.Cin >> 3, p.Tin, (int)b, (int)ci, q, v);
     }
 }
 
@@ -246,9 +258,10 @@ __global__ __launch_bounds__(256) void conv_cout1_wgrad_multi_kernel(const SkMul
 }
 
 // Cout == 1, ungrouped, no upsample / input activation / residual / (B, T, C) output: everything else returns 1
-int fill(const stegan_conv_desc* d, SkP& p) {
+int fill(const stegan_conv_desc* d, SkP& p, bool lrelu_mask_ok = false) {
     if (!d) return STEGAN_E_ARG;
-    if (d->Cout != 1 || d->groups != 1 || d->upsample != 1 || d->in_act != STEGAN_ACT_NONE || d->out_btc) return 1;
+    if (d->Cout != 1 || d->groups != 1 || d->upsample != 1 || d->out_btc) return 1;
+    if (d->in_act != STEGAN_ACT_NONE && !(lrelu_mask_ok && d->in_act == STEGAN_ACT_LRELU)) return 1;
     if (d->K < 1 || d->K > SK_KMAX || d->B <= 0 || d->Cin <= 0 || d->Tin <= 0 || d->Tout <= 0 || d->stride < 1 ||
         d->dilation < 1 || d->pad < 0)
         return 1;
@@ -262,6 +275,8 @@ int fill(const stegan_conv_desc* d, SkP& p) {
     p.fdCT = make_fastdiv((uint32_t)(d->Cin * d->Tin));
     p.TT = p.CL = p.per = p.nqt = 1;
     p.part = nullptr;
+    p.mask = p.add = nullptr;
+    p.out_h = nullptr;
     p.fdTT = make_fastdiv(1); p.fdCL = make_fastdiv(1);
     p.x = p.w = p.dy = p.scale = p.bias = nullptr;
     p.out = nullptr;
@@ -322,8 +337,9 @@ extern "C" int stegan_conv1d_fwd_skinny_multi(int32_t n, const stegan_conv_desc*
 }
 
 extern "C" int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_desc* const* descs, const float* const* dy,
-                                                   const float* const* w, const float* const* scale, float* const* dx,
-                                                   void* stream) {
+                                                   const float* const* w, const float* const* scale,
+                                                   const float* const* mask_src, const float* const* add_src,
+                                                   float* const* dx, uint16_t* const* dxh, void* stream) {
     STEGAN_CHECK_ARG(n >= 1 && descs && dy && w && dx);
     if (n > SK_MULTI) return 1;
     SkMulti a;
@@ -331,10 +347,16 @@ extern "C" int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_
     long blocks = 1;
     for (int i = 0; i < n; ++i) {
         SkP& p = a.p[i];
-        int rc = fill(descs[i], p);
+        int rc = fill(descs[i], p, true);
         if (rc) return rc;
         STEGAN_CHECK_ARG(dy[i] && w[i] && dx[i]);
         p.dy = dy[i]; p.w = w[i]; p.scale = scale ? scale[i] : nullptr; p.out = dx[i];
+        const bool lm = descs[i]->in_act == STEGAN_ACT_LRELU;
+        STEGAN_CHECK_ARG(!lm || (mask_src && mask_src[i]));
+        p.mask = lm ? mask_src[i] : nullptr;
+        p.add = (lm && add_src) ? add_src[i] : nullptr;
+        if (!lm && add_src && add_src[i]) return 1;           // a plain add without the mask: not this kernel's case
+        p.out_h = (dxh && descs[i]->Cin % 8 == 0) ? dxh[i] : nullptr;
         a.ne[i] = (long)descs[i]->B * descs[i]->Cin * descs[i]->Tin;
         const long b = (a.ne[i] + 255) / 256;
         if (b > blocks) blocks = b;
@@ -347,13 +369,17 @@ extern "C" int stegan_conv1d_bwd_data_skinny_multi(int32_t n, const stegan_conv_
 }
 
 extern "C" int stegan_conv1d_bwd_data_skinny(const stegan_conv_desc* d, const float* dy, const float* w, const float* scale,
-                                             const float* mask_src, const float* add_src, float* dx, void* stream) {
+                                             const float* mask_src, const float* add_src, float* dx, uint16_t* dxh,
+                                             void* stream) {
     SkP p;
-    int rc = fill(d, p);
+    int rc = fill(d, p, true);
     if (rc) return rc;
-    if (mask_src || add_src) return 1;
-    STEGAN_CHECK_ARG(dy && w && dx);
+    const bool lm = d->in_act == STEGAN_ACT_LRELU;
+    if (!lm && (mask_src || add_src)) return 1;
+    STEGAN_CHECK_ARG(dy && w && dx && (!lm || mask_src));
     p.dy = dy; p.w = w; p.scale = scale; p.out = dx;
+    p.mask = lm ? mask_src : nullptr; p.add = lm ? add_src : nullptr;
+    p.out_h = (dxh && d->Cin % 8 == 0) ? dxh : nullptr;
     const long n = (long)d->B * d->Cin * d->Tin;
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;

@@ -164,9 +164,9 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
 #pragma unroll
         for (int it = 0; it < WDI; ++it) {
             const int ii = it * 4 + wave;
-            a_seg[it] = 0; a_uu[it] = 0; a_ldsb[it] = -1; a_lane[it] = -1;
-            x_seg[it] = 0; x_sl[it] = 0; x_ldsb[it] = -1; x_lane[it] = -1;
-            if (ii < nA) {
+            // (branch-free: items past nA / nX are never issued -- WG_NEST counts -- so their fields may hold anything; guarded
+            // writes into these register arrays turn into whole-tuple copies, see conv_bf16.hip HB_W_OFFSETS)
+            {
                 const int piece = ii * 64 + lane;
                 const int cg = (int)fd_div((uint32_t)piece, h.fdRSA), slot = piece - cg * h.RSA;
                 const int seg = (int)fd_div((uint32_t)slot, h.fdRUp), uu = slot - seg * h.RUp;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 a_lane[it] = (cg < CBA && slot < h.R && cg < ylive && seg < h.NB && uu < h.RU)
                                  ? ((seg * CBy + ((g * h.Cout_g + co0) >> 3) + cg) * h.Tout + uu) * 16 : -2;
             }
-            if (ii < nX) {
+            {
                 const int piece = ii * 64 + lane;
                 const int cg = (int)fd_div((uint32_t)piece, h.fdRSX), slot = piece - cg * h.RSX;
                 const int seg = (int)fd_div((uint32_t)slot, h.fdSEG), sl = slot - seg * h.SEG;

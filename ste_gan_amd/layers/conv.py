@@ -75,11 +75,12 @@ class WNConv1d(nn.Module):
             self._prep = (stamp, (scale, bufs[0], bufs[1]))
         return self._prep[1]
 
-    def forward(self, x, residual=None, hand=None):
+    def forward(self, x, residual=None, hand=None, fuse=None):
+        """``fuse`` = (ops.ActFuse of x's producer | None, ops.ActFuse of this layer's output activation | None)."""
         sink = None
         if self._pack is not None and torch.is_grad_enabled() and self.weight_v.requires_grad:
             sink = (self._pack[4], self.bias.grad)          # raw dw slice, bias-gradient view
-        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared(), sink, hand)
+        return ops.wn_conv1d(x, self.weight_v, self.weight_g, self.bias, residual, self.cfg, self.prepared(), sink, hand, fuse)
 
     def extra_repr(self):
         return str(self.cfg)
@@ -176,15 +177,15 @@ class SNConv1d(nn.Module):
                                                   self._prep[1][0].device == w.device else None))
         return self._prep[1]
 
-    def forward(self, x, pre=None):
+    def forward(self, x, pre=None, fuse=None):
         """``pre``: this forward's spectral-norm state from :func:`ops.spectral_norm_multi` (all layers of the
-        discriminator in one call); None: the layer runs its own power iteration."""
+        discriminator in one call); None: the layer runs its own power iteration.  ``fuse``: see WNConv1d.forward."""
         sink = None
         w, b = self.weight_orig, self.bias
         if (self.grad_sink and torch.is_grad_enabled() and w.requires_grad and b.requires_grad and w.grad is not None
                 and b.grad is not None and w.grad.is_contiguous() and w.grad.is_cuda):
             sink = (w.grad, b.grad)              # FlatParams arena views (optim.FlatParams sets ``grad_sink``)
-        return ops.sn_conv1d(x, w, self.weight_u, self.weight_v, b, self.cfg, self.training, self.prepared(), pre, sink)
+        return ops.sn_conv1d(x, w, self.weight_u, self.weight_v, b, self.cfg, self.training, self.prepared(), pre, sink, fuse)
 
 
 def NormedConv1d(*args, **kwargs):

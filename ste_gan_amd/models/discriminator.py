@@ -30,10 +30,13 @@ class _PeriodDisc(nn.Module):
         B = x_btc.shape[0]
         x = ops.mpd_fold(x_btc, self.period)
         fmaps = []
+        prev = None                            # ops.ActFuse chain: layer L + 1's backward applies layer L's lrelu'
         for layer in self.layers:
-            x = layer(x)                       # conv + leaky_relu(0.1) fused
+            cur = ops.new_act_fuse()
+            x = layer(x, fuse=(prev, cur))     # conv + leaky_relu(0.1) fused
+            prev = cur
             fmaps.append(_unfold_view(x, B, self.period))
-        fmaps.append(_unfold_view(self.output(x), B, self.period))
+        fmaps.append(_unfold_view(self.output(x, fuse=(prev, None)), B, self.period))
         return fmaps
 
 
@@ -85,10 +88,15 @@ class _ScaleDisc(nn.Module):
         x = x_bct
         if pre is None:
             pre = self.sn_prepare() or [None] * len(self.layers)
+        # every feature map feeds exactly one conv (the feature-matching term's gradient is added inside the backward
+        # kernels): the conv behind it applies the leaky-ReLU derivative in its input-gradient epilogue (ops.ActFuse)
+        prev = None
         for layer, pr in zip(self.layers, pre):
-            x = layer(x) if pr is None else layer(x, pr)
+            cur = ops.new_act_fuse()
+            x = layer(x, fuse=(prev, cur)) if pr is None else layer(x, pr, fuse=(prev, cur))
+            prev = cur
             fmaps.append(x)
-        fmaps.append(self.output(x))
+        fmaps.append(self.output(x, fuse=(prev, None)))
         return fmaps
 
 
@@ -261,9 +269,12 @@ class _MultiDisc(nn.Module):
         hs = ops.mpd_fold_multi(x, [d.period for d in discs])
         fmaps = [[] for _ in discs]
         depth = len(discs[0].layers) + 1
+        prev = None
         for L in range(depth):
             convs = [d.layers[L] if L < depth - 1 else d.output for d in discs]
-            hs = ops.wn_conv1d_multi(hs, convs)
+            cur = ops.new_act_fuse() if L < depth - 1 else None
+            hs = ops.wn_conv1d_multi(hs, convs, fuse=(prev, cur))
+            prev = cur
             for f, h, d in zip(fmaps, hs, discs):
                 f.append(_unfold_view(h, B, d.period))
         return fmaps

@@ -86,6 +86,9 @@ class ConvProfiler:
             self.kernel_timestamps = False
 
     def plan(self, d: ConvDesc, mode: int):
+        if d.in_act == ACT_LRELU:              # (input gradient that also applies the producer's lrelu': same work, plain desc)
+            d = ConvDesc(*[getattr(d, f) for f, _ in ConvDesc._fields_])
+            d.in_act = ACT_NONE
         tile, splits, live = C.c_int32(), C.c_int32(), C.c_int64()
         check(_lib.lib().stegan_conv1d_plan(C.byref(d), mode, C.byref(tile), C.byref(splits), C.byref(live)),
               "stegan_conv1d_plan")
@@ -487,21 +490,49 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
     return y
 
 
+class ActFuse:
+    """Link between a conv whose output goes through leaky_relu (the producer) and the conv that reads that output (the
+    consumer): in the backward pass the CONSUMER's input-gradient launch applies the producer's activation derivative --
+    and adds the feature-matching gradient of the tensor in front of it -- in its epilogue (conv1d_bwd_data(act_src=...)),
+    sets ``done``, and the producer skips its own activation-backward launch.  Set up by the model that knows the
+    topology (the discriminator stacks: every feature map has exactly one conv behind it), like GradHandover."""
+    __slots__ = ("done",)
+
+    def __init__(self):
+        self.done = False
+
+
 def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Optional[Tensor],
                     add_src: Optional[Tensor], cfg: ConvCfg, tin: int, wb: Optional[Tensor] = None,
-                    uniform_scale: bool = False) -> Tensor:
+                    uniform_scale: bool = False, act_src: Optional[Tensor] = None,
+                    act_add: Optional[Tensor] = None) -> Tensor:
     """``wb`` (from prep_weights WITH the per-channel scale folded in) selects the direct kernel; ``uniform_scale``
-    says that ``scale`` holds one value repeated (spectral norm) and was NOT folded into wb."""
+    says that ``scale`` holds one value repeated (spectral norm) and was NOT folded into wb.
+    ``act_src`` (round 4): the conv's input x, which is the leaky_relu(0.1) OUTPUT of the layer before: the result is then
+    that layer's PRE-activation gradient, (conv_T(dy) + act_add) * lrelu'(act_src), formed in the kernel's epilogue
+    (``act_add``: the feature-matching gradient of x or None); kernels without that epilogue are followed by act_bwd."""
     dy = _gpu_f32(dy, "dy")
     B, _, tout = dy.shape
     dx = torch.empty((B, cfg.cin, tin * cfg.upsample), device=dy.device, dtype=torch.float32)
     d = _desc(cfg, B, tin, tout)
+    fuse = act_src is not None
+    if fuse:
+        if mask_src is not None or add_src is not None or cfg.upsample != 1 or cfg.in_act != ACT_NONE:
+            raise RuntimeError("ste_gan_amd.conv1d_bwd_data: act_src excludes mask_src / add_src / upsample / in_act")
+        if act_src.shape != dx.shape or (act_add is not None and act_add.numel() != dx.numel()):
+            raise RuntimeError("ste_gan_amd.conv1d_bwd_data: act_src / act_add do not match the input gradient")
+        dl = _desc(replace(cfg, in_act=ACT_LRELU), B, tin, tout)
+        mk, ad = act_src, act_add
+    else:
+        dl, mk, ad = d, mask_src, add_src
     if cfg.cout == 1 and SKINNY:
-        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_skinny(C.byref(d), _p(dy), _p(_gpu_f32(w, "weight")),
-                                                                           _p(scale), _p(mask_src), _p(add_src), _p(dx),
-                                                                           _stream()), "skinny")
+        dxh = _new_image(dx, cfg.cin, cfg.groups, tin) if fuse else None
+        rc = _timed(dl, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_skinny(C.byref(dl), _p(dy), _p(_gpu_f32(w, "weight")),
+                                                                            _p(scale), _p(mk), _p(ad), _p(dx), _p(dxh),
+                                                                            _stream()), "skinny")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_skinny")
+            _attach_image(dx, dxh)
             return dx
     wbh = _bf16_of(wb)
     if wbh is not None:
@@ -511,9 +542,9 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
         if IMG_STATS is not None:
             IMG_STATS.setdefault((1, dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
         dxh = _new_image(dx, cfg.cin, cfg.groups, tin * cfg.upsample) if cfg.upsample == 1 else None
-        rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_hx(C.byref(d), _p(dy), _p(dyh), _p(wbh), _p(us),
-                                                                       _p(mask_src), _p(add_src), _p(dx), _p(dxh), _p(ws),
-                                                                       ws.numel(), _stream()),
+        rc = _timed(dl, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_hx(C.byref(dl), _p(dy), _p(dyh), _p(wbh), _p(us),
+                                                                        _p(mk), _p(ad), _p(dx), _p(dxh), _p(ws),
+                                                                        ws.numel(), _stream()),
                     "bf16")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_hx")
@@ -527,11 +558,11 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
                     "direct")
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_t")
-            return dx
+            return act_bwd(dx, act_src, ACT_LRELU, act_add) if fuse else dx
     check(_timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data(C.byref(d), _p(dy), _p(w), _p(scale), _p(mask_src),
                                                                  _p(add_src), _p(dx), _stream())),
           "stegan_conv1d_bwd_data")
-    return dx
+    return act_bwd(dx, act_src, ACT_LRELU, act_add) if fuse else dx
 
 
 class WgradReduce(C.Structure):       # mirrors struct stegan_wgrad_reduce
@@ -748,9 +779,11 @@ class _WNConvFn(torch.autograd.Function):
     ``hand`` = (PARK_DX | PARK_RES | TAKE, GradHandover) or None: see the gradient hand-over above."""
 
     @staticmethod
-    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None):
+    def forward(ctx, x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None, fuse=None):
+        """``fuse`` = (ActFuse of the layer that produced x or None, ActFuse of this layer's own output activation or None)"""
         ctx.sink = sink
         ctx.hand = hand
+        ctx.fuse_in, ctx.fuse_out = fuse if fuse is not None else (None, None)
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         if prepared is None:
             scale, wf, wb = wn_scale(v, g), None, None
@@ -775,8 +808,9 @@ class _WNConvFn(torch.autograd.Function):
             dy = dy.transpose(1, 2).contiguous()
             if y is not None:
                 y = y.transpose(1, 2).contiguous()
-        if cfg.out_act != ACT_NONE:
+        if cfg.out_act != ACT_NONE and not (ctx.fuse_out is not None and ctx.fuse_out.done):
             dy = act_bwd(dy, y, cfg.out_act, None if cfg.out_btc else _fm_take(y))
+        # (fuse_out.done: the consumer of y applied this layer's activation derivative in its input-gradient epilogue)
         w3 = v.reshape(v.shape[0], v.shape[1], -1)
         dx = dv = dg = db = dres = None
         role, hand = ctx.hand if ctx.hand is not None else (0, None)
@@ -788,7 +822,11 @@ class _WNConvFn(torch.autograd.Function):
                 if add is not None and (add.shape[0] != x.shape[0] or add.shape[1] != cfg.cin
                                         or add.shape[2] != x.shape[2] * cfg.upsample or not add.is_contiguous()):
                     raise RuntimeError("ste_gan_amd: parked gradient does not match the taker's input gradient")
-            dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, add, cfg, x.shape[2], ctx.wb)
+            if ctx.fuse_in is not None and ACT_FUSE and add is None and cfg.in_act == ACT_NONE and cfg.upsample == 1:
+                dxe = conv1d_bwd_data(dy, w3, scale, None, None, cfg, x.shape[2], ctx.wb, act_src=x, act_add=_fm_take(x))
+                ctx.fuse_in.done = True
+            else:
+                dxe = conv1d_bwd_data(dy, w3, scale, x if cfg.in_act == ACT_RELU else None, add, cfg, x.shape[2], ctx.wb)
             if role == PARK_DX and not hand.taken:
                 hand.parked = dxe                    # at the upsampled resolution: the taker folds the sum once
             else:
@@ -813,7 +851,34 @@ class _WNConvFn(torch.autograd.Function):
                 hand.parked = dy
             else:
                 dres = dy
-        return dx, dv, dg, db, dres, None, None, None, None
+        return dx, dv, dg, db, dres, None, None, None, None, None
+
+
+ACT_FUSE = os.environ.get("STEGAN_ACT_FUSE", "1") != "0"      # the consumer's input-gradient epilogue applies lrelu' (ActFuse)
+_ACT_FUSE_SCOPE = [0]
+
+
+class act_fuse_scope:
+    """Inside this scope the discriminators link their layers with ActFuse objects.  ONLY valid when no gradient reaches a
+    feature map through autograd except from the conv behind it -- the train step's discriminator passes: the D step uses
+    the logits alone, the generator step's feature-matching gradients are parked for the backward kernels (fm_fold_begin),
+    never returned to autograd.  A caller that differentiates a loss of the feature maps through autograd (the API allows
+    it, tests/test_gpu_discriminator.py does) must NOT be in this scope: the producer would skip its activation derivative
+    for that second gradient."""
+
+    def __enter__(self):
+        _ACT_FUSE_SCOPE[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _ACT_FUSE_SCOPE[0] -= 1
+        return False
+
+
+def new_act_fuse() -> Optional["ActFuse"]:
+    """An ActFuse link inside an act_fuse_scope (and with gradients on), else None: the layers then apply their own
+    activation derivatives, as autograd's general contract needs."""
+    return ActFuse() if (ACT_FUSE and _ACT_FUSE_SCOPE[0] > 0 and torch.is_grad_enabled()) else None
 
 
 def _ptr_array(items):
@@ -863,22 +928,32 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases, raws=None):
     return ys
 
 
-def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
+def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None, act_srcs=None, act_adds=None):
+    """``act_srcs`` / ``act_adds``: see conv1d_bwd_data (every problem's input is the leaky-ReLU output of the layer before)."""
     n = len(dys)
     dys = [_gpu_f32(t, "dy") for t in dys]
+    fuse = act_srcs is not None
     dxs, descs = [], []
     for dy, cfg, tin in zip(dys, cfgs, tins):
         B, _, tout = dy.shape
         dxs.append(torch.empty((B, cfg.cin, tin), device=dy.device, dtype=torch.float32))
-        descs.append(_desc(cfg, B, tin, tout))
+        descs.append(_desc(replace(cfg, in_act=ACT_LRELU) if fuse else cfg, B, tin, tout))
     dptr = (C.c_void_p * n)(*[C.cast(C.pointer(d), C.c_void_p) for d in descs])
+    masks = _ptr_array(act_srcs) if fuse else None
+    adds = _ptr_array(act_adds) if (fuse and act_adds is not None and any(a is not None for a in act_adds)) else None
     if SKINNY and raws is not None and all(c.cout == 1 for c in cfgs):
+        dxhs = [_new_image(t, c.cin, c.groups, t.shape[2]) for t, c in zip(dxs, cfgs)] if fuse else None
         rc = _lib.lib().stegan_conv1d_bwd_data_skinny_multi(n, dptr, _ptr_array(dys),
                                                             _ptr_array([_gpu_f32(w, "weight") for w in raws]),
-                                                            _ptr_array(scales) if scales is not None else None,
-                                                            _ptr_array(dxs), _stream())
+                                                            _ptr_array(scales) if scales is not None else None, masks, adds,
+                                                            _ptr_array(dxs),
+                                                            _ptr_array(dxhs) if dxhs and any(h is not None for h in dxhs) else None,
+                                                            _stream())
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_skinny_multi")
+            if dxhs:
+                for t, th in zip(dxs, dxhs):
+                    _attach_image(t, th)
             return dxs
     whs = [_bf16_of(w) for w in wbs]
     if all(w is not None for w in whs):
@@ -886,7 +961,7 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
         dxhs = [_new_image(t, c.cin, c.groups, t.shape[2]) for t, c in zip(dxs, cfgs)]
         rc = _lib.lib().stegan_conv1d_bwd_data_multi_hx(n, dptr, _ptr_array(dys),
                                                         _ptr_array(dyhs) if all(h is not None for h in dyhs) else None,
-                                                        _ptr_array(whs), None, None, _ptr_array(dxs),
+                                                        _ptr_array(whs), masks, adds, _ptr_array(dxs),
                                                         _ptr_array(dxhs) if any(h is not None for h in dxhs) else None, _stream())
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_data_multi_hx")
@@ -894,7 +969,7 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None):
                 _attach_image(t, th)
             return dxs
         return None
-    if COMPUTE_DTYPE == "bf16":
+    if COMPUTE_DTYPE == "bf16" or fuse:
         return None
     rc = _lib.lib().stegan_conv1d_bwd_data_multi(n, dptr, _ptr_array(dys), _ptr_array(wbs), None, None, _ptr_array(dxs),
                                                  _stream())
@@ -910,7 +985,10 @@ class _WNConvMultiFn(torch.autograd.Function):
     variant across them, per-problem launches otherwise.  ``layers`` = [(v, g, bias, cfg, (scale, wf, wb), sink)]."""
 
     @staticmethod
-    def forward(ctx, layers, n, *ts):
+    def forward(ctx, layers, n, fuse, *ts):
+        """``fuse`` = (ActFuse of the layer that produced the inputs | None, ActFuse of this layer's output activation | None):
+        one object for all problems (they run as one node)."""
+        ctx.fuse_in, ctx.fuse_out = fuse if fuse is not None else (None, None)
         xs = ts[:n]
         cfgs = [l[3] for l in layers]
         ys = None
@@ -921,7 +999,7 @@ class _WNConvMultiFn(torch.autograd.Function):
             ys = [conv1d_fwd(x, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], l[2], None, l[3], l[4][1])
                   for x, l in zip(xs, layers)]
         ctx.layers, ctx.n = layers, n
-        ctx.wgrad = any(ctx.needs_input_grad[2 + n:])
+        ctx.wgrad = any(ctx.needs_input_grad[3 + n:])
         ctx.save_for_backward(*xs, *ys)
         for y, c in zip(ys, cfgs):
             if not c.out_btc:
@@ -935,7 +1013,9 @@ class _WNConvMultiFn(torch.autograd.Function):
         xs, ys = saved[:n], saved[n:]
         gs = [_gpu_f32(dy, "grad_output") for dy in dys]
         acts = {l[3].out_act for l in layers}
-        if ACT_MULTI and len(acts) == 1 and ACT_NONE not in acts and n <= 8 and not any(l[3].out_btc for l in layers) \
+        if ctx.fuse_out is not None and ctx.fuse_out.done:
+            pass         # the consumer layer applied this layer's activation derivative in its input-gradient epilogue
+        elif ACT_MULTI and len(acts) == 1 and ACT_NONE not in acts and n <= 8 and not any(l[3].out_btc for l in layers) \
                 and all(g.is_contiguous() for g in gs):
             # the activation backward of all problems (folded feature-matching gradients included) in one launch
             adds = [_fm_take(y) for y in ys]
@@ -975,42 +1055,49 @@ class _WNConvMultiFn(torch.autograd.Function):
                     if l[5] is not None:
                         conv1d_bwd_weight(x, g, l[3], l[5][0], l[5][1] if l[2] is not None else None, defer=True)
         dxs = [None] * n
-        need = [ctx.needs_input_grad[2 + i] for i in range(n)]
+        need = [ctx.needs_input_grad[3 + i] for i in range(n)]
         if any(need):
             cfgs = [l[3] for l in layers]
             out = None
+            fuse = ctx.fuse_in is not None and ACT_FUSE and all(need) and all(c.in_act == ACT_NONE and c.upsample == 1 for c in cfgs)
+            srcs = list(xs) if fuse else None
+            adds = [_fm_take(x) for x in xs] if fuse else None
             if PROFILER is None and all(need):
                 out = conv1d_bwd_data_multi(gs, cfgs, [l[4][2] for l in layers], [x.shape[2] for x in xs],
                                             [l[0].reshape(l[0].shape[0], l[0].shape[1], -1) for l in layers],
-                                            [l[4][0] for l in layers])
+                                            [l[4][0] for l in layers], srcs, adds)
             if out is None:
                 out = [conv1d_bwd_data(g, l[0].reshape(l[0].shape[0], l[0].shape[1], -1), l[4][0], None, None, l[3],
-                                       x.shape[2], l[4][2]) if nd else None for g, x, l, nd in zip(gs, xs, layers, need)]
+                                       x.shape[2], l[4][2], act_src=(x if fuse else None), act_add=(adds[i] if fuse else None))
+                       if nd else None for i, (g, x, l, nd) in enumerate(zip(gs, xs, layers, need))]
+            if fuse:
+                ctx.fuse_in.done = True
             dxs = out
-        return (None, None, *dxs, *([None] * (len(ctx.needs_input_grad) - 2 - n)))
+        return (None, None, None, *dxs, *([None] * (len(ctx.needs_input_grad) - 3 - n)))
 
 
-def wn_conv1d_multi(xs, convs):
+def wn_conv1d_multi(xs, convs, fuse=None):
     """convs: one WNConv1d per input (same layer of several sub-discriminators).  Falls back to per-module calls when a
-    conv needs weight gradients but has no gradient sink."""
+    conv needs weight gradients but has no gradient sink.  ``fuse``: see _WNConvMultiFn.forward."""
     grad = torch.is_grad_enabled()
     needs_w = grad and any(c.weight_v.requires_grad for c in convs)
     # the multi node's backward passes no ReLU mask and no residual: only plain convs (in_act NONE) take this path
     if any(c.cfg.in_act != ACT_NONE for c in convs) or (needs_w and any(c._pack is None for c in convs)):
-        return [c(x) for c, x in zip(convs, xs)]
+        return [c(x, fuse=fuse) for c, x in zip(convs, xs)]         # (one ActFuse object shared by the problems)
     layers, params = [], []
     for c in convs:
         sink = (c._pack[4], c.bias.grad) if (needs_w and c._pack is not None) else None
         layers.append((c.weight_v, c.weight_g, c.bias, c.cfg, c.prepared(), sink))
         params += [c.weight_v, c.weight_g, c.bias]
-    return list(_WNConvMultiFn.apply(layers, len(xs), *xs, *params))
+    return list(_WNConvMultiFn.apply(layers, len(xs), fuse, *xs, *params))
 
 
-def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None) -> Tensor:
+def wn_conv1d(x, v, g, bias, residual, cfg: ConvCfg, prepared=None, sink=None, hand=None, fuse=None) -> Tensor:
     """prepared = (scale, wf, wb) of the CURRENT weights (see layers.conv.WNConv1d.prepared) or None;
     sink = (raw dw arena slice, bias-gradient view) switches the backward to fused accumulation (optim.ConvPack);
-    hand = (role, GradHandover): this conv's part in a gradient hand-over (GBlock)."""
-    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink, hand)
+    hand = (role, GradHandover): this conv's part in a gradient hand-over (GBlock);
+    fuse = (ActFuse of x's producer | None, ActFuse of this conv's output activation | None)."""
+    return _WNConvFn.apply(x, v, g, bias, residual, cfg, prepared, sink, hand, fuse)
 
 
 def act_bwd(dy: Tensor, y: Tensor, act: int, add: Optional[Tensor] = None) -> Tensor:
@@ -1102,10 +1189,11 @@ class _SNConvFn(torch.autograd.Function):
     """y = out_act( (w_orig (*) x) / sigma + bias ), sigma = u^T W v after one in-place power iteration."""
 
     @staticmethod
-    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None):
+    def forward(ctx, x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None, fuse=None):
         """``sink`` = (weight_orig.grad, bias.grad) arena views: the backward pass accumulates into them directly and
-        returns no parameter gradients (as the ConvPack sink of the weight-norm convs does)."""
+        returns no parameter gradients (as the ConvPack sink of the weight-norm convs does); ``fuse``: see _WNConvFn."""
         ctx.sink = sink
+        ctx.fuse_in, ctx.fuse_out = fuse if fuse is not None else (None, None)
         wf, wb = prepared if prepared is not None else (None, None)
         need_w = ctx.needs_input_grad[1]
         if pre is not None:
@@ -1140,11 +1228,16 @@ class _SNConvFn(torch.autograd.Function):
         cfg: ConvCfg = ctx.cfg
         x, w_orig, u, v, scale, sigma, y = ctx.saved_tensors
         dy = _gpu_f32(dy, "grad_output")
-        if cfg.out_act != ACT_NONE:
+        if cfg.out_act != ACT_NONE and not (ctx.fuse_out is not None and ctx.fuse_out.done):
             dy = act_bwd(dy, y, cfg.out_act, _fm_take(y))
         dx = dw_orig = db = None
         if ctx.needs_input_grad[0]:
-            dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True)
+            if ctx.fuse_in is not None and ACT_FUSE and cfg.upsample == 1:
+                dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True,
+                                     act_src=x, act_add=_fm_take(x))
+                ctx.fuse_in.done = True
+            else:
+                dx = conv1d_bwd_data(dy, w_orig, scale, None, None, cfg, x.shape[2], ctx.wb, uniform_scale=True)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[4]:
             sink = ctx.sink
             if sink is not None:
@@ -1160,11 +1253,11 @@ class _SNConvFn(torch.autograd.Function):
                   "stegan_spectral_norm_bwd_acc")
             if sink is not None:
                 dw_orig = db = None              # already in the gradient arena
-        return dx, dw_orig, None, None, db, None, None, None, None, None
+        return dx, dw_orig, None, None, db, None, None, None, None, None, None
 
 
-def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None) -> Tensor:
-    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre, sink)
+def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None, fuse=None) -> Tensor:
+    return _SNConvFn.apply(x, w_orig, u, v, bias, cfg, training, prepared, pre, sink, fuse)
 
 
 SKINNY = os.environ.get("STEGAN_SKINNY", "1") != "0"   # Cout == 1 convs on the streaming kernels of conv_skinny.hip

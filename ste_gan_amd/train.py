@@ -259,7 +259,8 @@ class GANTrainStep:
         if t.loss_adversarial:
             if hasattr(netD, "forward_pair_logits"):
                 # train.py:190-196 on the concatenated batch: fake | real logits against zeros | ones, unsliced, one launch
-                loss_D = lsgan_pair_loss(netD.forward_pair_logits(x_pred_t.detach(), x_t), 0.0, 1.0, unit_grad=True)
+                with ops.act_fuse_scope():       # only the logits carry gradient: the layers may chain their lrelu'
+                    loss_D = lsgan_pair_loss(netD.forward_pair_logits(x_pred_t.detach(), x_t), 0.0, 1.0, unit_grad=True)
                 ops.mark("D step: forward + loss done")
             else:
                 D_fake_det, D_real = netD(x_pred_t.detach()), netD(x_t)
@@ -317,7 +318,11 @@ class GANTrainStep:
         if fold:
             _ops.fm_fold_begin()         # the feature maps' producers add the feature-matching gradients themselves
         try:
-            D_fake = netD(x_pred_t)
+            if fold:                          # feature-matching gradients are parked, not returned to autograd (ops.ActFuse)
+                with ops.act_fuse_scope():
+                    D_fake = netD(x_pred_t)
+            else:
+                D_fake = netD(x_pred_t)
             ops.mark("G step: D(fake) done")
             if "no_dreal_g" in _ops.WHATIF:          # what-if (scripts/whatif.py): the pass skipped, WRONG values
                 D_real = [[f.detach() for f in sc] for sc in D_fake]
@@ -331,6 +336,12 @@ class GANTrainStep:
             if t.loss_feat_match_error:
                 w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
                 loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
+                n_fm = sum(len(sc) - 1 for sc in D_fake)
+                if fold and _ops._FM_COUNT[0] != n_fm:
+                    # a gradient that went back to autograd would meet feature maps whose producers no longer apply their
+                    # own activation derivative (ops.act_fuse_scope): refuse instead of training on a wrong gradient
+                    raise RuntimeError(f"ste_gan_amd: {n_fm - _ops._FM_COUNT[0]} of {n_fm} feature-matching gradients were "
+                                       "not parked for the backward kernels")
                 loss_main = loss_feat_w if loss_main is None else loss_main + loss_feat_w
                 out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
             ops.mark("G step: losses done")

@@ -124,3 +124,24 @@ def test_config3_full_size_step_is_bit_reproducible(dtype):
         _assert_identical(snaps[0], snaps[1], f"config 3 {dtype}")
     finally:
         ops.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_activation_derivative_equals_the_separate_launch(dtype):
+    """ops.ActFuse (round 4): inside the train step the conv BEHIND a discriminator feature map applies the leaky-ReLU
+    derivative of the layer before it -- and adds the feature-matching gradient in front of it -- in its input-gradient
+    epilogue, instead of one act_bwd launch per layer.  Same fp32 operations in the same order: the step's results do not
+    change by a bit (fp32 mode takes the post-applied form of the same path, bf16 mode the fused epilogues)."""
+    from ste_gan_amd import ops
+    name = next(iter(cases.STEP_CASES))
+    ops.set_compute_dtype(dtype)
+    old = ops.ACT_FUSE
+    try:
+        snaps = []
+        for fuse in (True, False):
+            ops.ACT_FUSE = fuse
+            snaps.append(_run_eager(name, 2))
+        _assert_identical(snaps[0], snaps[1], f"ActFuse on vs off, {dtype}")
+    finally:
+        ops.ACT_FUSE = old
+        ops.set_compute_dtype("f32")

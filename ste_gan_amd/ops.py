@@ -878,7 +878,9 @@ class act_fuse_scope:
 def new_act_fuse() -> Optional["ActFuse"]:
     """An ActFuse link inside an act_fuse_scope (and with gradients on), else None: the layers then apply their own
     activation derivatives, as autograd's general contract needs."""
-    return ActFuse() if (ACT_FUSE and _ACT_FUSE_SCOPE[0] > 0 and torch.is_grad_enabled()) else None
+    # (bf16 mode only: the fp32 kernels have no such epilogue -- they would run per problem and post-apply the derivative,
+    # more launches than the layers' own act_bwd)
+    return ActFuse() if (ACT_FUSE and _ACT_FUSE_SCOPE[0] > 0 and torch.is_grad_enabled() and COMPUTE_DTYPE == "bf16") else None
 
 
 def _ptr_array(items):

@@ -131,7 +131,7 @@ def test_fused_activation_derivative_equals_the_separate_launch(dtype):
     """ops.ActFuse (round 4): inside the train step the conv BEHIND a discriminator feature map applies the leaky-ReLU
     derivative of the layer before it -- and adds the feature-matching gradient in front of it -- in its input-gradient
     epilogue, instead of one act_bwd launch per layer.  Same fp32 operations in the same order: the step's results do not
-    change by a bit (fp32 mode takes the post-applied form of the same path, bf16 mode the fused epilogues)."""
+    change by a bit (bf16 mode: the fused epilogues; fp32 mode never links its layers, the parity path is untouched)."""
     from ste_gan_amd import ops
     name = next(iter(cases.STEP_CASES))
     ops.set_compute_dtype(dtype)

@@ -249,6 +249,16 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 
     // image path, two-stage ring: the consumers request chunk 0's weights (h.cw0; STEGAN_BF16_CW0=0: the producers do)
     const bool cw0 = XH && h.cw0 != 0 && h.nstage == 2;
+    // accumulators: multiplied in the consumer waves; for the epilogue each consumer hands the second half of every tile to
+    // the producer wave at its position (round 4, below), so both roles own the variable
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int hl = lane >> 5, l31 = lane & 31;
     // ================= producers (waves 4-7): stage chunk c + 1 while the consumers multiply chunk c =================
     // (each role computes only its own per-lane state inside its branch: register demand is the maximum of the two
     // roles, not their sum)
@@ -413,7 +423,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             }
             if (j == 4) { PSTAMP(4) }                                // iteration 4's DMAs issued
         }
-        return;
+        // (no return: the producers take half of the epilogue, below)
 #undef HB_DMA_X
 #undef HB_DMA_W2
 #undef HB_W_IT
@@ -518,7 +528,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                 HB_STORE_X(cur ^ 1, xAr, xAv)
             }
         }
-        return;                             // the accumulators live in the consumer waves
+        // (no return: the producers take half of the epilogue, below)
     }   // !XH
     }
 #undef HB_LOAD_X
@@ -527,7 +537,8 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #undef HB_DMA_W
 #undef HB_W_OFFSETS
 
-    // ================= consumers (waves 0-3): LDS operand reads + MFMAs, then the epilogue =================
+    if (!producer) {
+    // ================= consumers (waves 0-3): LDS operand reads + MFMAs =================
     // ---- chunk 0's weights (cw0): the same pieces the producers would request (piece = it * 256 + tid of the role), issued
     // here FIRST, before the consumers' own index setup: their round trip runs under it, and the producers go straight to
     // the X offsets.  The first barrier is preceded by this role's vmcnt(0).
@@ -554,7 +565,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     }
     // ---- per-lane operand addresses.  Reduction "atoms" (tap, cb) are BM (W) / XROW or step (X) 16-byte pieces apart; the
     // two lane halves of an MFMA take atoms 2 s and 2 s + 1 of k-step s: W offset s * 2 BM * 16 for every chunk shape
-    const int hl = lane >> 5, l31 = lane & 31;
     int a_byte[TM], b_byte[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a_byte[i] = ((wm * TM + i) * 32 + l31 + hl * BM) * 16;
@@ -571,14 +581,6 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         }
         b_byte[j] = cb * 16 + hl * (NCB == 1 ? tapB : cbB);
     }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
 #define HB_LDS(ptr_) (*(const bf16x8*)(ptr_))
 #define HB_LOAD(a_, b_, s_)                                                                                     \
@@ -655,6 +657,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #undef HB_XFRAG
 #undef HB_LOAD
 #undef HB_LDS
+    }   // consumers
 
     // ---- epilogue.  The MFMAs ran with the X fragment as the A operand, so a 32 x 32 accumulator tile has its output
     // CHANNEL on the lane and 16 output COLUMNS (time) in its registers, as four runs of 4 consecutive columns
@@ -665,6 +668,40 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
 #ifndef STEGAN_STAMPS_ITER
     HSTAMP(5)
 #endif
+    // ---- ALL EIGHT WAVES run the epilogue (round 4).  It is bound by instruction issue, not by memory: with every load and
+    // store switched off it still cost 1.2 ms of a 6.1 ms train step (ablation builds) -- a few hundred
+    // VALU / LDS / address instructions per 32 x 32 tile and wave, issued by ONE wave per SIMD while the four producer
+    // waves had already left.  Now each consumer wave hands the SECOND half of every tile it owns (column runs q = 2, 3:
+    // 8 of its 16 values per lane) to the producer wave at the same (wm, wn) position through LDS, and both process 8
+    // values per lane and tile: compile-time register indices in both roles (the producer receives the values into
+    // elements 0..7), only the column base differs (+16).
+    block_sync();                        // every wave: the last chunk's operands have been read, all DMAs have landed
+    const int half = producer ? 1 : 0;
+    {
+        float* const hand = (float*)smem + ((wave * TM * TN) * 64 + lane) * 8;          // [position][tile][lane][8 floats]
+        if (!producer) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float* hp = hand + (i * TN + j) * 64 * 8;
+                    *(f32x4*)(hp) = (f32x4){acc[i][j][8], acc[i][j][9], acc[i][j][10], acc[i][j][11]};
+                    *(f32x4*)(hp + 4) = (f32x4){acc[i][j][12], acc[i][j][13], acc[i][j][14], acc[i][j][15]};
+                }
+        }
+        block_sync();
+        if (producer) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* hp = hand + (i * TN + j) * 64 * 8;
+                    const f32x4 lo = *(const f32x4*)(hp), hi = *(const f32x4*)(hp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[i][j][e] = lo[e]; acc[i][j][4 + e] = hi[e]; }
+                }
+        }
+    }
     if (HB_DBG(16)) {
         if (acc[0][0][0] == 123.456f) p.out[0] = 1.f;        // keep the accumulators alive
         return;
@@ -676,44 +713,44 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     // every launch-uniform condition is resolved ONCE here (a single wave per SIMD pays every branch and scalar load
     // of the epilogue in full: the first version, with the conditions inside the element loops, took 20k cycles)
     const int act = raw ? STEGAN_ACT_NONE : p.out_act;
-    const float* const resp = raw ? nullptr : p.res;
-    const float* const maskp = (raw || p.mode != 1) ? nullptr : p.mask;
-    const float* const scalep = raw ? nullptr : p.scale;
-    const float* const biasp = (raw || p.mode != 0) ? nullptr : p.bias;
+    // (HB_DBG: diagnostic ablations of the epilogue's parts, -DSTEGAN_BF16_ABLATE builds only: 32 no image, 64 no mask /
+    // residual loads, 128 no scale / bias loads, 256 no fp32 stores -- results wrong when set)
+    const float* const resp = (raw || HB_DBG(64)) ? nullptr : p.res;
+    const float* const maskp = (raw || p.mode != 1 || HB_DBG(64)) ? nullptr : p.mask;
+    const float* const scalep = (raw || HB_DBG(128)) ? nullptr : p.scale;
+    const float* const biasp = (raw || p.mode != 0 || HB_DBG(128)) ? nullptr : p.bias;
     const int mode = p.mode, ups = p.ups, Cdst = p.Cdst, Tdst = p.Tdst, Tmask = p.Tmask, M_g = p.M_g;
     const bool mlr = p.mask_lrelu != 0;                        // the mask is a leaky-ReLU output: factor AFTER scale and add
-#define HB_ACT16(v_)                                                                                            \
-    if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
-    else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = fmaxf(v_[e], 0.f); }      \
-    else if (act == STEGAN_ACT_TANH) { _Pragma("unroll") for (int e = 0; e < 16; ++e) v_[e] = tanhf(v_[e]); }
+#define HB_ACT8(v_)                                                                                             \
+    if (act == STEGAN_ACT_LRELU) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v_[e] = v_[e] > 0.f ? v_[e] : 0.1f * v_[e]; } \
+    else if (act == STEGAN_ACT_RELU) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v_[e] = fmaxf(v_[e], 0.f); }       \
+    else if (act == STEGAN_ACT_TANH) { _Pragma("unroll") for (int e = 0; e < 8; ++e) v_[e] = tanhf(v_[e]); }
     // ---- bf16 image of the output (DirP::out_h), for the kernel that consumes it next: [B][out_cb][Tdst][8 channels].
-    // A 16-byte piece needs 8 CHANNELS of one column -- 8 lanes of this layout -- so each 32 x 32 tile goes through a
-    // 2 KiB LDS scratch: 16 two-byte stores per lane into [column][channel], two 16-byte reads per lane of (column, 8-channel
-    // block) pieces, consecutive lanes on consecutive columns: 512 contiguous bytes of the image per store instruction.
-    // The scratch reuses the W ring: the producers have left, the consumer waves meet at one more barrier (a wave that has
-    // ended is not waited for) so that no wave overwrites operands another one still reads.
-    unsigned short* const outh = raw ? nullptr : p.out_h;
-    char* const scr = smem + wave * 2048;
-    if (outh) block_sync();
+    // A 16-byte piece needs 8 CHANNELS of one column -- 8 lanes of this layout -- so each half tile (32 channels x 16
+    // columns) goes through a 1 KiB LDS scratch of its wave: 8 two-byte stores per lane into [column][channel], ONE 16-byte
+    // read per lane of a (column, 8-channel block) piece, 16 consecutive lanes on consecutive columns: 256 contiguous bytes
+    // of the image per quarter of a store instruction.  The scratch sits behind the hand-over area of the W / X ring.
+    unsigned short* const outh = (raw || HB_DBG(32)) ? nullptr : p.out_h;
+    char* const scr = smem + 4 * TM * TN * 64 * 32 + (wave + 4 * half) * 1024;
 #define HB_IMAGE_TILE(v_, i_, j_, m_ok_)                                                                        \
     if (outh) {                                                                                                 \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                        \
-            const int nl_ = 8 * (e >> 2) + 4 * hl + (e & 3);                                                    \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                         \
+            const int nl_ = 8 * (e >> 2) + 4 * hl + (e & 3);                     /* local column 0..15 */       \
             *(unsigned short*)(scr + nl_ * 64 + l31 * 2) = (m_ok_) ? f32_to_bf16_bits(v_[e]) : (unsigned short)0; \
         }                                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
-        _Pragma("unroll") for (int h2 = 0; h2 < 2; ++h2) {                                                      \
-            const int cbq_ = hl + 2 * h2, nl_ = l31;                                                            \
+        {                                                                                                       \
+            const int cbq_ = lane >> 4, nl_ = lane & 15;                                                        \
             const u32x4 pc_ = *(const u32x4*)(scr + nl_ * 64 + cbq_ * 16);                                      \
             const int mb_ = m0 + (wm * TM + (i_)) * 32 + cbq_ * 8;                                              \
-            const int n_ = n0 + (wn * TN + (j_)) * 32 + nl_;                                                    \
+            const int n_ = n0 + (wn * TN + (j_)) * 32 + 16 * half + nl_;                                        \
             if (mb_ < M_g && n_ < N) {                                                                          \
                 const int b_ = (int)fd_div((uint32_t)n_, fdU), u_ = n_ - b_ * U;                                \
                 const int to_ = mode == 0 ? u_ : phase + u_ * os;                                               \
                 *(u32x4*)(outh + (((size_t)b_ * p.out_cb + ((g * M_g + mb_) >> 3)) * Tdst + to_) * 8) = pc_;    \
             }                                                                                                   \
         }                                                                                                       \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the reads are done before the next tile's stores */ \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the read is done before the next tile's stores */ \
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -725,13 +762,15 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
         if (biasp) bi = biasp[ch];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int nb0 = n0 + (wn * TN + j) * 32 + 4 * hl;
-            f32x16 v = acc[i][j];
-            if (vec4) {
-                int oidx[4], midx[4];
-                bool ok[4];
+            const int nb0 = n0 + (wn * TN + j) * 32 + 4 * hl + 16 * half;       // this wave's half of the tile's columns
+            float v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][j][e];
+            if (vec4) {
+                int oidx[2], midx[2];
+                bool ok[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
                     const int n = nb0 + 8 * q;
                     ok[q] = m_ok && n < N;
                     const int nn = n < N ? n : 0;
@@ -741,45 +780,45 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                 }
                 if (maskp && !mlr) {
                     if (ups == 0) {
-                        f32x4 mk[4];
+                        f32x4 mk[2];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
+                        for (int q = 0; q < 2; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = mk[e >> 2][e & 3] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) v[e] = mk[e >> 2][e & 3] > 0.f ? v[e] : 0.f;
                     } else {
-                        f32x2 mk[4];
+                        f32x2 mk[2];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) mk[q] = *(const f32x2*)(maskp + midx[q]);
+                        for (int q = 0; q < 2; ++q) mk[q] = *(const f32x2*)(maskp + midx[q]);
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = mk[e >> 2][(e & 3) >> 1] > 0.f ? v[e] : 0.f;
+                        for (int e = 0; e < 8; ++e) v[e] = mk[e >> 2][(e & 3) >> 1] > 0.f ? v[e] : 0.f;
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] * sc + bi;
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc + bi;
                 if (resp) {
-                    f32x4 rs[4];
+                    f32x4 rs[2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) rs[q] = *(const f32x4*)(resp + oidx[q]);
+                    for (int q = 0; q < 2; ++q) rs[q] = *(const f32x4*)(resp + oidx[q]);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] += rs[e >> 2][e & 3];
+                    for (int e = 0; e < 8; ++e) v[e] += rs[e >> 2][e & 3];
                 }
                 if (maskp && mlr) {                        // leaky-ReLU derivative of the layer before (host: ups == 0)
-                    f32x4 mk[4];
+                    f32x4 mk[2];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
+                    for (int q = 0; q < 2; ++q) mk[q] = *(const f32x4*)(maskp + oidx[q]);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] *= mk[e >> 2][e & 3] > 0.f ? 1.f : 0.1f;
+                    for (int e = 0; e < 8; ++e) v[e] *= mk[e >> 2][e & 3] > 0.f ? 1.f : 0.1f;
                 }
-                HB_ACT16(v)
+                HB_ACT8(v)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (ok[q]) *(f32x4*)(outp + oidx[q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                for (int q = 0; q < 2; ++q)
+                    if (ok[q] && !HB_DBG(256)) *(f32x4*)(outp + oidx[q]) = (f32x4){v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
                 HB_IMAGE_TILE(v, i, j, m_ok)
             } else {
-                int oi[16];
-                bool okk[16];
+                int oi[8];
+                bool okk[8];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
+                for (int e = 0; e < 8; ++e) {
                     const int n = nb0 + 8 * (e >> 2) + (e & 3);
                     okk[e] = m_ok && n < N;
                     const int nn = n < N ? n : 0;
@@ -793,24 +832,24 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
                     if (!raw && p.out_btc) oi[e] = (b * Tdst + to) * Cdst + ch;       // (B, T, C) store; never with a residual
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] * sc + bi;
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc + bi;
                 if (resp) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] += resp[oi[e]];
+                    for (int e = 0; e < 8; ++e) v[e] += resp[oi[e]];
                 }
                 if (maskp && mlr) {                        // (ups == 0, no (B, T, C) store: the mask sits at the output's index)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) v[e] *= maskp[oi[e]] > 0.f ? 1.f : 0.1f;
+                    for (int e = 0; e < 8; ++e) v[e] *= maskp[oi[e]] > 0.f ? 1.f : 0.1f;
                 }
-                HB_ACT16(v)
+                HB_ACT8(v)
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
+                for (int e = 0; e < 8; ++e)
                     if (okk[e]) outp[oi[e]] = v[e];
                 HB_IMAGE_TILE(v, i, j, m_ok)
             }
         }
     }
-#undef HB_ACT16
+#undef HB_ACT8
 #undef HB_IMAGE_TILE
 #ifndef STEGAN_STAMPS_ITER
     HSTAMP(6)
@@ -1253,7 +1292,10 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         h.nstage = ns;
         gm.lds = (size_t)ns * stage;
     }
-    if (p.out_h && gm.lds < 8192) gm.lds = 8192;                  // the image epilogue's scratch (4 waves x 2 KiB)
+    {   // the epilogue's LDS: hand-over of the tiles' second halves (4 positions x TM TN tiles x 2 KiB) + 8 x 1 KiB of image scratch
+        const size_t epi = (size_t)4 * TM * TN * 2048 + 8192;
+        if (gm.lds < epi) gm.lds = epi;
+    }
     { const char* ed = getenv("STEGAN_BF16_DBG"); h.dbg = ed ? atoi(ed) : 0; }
     {
         const bool al = ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&

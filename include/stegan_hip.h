@@ -581,6 +581,19 @@ int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float*
 int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
                              float* const* out, const int64_t* n, int32_t act, void* stream);
 
+/*
+ * Generator input (generator.py:143-154): out[b, c, t] = c < F ? x[b, t, c] : w1[id1[b], c - F] (: w2[id2[b], c - F - E])
+ * -- the session (and optional speaking-mode) embedding gathered, broadcast over time, concatenated behind the speech
+ * features and stored 'b c t' -- in one launch; out_h (nullable, F + E (+ E) a multiple of 8): the bf16 image of out.
+ * id2 / w2 NULL: one embedding.  Ids outside their table read zeros.  _bwd: the table's gradient,
+ * dw[s, j] += sum_{b: ids[b] == s} sum_t dout[b, c_off + j, t], in a fixed order (deterministic).
+ */
+int stegan_embed_concat_fwd(const float* x, const int64_t* id1, const float* w1, const int64_t* id2, const float* w2,
+                            float* out, uint16_t* out_h, int32_t B, int32_t T, int32_t F, int32_t E, int32_t S1, int32_t S2,
+                            void* stream);
+int stegan_embed_concat_bwd(const float* dout, const int64_t* ids, float* dw, int32_t B, int32_t T, int32_t Ct, int32_t c_off,
+                            int32_t E, int32_t S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,6 +120,8 @@ SIGNATURES = {
     "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add_multi": [_I32, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
+    "stegan_embed_concat_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "stegan_embed_concat_bwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
 }
 
 # symbols whose return value is not a status code
@@ -158,6 +160,21 @@ def lib() -> C.CDLL:
             fn.restype = C.c_int64
         if handle.stegan_abi_version() != ABI_VERSION:
             raise SteganHipError("libstegan_hip.so ABI version mismatch: rebuild")
+        # diagnostics (scripts/whatif2.py): STEGAN_SKIP=entry1,entry2 turns those entry points into no-ops that report
+        # success -- what would the step cost without them?  RESULTS ARE WRONG when set.
+        skip = [n for n in os.environ.get("STEGAN_SKIP", "").split(",") if n]
+        if skip:
+            class _Skipping:
+                def __init__(self, h, names):
+                    self._h, self._names = h, set(names)
+
+                def __getattr__(self, name):
+                    if name in self._names:
+                        return lambda *a, **k: 0
+                    return getattr(self._h, name)
+            for n in skip:
+                getattr(handle, n)              # typo guard: AttributeError for an unknown entry point
+            handle = _Skipping(handle, skip)
         _lib = handle
     return _lib
 

@@ -130,3 +130,82 @@ extern "C" int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const
 extern "C" int stegan_act_bwd(const float* dy, const float* y, float* out, int64_t n, int32_t act, void* stream) {
     return stegan_act_bwd_add(dy, nullptr, y, out, n, act, stream);
 }
+
+// ---- generator input (round 4): session-embedding gather + broadcast over time + concat + 'b t c -> b c t' in ONE launch
+// (generator.py:143-154; rounds 1-3 left these to ATen: gather, expand, cat, transpose-copy, and five launches backward).
+//   out[b, c, t] = c < F ? x[b, t, c] : (c < F + E ? w1[id1[b], c - F] : w2[id2[b], c - F - E])        (B, F + E (+ E), T)
+// and the bf16 image of out when the channel count is a multiple of 8.  Tiles of 32 time steps x 32 channels go through
+// LDS so that both the (b, t, c) reads and the (b, c, t) writes are coalesced.
+namespace {
+__global__ __launch_bounds__(256) void embed_concat_fwd_kernel(const float* __restrict__ x, const long long* __restrict__ id1,
+                                                               const float* __restrict__ w1, const long long* __restrict__ id2,
+                                                               const float* __restrict__ w2, float* __restrict__ out,
+                                                               unsigned short* __restrict__ out_h, int B, int T, int F, int E,
+                                                               int S1, int S2) {
+    __shared__ float tile[32][33];
+    const int Ct = F + E + (w2 ? E : 0);
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;               // 32 x 8 threads
+    for (int r = ly; r < 32; r += 8) {                                     // r: time step of the tile, lx: channel
+        const int t = t0 + r, c = c0 + lx;
+        float v = 0.f;
+        if (t < T && c < Ct) {
+            if (c < F) v = x[((size_t)b * T + t) * F + c];
+            else if (c < F + E) { const long long s = id1[b]; v = (s >= 0 && s < S1) ? w1[s * E + (c - F)] : 0.f; }
+            else { const long long s = id2[b]; v = (s >= 0 && s < S2) ? w2[s * E + (c - F - E)] : 0.f; }
+        }
+        tile[r][lx] = v;
+    }
+    block_sync();
+    for (int r = ly; r < 32; r += 8) {                                     // r: channel of the tile, lx: time step
+        const int c = c0 + r, t = t0 + lx;
+        if (c < Ct && t < T) {
+            const float v = tile[lx][r];
+            out[((size_t)b * Ct + c) * T + t] = v;
+            if (out_h) img_store(out_h, Ct >> 3, T, b, c, t, v);
+        }
+    }
+}
+
+// dW[s, j] += sum over the batch rows with id[b] == s, over t, of dout[b, c_off + j, t]: one block per table row s, one
+// thread per embedding column j, the batch walked in order -- a fixed summation order (deterministic), no atomics.
+__global__ __launch_bounds__(64) void embed_concat_bwd_kernel(const float* __restrict__ dout, const long long* __restrict__ id,
+                                                              float* __restrict__ dw, int B, int T, int Ct, int c_off, int E) {
+    const int s = blockIdx.x;
+    for (int j = threadIdx.x; j < E; j += 64) {
+        float acc = 0.f;
+        bool any = false;
+        for (int b = 0; b < B; ++b) {
+            if (id[b] != s) continue;
+            any = true;
+            const float* row = dout + ((size_t)b * Ct + c_off + j) * T;
+            float a = 0.f;
+            for (int t = 0; t < T; ++t) a += row[t];
+            acc += a;
+        }
+        if (any) dw[(size_t)s * E + j] += acc;
+    }
+}
+}  // namespace
+
+extern "C" int stegan_embed_concat_fwd(const float* x, const int64_t* id1, const float* w1, const int64_t* id2, const float* w2,
+                                       float* out, uint16_t* out_h, int32_t B, int32_t T, int32_t F, int32_t E, int32_t S1,
+                                       int32_t S2, void* stream) {
+    STEGAN_CHECK_ARG(x && id1 && w1 && out && B > 0 && T > 0 && F > 0 && E > 0 && S1 > 0);
+    STEGAN_CHECK_ARG((id2 == nullptr) == (w2 == nullptr) && (!w2 || S2 > 0));
+    const int Ct = F + E + (w2 ? E : 0);
+    STEGAN_CHECK_ARG(B <= 65535 && (!out_h || Ct % 8 == 0));
+    hipLaunchKernelGGL(embed_concat_fwd_kernel, dim3((unsigned)ceil_div(T, 32), (unsigned)ceil_div(Ct, 32), (unsigned)B), dim3(256),
+                       0, (hipStream_t)stream, x, (const long long*)id1, w1, (const long long*)id2, w2, out, out_h, B, T, F, E, S1, S2);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_embed_concat_bwd(const float* dout, const int64_t* ids, float* dw, int32_t B, int32_t T, int32_t Ct,
+                                       int32_t c_off, int32_t E, int32_t S, void* stream) {
+    STEGAN_CHECK_ARG(dout && ids && dw && B > 0 && T > 0 && E > 0 && S > 0 && c_off >= 0 && c_off + E <= Ct);
+    hipLaunchKernelGGL(embed_concat_bwd_kernel, dim3((unsigned)S), dim3(64), 0, (hipStream_t)stream, dout, (const long long*)ids,
+                       dw, B, T, Ct, c_off, E);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}

@@ -63,6 +63,7 @@ class EMGGeneratorGanTTS(EMGGenerator):
         self.speaking_mode_embeddings = (nn.Embedding(num_speaking_modes, embedding_dim)
                                          if use_speaking_mode_embedding else None)
         self.use_speaking_mode_embedding = use_speaking_mode_embedding
+        self.grad_sink = False      # set by optim.FlatParams: the tables' .grad are persistent, zeroed arena views
         self.input_size = self.speech_input_dim + embedding_dim * (int(use_session_embeddings)
                                                                    + int(use_speaking_mode_embedding))
         upsample_last = 2 if self.speech_feature_type == DataType.SPEECH_UNITS else 1
@@ -82,13 +83,22 @@ class EMGGeneratorGanTTS(EMGGenerator):
     def forward(self, speech_unit_sequence: Tensor, session_ids: Tensor, speaking_mode_ids: Tensor):
         x = speech_unit_sequence
         T = x.shape[1]
-        if self.use_session_embeddings:
-            e = self.session_embeddings(session_ids)
-            x = torch.cat((x, e[:, None, :].expand(-1, T, -1)), dim=-1)
-        if self.use_speaking_mode_embedding:
-            e = self.speaking_mode_embeddings(speaking_mode_ids)
-            x = torch.cat((x, e[:, None, :].expand(-1, T, -1)), dim=-1)
-        x = x.transpose(1, 2).contiguous()           # b t c -> b c t
+        if self.use_session_embeddings and x.is_cuda:
+            # gather + broadcast over time + concat + 'b t c -> b c t' (generator.py:143-154) in one launch
+            w1 = self.session_embeddings.weight
+            w2 = self.speaking_mode_embeddings.weight if self.use_speaking_mode_embedding else None
+            sink = self.grad_sink and torch.is_grad_enabled() and w1.requires_grad and w1.grad is not None and w1.grad.is_contiguous()
+            x = ops.embed_concat(x, session_ids, w1, speaking_mode_ids if w2 is not None else None, w2,
+                                 w1.grad if sink else None,
+                                 w2.grad if (sink and w2 is not None and w2.grad is not None) else None)
+        else:
+            if self.use_session_embeddings:
+                e = self.session_embeddings(session_ids)
+                x = torch.cat((x, e[:, None, :].expand(-1, T, -1)), dim=-1)
+            if self.use_speaking_mode_embedding:
+                e = self.speaking_mode_embeddings(speaking_mode_ids)
+                x = torch.cat((x, e[:, None, :].expand(-1, T, -1)), dim=-1)
+            x = x.transpose(1, 2).contiguous()           # b t c -> b c t
         x = self.gblocks(x)
         return self.last_conv[1](x)                  # (B, T_emg, C_emg) in (-1, 1)
 

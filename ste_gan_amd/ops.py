@@ -1300,6 +1300,74 @@ def spectral_norm_multi(layers, training: bool, keep_uv: bool):
 
 
 # ---------------------------------------------------------------------------------------------
+# autograd: generator input (embedding gather + concat + transpose)
+# ---------------------------------------------------------------------------------------------
+class _EmbedConcatFn(torch.autograd.Function):
+    """(B, T, F) speech features + embedding rows of the batch's session (and speaking-mode) ids -> (B, F + E (+ E), T), the
+    generator's first conv input (generator.py:143-154), in one launch; backward: the tables' gradients, one small launch
+    each (the speech features need none: a leaf of the data path)."""
+
+    @staticmethod
+    def forward(ctx, x, id1, w1, id2, w2, sink1=None, sink2=None):
+        """``sink1`` / ``sink2``: the tables' ``.grad`` views in a FlatParams arena -- the backward pass then accumulates into
+        them directly and returns no gradient (as the convs' gradient sinks do)."""
+        ctx.sinks = (sink1, sink2)
+        x = _gpu_f32(x, "speech_unit_sequence")
+        w1 = _gpu_f32(w1, "session_embeddings.weight")
+        if not id1.is_cuda or id1.dtype != torch.int64:
+            raise RuntimeError("ste_gan_amd: session ids must be a cuda int64 tensor")
+        id1 = id1.contiguous()
+        B, T, F = x.shape
+        E = w1.shape[1]
+        two = w2 is not None
+        if two:
+            w2 = _gpu_f32(w2, "speaking_mode_embeddings.weight")
+            id2 = id2.contiguous()
+            if w2.shape[1] != E or not id2.is_cuda or id2.dtype != torch.int64:
+                raise RuntimeError("ste_gan_amd: the two embeddings must share their width; ids cuda int64")
+        Ct = F + E * (2 if two else 1)
+        out = torch.empty((B, Ct, T), device=x.device, dtype=torch.float32)
+        outh = _new_image(out, Ct, 1, T)
+        check(_lib.lib().stegan_embed_concat_fwd(_p(x), _p(id1), _p(w1), _p(id2) if two else None, _p(w2) if two else None,
+                                                 _p(out), _p(outh), B, T, F, E, w1.shape[0], w2.shape[0] if two else 0,
+                                                 _stream()), "stegan_embed_concat_fwd")
+        _attach_image(out, outh)
+        ctx.dims = (B, T, F, E, Ct, two)
+        ctx.save_for_backward(id1, id2 if two else None)
+        ctx.shapes = (w1.shape, w2.shape if two else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, F, E, Ct, two = ctx.dims
+        id1, id2 = ctx.saved_tensors
+        dout = _gpu_f32(dout, "grad_output")
+        dw1 = dw2 = None
+        s1, s2 = ctx.sinks
+        if ctx.needs_input_grad[2]:
+            if s1 is not None:
+                _sink_touch()
+            dw1 = s1 if s1 is not None else torch.zeros(ctx.shapes[0], device=dout.device, dtype=torch.float32)
+            check(_lib.lib().stegan_embed_concat_bwd(_p(dout), _p(id1), _p(dw1), B, T, Ct, F, E, ctx.shapes[0][0], _stream()),
+                  "stegan_embed_concat_bwd")
+            if s1 is not None:
+                dw1 = None                       # already in the gradient arena
+        if two and ctx.needs_input_grad[4]:
+            if s2 is not None:
+                _sink_touch()
+            dw2 = s2 if s2 is not None else torch.zeros(ctx.shapes[1], device=dout.device, dtype=torch.float32)
+            check(_lib.lib().stegan_embed_concat_bwd(_p(dout), _p(id2), _p(dw2), B, T, Ct, F + E, E, ctx.shapes[1][0], _stream()),
+                  "stegan_embed_concat_bwd")
+            if s2 is not None:
+                dw2 = None
+        return None, None, dw1, None, dw2, None, None
+
+
+def embed_concat(x, id1, w1, id2=None, w2=None, sink1=None, sink2=None) -> Tensor:
+    return _EmbedConcatFn.apply(x, id1, w1, id2, w2, sink1, sink2)
+
+
+# ---------------------------------------------------------------------------------------------
 # autograd: discriminator input plumbing
 # ---------------------------------------------------------------------------------------------
 class _MPDFoldFn(torch.autograd.Function):

@@ -106,3 +106,31 @@ def test_gblock_gradient_handover_equals_autograd_accumulation(up, dtype, monkey
     (g1,) = torch.autograd.grad(y, x, dy, retain_graph=True)
     (g2,) = torch.autograd.grad(y, x, dy)
     assert float((g1 - g2).abs().max()) <= 2e-6 * float(g1.abs().max())
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_embed_concat_kernel_vs_torch(two):
+    """ops.embed_concat (generator.py:143-154: embedding gather, broadcast over time, concat, 'b t c -> b c t') and its
+    backward against the torch ops it replaces, ragged sizes, repeated and out-of-batch session ids."""
+    from ste_gan_amd import ops
+    torch.manual_seed(5)
+    B, T, F_, E, S = 7, 37, 25, 64, 17
+    x = torch.randn(B, T, F_, device="cuda")
+    w1 = torch.randn(S, E, device="cuda", requires_grad=True)
+    w2 = torch.randn(3, E, device="cuda", requires_grad=True) if two else None
+    id1 = torch.tensor([3, 3, 0, 16, 3, 9, 0], device="cuda")
+    id2 = torch.tensor([0, 2, 2, 1, 0, 0, 2], device="cuda") if two else None
+    out = ops.embed_concat(x, id1, w1, id2, w2)
+    ref = torch.cat([x, w1[id1][:, None, :].expand(-1, T, -1)] + ([w2[id2][:, None, :].expand(-1, T, -1)] if two else []), -1)
+    ref = ref.transpose(1, 2).contiguous()
+    assert torch.equal(out, ref)
+    g = torch.randn_like(out)
+    out.backward(g)
+    gw = [w1.grad.clone()] + ([w2.grad.clone()] if two else [])
+    w1.grad = None
+    if two:
+        w2.grad = None
+    ref.backward(g)
+    torch.testing.assert_close(gw[0], w1.grad, rtol=1e-5, atol=1e-5)
+    if two:
+        torch.testing.assert_close(gw[1], w2.grad, rtol=1e-5, atol=1e-5)

@@ -581,6 +581,11 @@ int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float*
 int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
                              float* const* out, const int64_t* n, int32_t act, void* stream);
 
+/* out[i] = sum_j coeff[i * n_in + j] * *in[j] (n_in, n_out <= 8; HOST arrays of device pointers / coefficients): the loss
+ * terms of a step combined into its reported scalars in one launch (train.py:213-264, loss_G += weight * term). */
+int stegan_scalar_combine(int32_t n_in, const float* const* in, int32_t n_out, float* const* out, const float* coeff,
+                          void* stream);
+
 /*
  * Generator input (generator.py:143-154): out[b, c, t] = c < F ? x[b, t, c] : w1[id1[b], c - F] (: w2[id2[b], c - F - E])
  * -- the session (and optional speaking-mode) embedding gathered, broadcast over time, concatenated behind the speech

@@ -120,6 +120,7 @@ SIGNATURES = {
     "stegan_act_bwd_add": [_P, _P, _P, _P, _I64, _I32, _P],
     "stegan_act_bwd_add_multi": [_I32, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_fold_upsample2": [_P, _P, _I64, _I32, _P],
+    "stegan_scalar_combine": [_I32, _P, _I32, _P, _P, _P],
     "stegan_embed_concat_fwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "stegan_embed_concat_bwd": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
 }

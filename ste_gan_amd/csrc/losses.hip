@@ -452,6 +452,36 @@ extern "C" int stegan_scale_by_scalar(const float* x, const float* scalar_dev, f
     return STEGAN_OK;
 }
 
+// out[i] = sum_j coeff[i * n_in + j] * *in[j]: the loss terms of a step combined into its reported scalars (the weighted
+// total, the unweighted terms) in ONE one-thread launch instead of a chain of 0-dim torch mul / add / div kernels
+// (train.py:213-264: loss_G += w * term).  n_in, n_out <= 8.
+namespace {
+struct Combine { const float* in[8]; float* out[8]; float coeff[64]; int n_in, n_out; };
+__global__ void scalar_combine_kernel(const Combine c) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float v[8];
+    for (int j = 0; j < c.n_in; ++j) v[j] = *c.in[j];
+    for (int i = 0; i < c.n_out; ++i) {
+        float a = 0.f;
+        for (int j = 0; j < c.n_in; ++j) a += c.coeff[i * c.n_in + j] * v[j];
+        *c.out[i] = a;
+    }
+}
+}  // namespace
+
+extern "C" int stegan_scalar_combine(int32_t n_in, const float* const* in, int32_t n_out, float* const* out, const float* coeff,
+                                     void* stream) {
+    STEGAN_CHECK_ARG(n_in >= 1 && n_in <= 8 && n_out >= 1 && n_out <= 8 && in && out && coeff);
+    Combine c;
+    c.n_in = n_in; c.n_out = n_out;
+    for (int j = 0; j < n_in; ++j) { STEGAN_CHECK_ARG(in[j]); c.in[j] = in[j]; }
+    for (int i = 0; i < n_out; ++i) { STEGAN_CHECK_ARG(out[i]); c.out[i] = out[i]; }
+    for (int k = 0; k < n_in * n_out; ++k) c.coeff[k] = coeff[k];
+    hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, c);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
 extern "C" int64_t stegan_multi_td_workspace_floats(int32_t B, int32_t C) { return (int64_t)B * C * 3; }
 
 namespace {

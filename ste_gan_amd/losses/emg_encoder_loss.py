@@ -60,10 +60,13 @@ class EMGEncoderLoss(nn.Module):
     def speech_unit_loss(self, speech_unit_target: Tensor, speech_unit_pred: Tensor) -> Tensor:
         return ops.speech_unit_loss(speech_unit_target, speech_unit_pred)
 
-    def forward(self, emg_signal: Tensor, target_speech_units: Tensor,
-                target_phoneme_sequence: Tensor) -> EMGEncoderLossOutput:
+    def forward(self, emg_signal: Tensor, target_speech_units: Tensor, target_phoneme_sequence: Tensor,
+                su_weight: float = 1.0, ph_weight: float = 1.0, unit_grad: bool = False) -> EMGEncoderLossOutput:
+        """``su_weight`` / ``ph_weight`` / ``unit_grad`` (the train step only): the two returned losses AND their gradients
+        carry the weights, upstream gradient 1 promised (ops._MultiTDFn.forward).  Defaults: the reference's module."""
         speech_unit_pred, phoneme_pred = self.emg_encoder(emg_signal)
-        su_loss = self.speech_unit_loss(target_speech_units, speech_unit_pred)
-        ph_loss, counters, argmax = ops.phoneme_ce(phoneme_pred, target_phoneme_sequence, SILENCE_PHONEME_INDEX)
+        su_loss = ops.speech_unit_loss(target_speech_units, speech_unit_pred, su_weight, unit_grad)
+        ph_loss, counters, argmax = ops.phoneme_ce(phoneme_pred, target_phoneme_sequence, SILENCE_PHONEME_INDEX, ph_weight,
+                                                   unit_grad)
         return EMGEncoderLossOutput(speech_unit_pred, phoneme_pred, su_loss, ph_loss, target_phoneme_sequence,
                                     counters, argmax)

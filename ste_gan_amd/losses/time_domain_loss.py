@@ -61,12 +61,15 @@ class MultiTimeDomainFeatureLoss(nn.Module):
             TimeDomainFeatureLoss(num_channels, win_size_samples=51, win_shift_samples=13),
             TimeDomainFeatureLoss(num_channels, win_size_samples=80, win_shift_samples=16)])
 
-    def time_domain_loss(self, x_real: Tensor, x_generated: Tensor) -> Tuple[Tensor, List[Tensor]]:
+    def time_domain_loss(self, x_real: Tensor, x_generated: Tensor, weight: float = 1.0,
+                         unit_grad: bool = False) -> Tuple[Tensor, List[Tensor]]:
         wins = [m.win_size_samples for m in self.time_domain_losses]
         shifts = [m.win_shift_samples for m in self.time_domain_losses]
-        loss, per = ops.multi_td_loss(x_real, x_generated, wins, shifts)
+        loss, per = ops.multi_td_loss(x_real, x_generated, wins, shifts, weight=weight, unit_grad=unit_grad)
         return loss, [per[i] for i in range(len(wins))]
 
-    def forward(self, x_real: Tensor, x_generated: Tensor) -> Tensor:
-        loss, _ = self.time_domain_loss(x_real, x_generated)
+    def forward(self, x_real: Tensor, x_generated: Tensor, weight: float = 1.0, unit_grad: bool = False) -> Tensor:
+        """``weight`` / ``unit_grad`` (the train step): the returned value AND its gradient carry the loss weight, and the
+        caller promises an upstream gradient of 1 -- see ops._MultiTDFn.forward.  Defaults: the reference's module."""
+        loss, _ = self.time_domain_loss(x_real, x_generated, weight, unit_grad)
         return loss

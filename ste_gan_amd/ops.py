@@ -1651,7 +1651,12 @@ def mse_to_const(a, target: float):
 
 class _MultiTDFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True):
+    def forward(ctx, x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True, weight: float = 1.0,
+                unit_grad: bool = False):
+        """``weight`` scales the loss value AND the stored gradient; ``unit_grad``: the caller promises an upstream gradient
+        of exactly 1 (the weighted value is a plain summand of the scalar it differentiates): backward then returns the
+        stored gradient as it is, no scaling launch."""
+        ctx.unit_grad = bool(unit_grad)
         x_real = _gpu_f32(x_real, "x_real")
         x_gen = _gpu_f32(x_gen, "x_generated")
         if x_real.shape != x_gen.shape:
@@ -1672,7 +1677,7 @@ class _MultiTDFn(torch.autograd.Function):
             raise RuntimeError("stegan_multi_td_scratch_floats: invalid argument or unsupported shape")
         scratch = torch.empty(ns, device=x_gen.device, dtype=torch.float32) if ns > 0 else None
         check(L.stegan_multi_td_fwd_bwd_ex(_p(x_real), _p(x_gen), B, T, Cc, n, wa, sa, int(avg_window), int(pad_windowing),
-                                           1.0, _p(loss), _p(per), _p(dx), _p(ws), _p(scratch), ns, _stream()),
+                                           float(weight), _p(loss), _p(per), _p(dx), _p(ws), _p(scratch), ns, _stream()),
               "stegan_multi_td_fwd_bwd_ex")
         ctx.save_for_backward(dx)
         ctx.mark_non_differentiable(per)
@@ -1681,11 +1686,15 @@ class _MultiTDFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gper):
         (dx,) = ctx.saved_tensors
-        return None, (_chain(dx, g) if dx is not None else None), None, None, None, None
+        if dx is None:
+            return None, None, None, None, None, None, None, None
+        return None, (dx if ctx.unit_grad else _chain(dx, g)), None, None, None, None, None, None
 
 
-def multi_td_loss(x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True):
-    return _MultiTDFn.apply(x_real.detach(), x_gen, tuple(wins), tuple(shifts), int(avg_window), bool(pad_windowing))
+def multi_td_loss(x_real, x_gen, wins, shifts, avg_window: int = 9, pad_windowing: bool = True, weight: float = 1.0,
+                  unit_grad: bool = False):
+    return _MultiTDFn.apply(x_real.detach(), x_gen, tuple(wins), tuple(shifts), int(avg_window), bool(pad_windowing),
+                            float(weight), bool(unit_grad))
 
 
 def td_features(x: Tensor, win: int, shift: int, avg_window: int = 9, pad_windowing: bool = True) -> Tensor:
@@ -1736,7 +1745,8 @@ def average_filter(x: Tensor, window: int = 9, pad_signal: bool = True) -> Tenso
 
 class _SULossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, target, pred):
+    def forward(ctx, target, pred, weight: float = 1.0, unit_grad: bool = False):
+        ctx.unit_grad = bool(unit_grad)             # see _MultiTDFn.forward
         target = _gpu_f32(target, "speech_unit_target")
         pred = _gpu_f32(pred, "speech_unit_pred")
         D = pred.shape[-1]
@@ -1744,7 +1754,7 @@ class _SULossFn(torch.autograd.Function):
         loss = pooled_zeros((), pred.device)
         ws = torch.empty(rows, device=pred.device, dtype=torch.float32)
         dp = torch.empty_like(pred) if ctx.needs_input_grad[1] else None
-        check(_lib.lib().stegan_su_loss_fwd_bwd(_p(target), _p(pred), rows, D, 1.0, _p(loss), _p(dp), _p(ws), _stream()),
+        check(_lib.lib().stegan_su_loss_fwd_bwd(_p(target), _p(pred), rows, D, float(weight), _p(loss), _p(dp), _p(ws), _stream()),
               "stegan_su_loss_fwd_bwd")
         ctx.save_for_backward(dp)
         return loss
@@ -1752,16 +1762,19 @@ class _SULossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return None, (_chain(dp, g) if dp is not None else None)
+        if dp is None:
+            return None, None, None, None
+        return None, (dp if ctx.unit_grad else _chain(dp, g)), None, None
 
 
-def speech_unit_loss(target, pred):
-    return _SULossFn.apply(target.detach(), pred)
+def speech_unit_loss(target, pred, weight: float = 1.0, unit_grad: bool = False):
+    return _SULossFn.apply(target.detach(), pred, float(weight), bool(unit_grad))
 
 
 class _PhonemeCEFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets, silence_index: int):
+    def forward(ctx, logits, targets, silence_index: int, weight: float = 1.0, unit_grad: bool = False):
+        ctx.unit_grad = bool(unit_grad)             # see _MultiTDFn.forward
         logits = _gpu_f32(logits, "phoneme_pred")
         if not targets.is_cuda or targets.dtype != torch.int64:
             raise RuntimeError("ste_gan_amd: phoneme targets must be a cuda int64 tensor")
@@ -1776,7 +1789,7 @@ class _PhonemeCEFn(torch.autograd.Function):
         argmax = torch.empty(logits.shape[:-1], device=dev, dtype=torch.int64)
         ws = torch.empty(rows, device=dev, dtype=torch.float32)
         dl = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        check(_lib.lib().stegan_phoneme_ce_fwd_bwd(_p(logits), _p(targets), rows, P, silence_index, 1.0, _p(loss),
+        check(_lib.lib().stegan_phoneme_ce_fwd_bwd(_p(logits), _p(targets), rows, P, silence_index, float(weight), _p(loss),
                                                    _p(counters), _p(dl), _p(argmax), _p(ws), _stream()),
               "stegan_phoneme_ce_fwd_bwd")
         ctx.save_for_backward(dl)
@@ -1786,11 +1799,37 @@ class _PhonemeCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _c, _a):
         (dl,) = ctx.saved_tensors
-        return (_chain(dl, g) if dl is not None else None), None, None
+        if dl is None:
+            return None, None, None, None, None
+        return (dl if ctx.unit_grad else _chain(dl, g)), None, None, None, None
 
 
-def phoneme_ce(logits, targets, silence_index):
-    return _PhonemeCEFn.apply(logits, targets, silence_index)
+def phoneme_ce(logits, targets, silence_index, weight: float = 1.0, unit_grad: bool = False):
+    return _PhonemeCEFn.apply(logits, targets, silence_index, float(weight), bool(unit_grad))
+
+
+def scalar_combine(ins, rows):
+    """[sum_j rows[i][j] * ins[j] for i] as 0-dim device tensors, ONE launch (stegan_scalar_combine): the step's loss terms
+    -> its reported scalars.  ``ins``: 0-dim cuda float tensors (detached), ``rows``: coefficient rows."""
+    n_in, n_out = len(ins), len(rows)
+    ins = [_gpu_f32(t.detach().reshape(()), "loss term") for t in ins]
+    outs = torch.empty(n_out, device=ins[0].device, dtype=torch.float32)
+    views = [outs[i] for i in range(n_out)]
+    coeff = (C.c_float * (n_in * n_out))(*[float(c) for r in rows for c in r])
+    check(_lib.lib().stegan_scalar_combine(n_in, _ptr_array(ins), n_out, _ptr_array(views), coeff, _stream()),
+          "stegan_scalar_combine")
+    return views
+
+
+_ONES: dict = {}
+
+
+def one_like(t: Tensor) -> Tensor:
+    """A persistent 0-dim 1.0 on ``t``'s device: the upstream gradient of a scalar root without autograd's ones_like fill."""
+    o = _ONES.get(t.device)
+    if o is None:
+        o = _ONES[t.device] = torch.ones((), device=t.device, dtype=torch.float32)
+    return o
 
 
 # ---------------------------------------------------------------------------------------------

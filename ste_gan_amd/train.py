@@ -203,48 +203,56 @@ class GANTrainStep:
                         speech_units_t=speech_units_t, phoneme_targets=batch_dict[DataType.PHONEMES])
 
     def _p_side_fwd(self) -> None:
-        """The D-independent generator losses (forward), on the CURRENT stream ..."""
+        """The D-independent generator losses (forward), on the CURRENT stream ...
+
+        Every term is computed WITH its loss weight folded into the kernel (value and gradient), as a plain summand whose
+        upstream gradient is one; the weighted total and the unweighted values the reference logs come out of ONE
+        ``ops.scalar_combine`` launch instead of a chain of 0-dim torch mul / add kernels (train.py:213-256)."""
         t = self.cfg.train
         st = self._st
         out, x_pred_t, x_t = st["out"], st["x_pred_t"], st["x_t"]
         speech_units_t, phoneme_targets = st["speech_units_t"], st["phoneme_targets"]
-        loss_side = None
         xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
+        terms = []                                          # (key in ``out``, weighted 0-dim loss, weight)
         ops.mark("side: start")
         if t.loss_multi_td_error:
-            td_error = self.multi_td_loss(x_t, xp)
-            loss_side = t.loss_multi_td_weight * td_error
-            out["multi_td"] = td_error.detach()
+            w = float(t.loss_multi_td_weight)
+            terms.append(("multi_td", self.multi_td_loss(x_t, xp, weight=w, unit_grad=True), w))
         ops.mark("side: TD done")
         if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
-            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets)
+            w_su = float(t.loss_speech_unit_weight) if t.loss_speech_unit_error else 0.0
+            w_ph = float(t.loss_phoneme_weight) if t.loss_phoneme_error else 0.0
+            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets, su_weight=w_su,
+                                                                  ph_weight=w_ph, unit_grad=True)
             if t.loss_speech_unit_error:
-                term = t.loss_speech_unit_weight * enc_out.speech_unit_loss
-                loss_side = term if loss_side is None else loss_side + term
-                out["speech_unit"] = enc_out.speech_unit_loss.detach()
+                terms.append(("speech_unit", enc_out.speech_unit_loss, w_su))
             if t.loss_phoneme_error:
-                term = t.loss_phoneme_weight * enc_out.phoneme_loss
-                loss_side = term if loss_side is None else loss_side + term
-                out["phoneme"] = enc_out.phoneme_loss.detach()
+                terms.append(("phoneme", enc_out.phoneme_loss, w_ph))
             out["phoneme_counters"] = enc_out._counters
         if t.loss_waveform_error:
-            wave_loss = ops.mse_loss(xp, x_t)
-            term = t.loss_waveform_weight * wave_loss
-            loss_side = term if loss_side is None else loss_side + term
-            out["waveform"] = wave_loss.detach()
+            w = float(t.loss_waveform_weight)
+            terms.append(("waveform", ops.multi_pair_loss([xp], [x_t], 1, w, unit_grad=True), w))
         ops.mark("side: encoder forward + losses done")
-        st["loss_side"], st["xp"] = loss_side, xp
+        loss_side = None
+        if terms:
+            n = len(terms)
+            rows = [[1.0] * n] + [[(1.0 / w if (j == i and w != 0.0) else 0.0) for j in range(n)] for i, (_, _, w) in enumerate(terms)]
+            vals = ops.scalar_combine([v for _, v, _ in terms], rows)
+            loss_side = vals[0]
+            for (key, _, _), v in zip(terms, vals[1:]):
+                out[key] = v
+        st["loss_side"], st["xp"], st["side_roots"] = loss_side, xp, [v for _, v, w in terms if w != 0.0]
 
     def _p_side_bwd(self) -> None:
         """... and their gradient w.r.t. the generated EMG (the backward pass of the side branch)."""
         st = self._st
-        loss_side, xp = st["loss_side"], st.pop("xp")
+        xp, roots = st.pop("xp"), st.pop("side_roots")
         g_side = None
-        if loss_side is not None:
-            (g_side,) = torch.autograd.grad(loss_side, xp)
-            loss_side = loss_side.detach()
+        if roots:
+            one = ops.one_like(xp)
+            (g_side,) = torch.autograd.grad(roots, xp, grad_outputs=[one] * len(roots))
         ops.mark("side: backward done")
-        st["loss_side"], st["g_side"] = loss_side, g_side
+        st["g_side"] = g_side
 
     def _p_side(self) -> None:
         self._p_side_fwd()
@@ -330,9 +338,9 @@ class GANTrainStep:
                 with torch.no_grad():
                     D_real = netD(x_t)
             ops.mark("G step: D(real) done")
-            loss_main = None
+            main_terms = []                                              # (key | None, weighted 0-dim loss, weight)
             if t.loss_adversarial:
-                loss_main = lsgan_loss(D_fake, 1.0, unit_grad=True)
+                main_terms.append((None, lsgan_loss(D_fake, 1.0, unit_grad=True), 1.0))
             if t.loss_feat_match_error:
                 w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
                 loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
@@ -342,29 +350,31 @@ class GANTrainStep:
                     # own activation derivative (ops.act_fuse_scope): refuse instead of training on a wrong gradient
                     raise RuntimeError(f"ste_gan_amd: {n_fm - _ops._FM_COUNT[0]} of {n_fm} feature-matching gradients were "
                                        "not parked for the backward kernels")
-                loss_main = loss_feat_w if loss_main is None else loss_main + loss_feat_w
-                out["feature_matching"] = loss_feat_w.detach() / w_fm if w_fm != 0 else loss_feat_w.detach()
+                main_terms.append(("feature_matching", loss_feat_w, w_fm))
             ops.mark("G step: losses done")
         except BaseException:
             _ops.fm_fold_abort()
             self._set_d_grad(True)
             raise
-        st["loss_main"], st["fold"] = loss_main, fold
+        st["main_terms"], st["fold"] = main_terms, fold
 
     def _p_g2(self) -> None:
         """Join of the side branch, ONE backward pass through the generator for both gradient sources, its gradients."""
         from . import ops as _ops
         st = self._st
         out, x_pred_t, side, main_stream = st["out"], st["x_pred_t"], st["side"], st["main_stream"]
-        loss_side, g_side, loss_main, fold = st["loss_side"], st["g_side"], st["loss_main"], st["fold"]
+        loss_side, g_side, main_terms, fold = st["loss_side"], st["g_side"], st["main_terms"], st["fold"]
         try:
             if side is not None:
                 main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
             ops.mark("G step: side joined")
-            # one pass through the generator for both gradient sources
+            # one pass through the generator for both gradient sources; the scalar roots meet a persistent 1.0 instead of
+            # autograd's ones_like fills
             roots, grads = [], []
-            if loss_main is not None:
-                roots.append(loss_main); grads.append(None)
+            one = ops.one_like(x_pred_t)
+            for _, v, _ in main_terms:
+                if v.requires_grad:
+                    roots.append(v); grads.append(one)
             if g_side is not None:
                 roots.append(x_pred_t); grads.append(g_side)
             if roots:
@@ -373,17 +383,30 @@ class GANTrainStep:
                     torch.autograd.backward(roots, grads)
                 finally:
                     _ops.wgrad_async(False)
-            loss_G = (loss_main.detach() if loss_main is not None else 0) + (loss_side if loss_side is not None else 0)
+            # loss_G and the unweighted feature-matching value in one launch (train.py:209-264: loss_G += w * term)
+            ins = [v for _, v, _ in main_terms] + ([loss_side] if loss_side is not None else [])
+            loss_G = None
+            if ins:
+                rows = [[1.0] * len(ins)]
+                for i, (key, _, w) in enumerate(main_terms):
+                    if key is not None:
+                        rows.append([(1.0 / w if (j == i and w != 0.0) else 0.0) for j in range(len(ins))])
+                vals = _ops.scalar_combine(ins, rows)
+                loss_G = vals[0]
+                k = 1
+                for key, _, _ in main_terms:
+                    if key is not None:
+                        out[key] = vals[k]; k += 1
             if fold:
                 _ops.fm_fold_end()       # raises if a parked gradient was not collected
         finally:
             _ops.fm_fold_abort()
             self._set_d_grad(True)
-        st["loss_main"] = None
+        st["main_terms"] = None
         ops.mark("G step: backward done")
         self.optG.finalize_grads()
         ops.mark("G step: gradients finalized")
-        out["generator"] = loss_G.detach() if torch.is_tensor(loss_G) else torch.zeros((), device=x_pred_t.device)
+        out["generator"] = loss_G if loss_G is not None else torch.zeros((), device=x_pred_t.device)
         out["x_pred"] = x_pred_t.detach()
 
     def phase_opt(self) -> Dict[str, torch.Tensor]:

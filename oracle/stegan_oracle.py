@@ -37,6 +37,100 @@ PERIODS = (2, 3, 5, 7, 11)      # ste_gan/models/discriminator.py:127,163
 
 
 # --------------------------------------------------------------------------------------
+# bf16-operand emulation (tests of the build's bf16 compute mode; off by default)
+# --------------------------------------------------------------------------------------
+# The build's BASELINE-config-3 mode rounds the two operands of every matrix-core contraction to bf16 and keeps everything
+# else in fp32.  Inside ``with bf16_operands():`` this oracle rounds AT THE SAME POINTS, so that the
+# bf16 train step can be compared with it to ~1e-3 instead of the 3 % / 8 % that a comparison with the fp32 reference
+# allows.  The rounding points, per contraction y = W (*) x:
+#   forward          bf16(x) (*) bf16(w_raw), then the per-channel factor (weight norm g/||v||, 1/sigma, folded BatchNorm
+#                    scale) and the bias in fp32 -- w_raw is the direction tensor v / weight_orig / the frozen weight;
+#   input gradient   bf16(dy) (*) bf16(w_raw * factor)  (per-channel factors are folded into the gradient copy of the
+#                    weights BEFORE rounding; the spectral norm's single factor is applied after, in fp32);
+#   weight gradient  bf16(x) (*) bf16(dy) -> the gradient w.r.t. the EFFECTIVE weight, from which the fp32 weight-norm /
+#                    spectral-norm chain rule continues (as the build's wn_backward / spectral_norm_bwd kernels do).
+# Contractions the build leaves on exact fp32 kernels stay exact here: the single-output-channel convs, and any direction
+# whose group has fewer than 8 channels on either side (weight gradients: fewer than 16).  With the flag off (the default,
+# and always for the golden fixtures) every function below is the plain fp32 restatement.
+BF16_OPERANDS = False
+
+
+class bf16_operands:
+    def __enter__(self):
+        global BF16_OPERANDS
+        self._old, BF16_OPERANDS = BF16_OPERANDS, True
+        return self
+
+    def __exit__(self, *exc):
+        global BF16_OPERANDS
+        BF16_OPERANDS = self._old
+        return False
+
+
+def _r(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _emu_flags(cin: int, cout: int, groups: int) -> Tuple[bool, bool, bool]:
+    """(forward, input gradient, weight gradient) run with bf16 operands in the build (ops.conv1d_* dispatch rules)."""
+    cig, cog = cin // groups, cout // groups
+    if cout == 1 and groups == 1:
+        return False, False, False                     # conv_skinny.hip: exact fp32 in all three directions
+    mm = cig >= 8 and cog >= 8
+    return mm, mm, (cig >= 16 and cog >= 16)
+
+
+class _ContractEmu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_eff, bias, w_raw, scale, conv, kw, uniform, flags):
+        fwd_b = flags[0]
+        y = conv(_r(x) if fwd_b else x, _r(w_raw) if fwd_b else w_raw, None, **kw)
+        shape = (1, -1) + (1,) * (y.dim() - 2)
+        if scale is not None:
+            y = y * (scale if uniform else scale.view(shape))
+        if bias is not None:
+            y = y + bias.view(shape)
+        ctx.conv, ctx.kw, ctx.uniform, ctx.flags = conv, kw, uniform, flags
+        ctx.save_for_backward(x, w_raw, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_raw, scale = ctx.saved_tensors
+        conv, kw, uniform, (_, bwd_b, wg_b) = ctx.conv, ctx.kw, ctx.uniform, ctx.flags
+        dx = dw = db = None
+        wshape = (-1,) + (1,) * (w_raw.dim() - 1)
+        with torch.enable_grad():
+            if ctx.needs_input_grad[0]:
+                wb = w_raw if (scale is None or uniform) else w_raw * scale.view(wshape)
+                xe = torch.zeros_like(x, requires_grad=True)
+                ye = conv(xe, _r(wb) if bwd_b else wb, None, **kw)
+                (dx,) = torch.autograd.grad(ye, xe, _r(dy) if bwd_b else dy)
+                if scale is not None and uniform:
+                    dx = dx * scale
+            if ctx.needs_input_grad[1]:
+                w0 = torch.zeros_like(w_raw, requires_grad=True)
+                y0 = conv(_r(x) if wg_b else x, w0, None, **kw)
+                (dw,) = torch.autograd.grad(y0, w0, _r(dy) if wg_b else dy)
+        if ctx.needs_input_grad[2]:
+            db = dy.sum([d for d in range(dy.dim()) if d != 1])
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def _contract(x, w_eff, bias, w_raw, scale, conv, uniform=False, **kw):
+    """One conv / linear contraction: plain fp32 ``conv(x, w_eff, bias)`` -- or, under bf16_operands(), the emulation.
+    ``w_eff`` (the effective weight, with autograd history back to the parameters; None for frozen weights),
+    ``w_raw`` + ``scale``: its factorisation as the build stores it."""
+    if not BF16_OPERANDS:
+        return conv(x, w_eff if w_eff is not None else (w_raw if scale is None else w_raw * scale.view((-1,) + (1,) * (w_raw.dim() - 1))),
+                    bias, **kw)
+    groups = kw.get("groups", 1)
+    flags = _emu_flags(w_raw.shape[1] * groups, w_raw.shape[0], groups)
+    return _ContractEmu.apply(x, w_eff, bias, w_raw.detach(), scale.detach() if scale is not None else None, conv, kw,
+                              uniform, flags)
+
+
+# --------------------------------------------------------------------------------------
 # weight re-parametrisations
 # --------------------------------------------------------------------------------------
 def weight_norm_weight(v: Tensor, g: Tensor) -> Tensor:
@@ -65,9 +159,16 @@ def spectral_norm_weight(w_orig: Tensor, u: Tensor, v: Tensor, training: bool = 
     return w_orig / sigma, u, v
 
 
+def _wn_scale(v: Tensor, g: Tensor) -> Tensor:
+    return (g.flatten() / v.flatten(1).norm(dim=1))
+
+
 def _wn_conv1d(sd: SD, prefix: str, x: Tensor, **kw) -> Tensor:
-    w = weight_norm_weight(sd[prefix + ".weight_v"], sd[prefix + ".weight_g"])
-    return F.conv1d(x, w, sd[prefix + ".bias"], **kw)
+    v, g = sd[prefix + ".weight_v"], sd[prefix + ".weight_g"]
+    w = weight_norm_weight(v, g)
+    if not BF16_OPERANDS:
+        return F.conv1d(x, w, sd[prefix + ".bias"], **kw)
+    return _contract(x, w, sd[prefix + ".bias"], v, _wn_scale(v, g), F.conv1d, **kw)
 
 
 # --------------------------------------------------------------------------------------
@@ -146,12 +247,14 @@ def mpd_forward(sd: SD, prefix: str, x: Tensor, period: int, small: bool) -> Lis
     fmaps = []
     for j, (k, s, p) in enumerate(MPD_SMALL if small else MPD_FULL):
         pre = f"{prefix}.layers.{j}"
-        w = weight_norm_weight(sd[pre + ".weight_v"], sd[pre + ".weight_g"])
-        x = F.leaky_relu(F.conv2d(x, w, sd[pre + ".bias"], stride=(s, 1), padding=(p, 0)), 0.1)
+        v, g = sd[pre + ".weight_v"], sd[pre + ".weight_g"]
+        w = weight_norm_weight(v, g)
+        x = F.leaky_relu(_contract(x, w, sd[pre + ".bias"], v, _wn_scale(v, g), F.conv2d, stride=(s, 1), padding=(p, 0)), 0.1)
         fmaps.append(x)
     pre = f"{prefix}.output"
-    w = weight_norm_weight(sd[pre + ".weight_v"], sd[pre + ".weight_g"])
-    fmaps.append(F.conv2d(x, w, sd[pre + ".bias"], padding=(1, 0)))
+    v, g = sd[pre + ".weight_v"], sd[pre + ".weight_g"]
+    w = weight_norm_weight(v, g)
+    fmaps.append(_contract(x, w, sd[pre + ".bias"], v, _wn_scale(v, g), F.conv2d, padding=(1, 0)))
     return fmaps
 
 
@@ -171,9 +274,15 @@ def msd_forward(sd: SD, prefix: str, x: Tensor, spectral: bool, small: bool,
                                            sd[pre + ".weight_v"], training)
             if sn_state is not None:
                 sn_state[pre + ".weight_u"], sn_state[pre + ".weight_v"] = u, v
+            w_raw = sd[pre + ".weight_orig"]
+            with torch.no_grad():
+                scale = 1.0 / torch.dot(u, torch.mv(w_raw.flatten(1), v))           # 1 / sigma, one factor for the layer
+            y = _contract(x, w, sd[pre + ".bias"], w_raw, scale, F.conv1d, uniform=True, stride=s, padding=p, groups=g)
         else:
-            w = weight_norm_weight(sd[pre + ".weight_v"], sd[pre + ".weight_g"])
-        x = F.leaky_relu(F.conv1d(x, w, sd[pre + ".bias"], stride=s, padding=p, groups=g), 0.1)
+            vv, gg = sd[pre + ".weight_v"], sd[pre + ".weight_g"]
+            w = weight_norm_weight(vv, gg)
+            y = _contract(x, w, sd[pre + ".bias"], vv, _wn_scale(vv, gg), F.conv1d, stride=s, padding=p, groups=g)
+        x = F.leaky_relu(y, 0.1)
         fmaps.append(x)
     fmaps.append(_wn_conv1d(sd, f"{prefix}.output", x, padding=1))
     return fmaps
@@ -280,8 +389,31 @@ def _bn_eval(sd: SD, pre: str, x: Tensor, eps: float = 1e-5) -> Tensor:
                         sd[pre + ".weight"], sd[pre + ".bias"], False, 0.0, eps)
 
 
+def _frozen_conv_bn(sd: SD, conv: str, bn: str, x: Tensor, eps: float = 1e-5, **kw) -> Tensor:
+    """conv + eval-mode BatchNorm as the build runs it: the BatchNorm scale is a per-channel factor behind the contraction
+    (folded into the weights' gradient copy), conv bias and shift are one folded bias."""
+    s_ = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + eps)
+    b_ = (sd[conv + ".bias"] - sd[bn + ".running_mean"]) * s_ + sd[bn + ".bias"]
+    return _contract(x, None, b_, sd[conv + ".weight"], s_, F.conv1d, **kw)
+
+
+def _frozen_linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """F.linear over the last axis as the build's K = 1 conv over (B, C, T)."""
+    if not BF16_OPERANDS:
+        return F.linear(x, w, b)
+    lead = x.shape[:-1]
+    y = _contract(x.reshape(-1, x.shape[-1]).t().unsqueeze(0), None, b, w.unsqueeze(-1), None, F.conv1d)
+    return y.squeeze(0).t().reshape(*lead, w.shape[0])
+
+
 def encoder_resblock(sd: SD, pre: str, x: Tensor, stride: int = 2) -> Tensor:
     """ResBlock.forward (eval-mode BatchNorm) -- ste_gan/layers/conv.py:106-133."""
+    if BF16_OPERANDS:
+        h = F.relu(_frozen_conv_bn(sd, pre + ".conv1", pre + ".bn1", x, stride=stride, padding=1))
+        h = _frozen_conv_bn(sd, pre + ".conv2", pre + ".bn2", h, padding=1)
+        r = (_frozen_conv_bn(sd, pre + ".residual_path", pre + ".res_norm", x, stride=stride)
+             if pre + ".residual_path.weight" in sd else x)
+        return F.relu(h + r)
     h = F.relu(_bn_eval(sd, pre + ".bn1", F.conv1d(x, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"],
                                                   stride=stride, padding=1)))
     h = _bn_eval(sd, pre + ".bn2", F.conv1d(h, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], padding=1))
@@ -314,6 +446,18 @@ def attention_forward(sd: SD, pre: str, x_tbf: Tensor, max_rel: int = 100) -> Te
     """MultiHeadAttention.forward (eval: dropout off) -- ste_gan/layers/transformer.py:88-113."""
     wq, wk, wv, wo = (sd[f"{pre}.w_{n}"] for n in "qkvo")
     d = wq.shape[-1]
+    if BF16_OPERANDS:
+        # the build's projections are K = 1 convs over the packed (H A, F) weights (layers/transformer.py packed())
+        H, Fd, A = wq.shape
+        T_, B_ = x_tbf.shape[0], x_tbf.shape[1]
+        proj = lambda w: _frozen_linear(x_tbf, w.permute(0, 2, 1).reshape(H * A, Fd), None).view(T_, B_, H, A).permute(1, 2, 0, 3)
+        q, k, v = proj(wq), proj(wk), proj(wv)
+        logits = torch.einsum("bhqa,bhka->bhqk", q, k) / (d ** 0.5)
+        logits = logits + relative_position_logits(q, sd[f"{pre}.relative_positional.embeddings"], max_rel)
+        probs = F.softmax(logits, dim=-1)
+        o = torch.einsum("bhqk,bhka->bhqa", probs, v)                       # (B, H, T, A)
+        o = o.permute(2, 0, 1, 3).reshape(T_, B_, H * A)
+        return _frozen_linear(o, wo.reshape(H * A, Fd).t(), None)
     q = torch.einsum("tbf,hfa->bhta", x_tbf, wq)
     k = torch.einsum("tbf,hfa->bhta", x_tbf, wk)
     v = torch.einsum("tbf,hfa->bhta", x_tbf, wv)
@@ -329,8 +473,8 @@ def transformer_layer(sd: SD, pre: str, src: Tensor) -> Tensor:
     D = src.shape[-1]
     src = src + attention_forward(sd, pre + ".self_attn", src)
     src = F.layer_norm(src, (D,), sd[pre + ".norm1.weight"], sd[pre + ".norm1.bias"], 1e-5)
-    h = F.linear(F.relu(F.linear(src, sd[pre + ".linear1.weight"], sd[pre + ".linear1.bias"])),
-                 sd[pre + ".linear2.weight"], sd[pre + ".linear2.bias"])
+    h = _frozen_linear(F.relu(_frozen_linear(src, sd[pre + ".linear1.weight"], sd[pre + ".linear1.bias"])),
+                       sd[pre + ".linear2.weight"], sd[pre + ".linear2.bias"])
     src = src + h
     return F.layer_norm(src, (D,), sd[pre + ".norm2.weight"], sd[pre + ".norm2.bias"], 1e-5)
 
@@ -346,15 +490,15 @@ def encoder_forward(sd: SD, emg_btc: Tensor) -> Tuple[Tensor, Tensor]:
     while f"conv_blocks.{i}.conv1.weight" in sd:
         x = encoder_resblock(sd, f"conv_blocks.{i}", x)
         i += 1
-    x = F.linear(x.transpose(1, 2), sd["w_raw_in.weight"], sd["w_raw_in.bias"])
+    x = _frozen_linear(x.transpose(1, 2), sd["w_raw_in.weight"], sd["w_raw_in.bias"])
     x = x.transpose(0, 1)
     i = 0
     while f"transformer.layers.{i}.linear1.weight" in sd:
         x = transformer_layer(sd, f"transformer.layers.{i}", x)
         i += 1
     x = x.transpose(0, 1)
-    return (F.linear(x, sd["w_out.weight"], sd["w_out.bias"]),
-            F.linear(x, sd["w_aux.weight"], sd["w_aux.bias"]))
+    return (_frozen_linear(x, sd["w_out.weight"], sd["w_out.bias"]),
+            _frozen_linear(x, sd["w_aux.weight"], sd["w_aux.bias"]))
 
 
 # --------------------------------------------------------------------------------------

@@ -32,6 +32,12 @@ extern "C" {
 
 #define STEGAN_ABI_VERSION 1
 int stegan_abi_version(void);
+/* The 2-byte operand type this build of the library rounds matrix-core operands to: "bf16" (libstegan_hip.so) or "f16"
+ * (libstegan_hip_f16.so, the same sources compiled with -DSTEGAN_OPERAND_F16).  Every entry point below whose name or
+ * comment says "bf16" -- the *_h / *_hx conv entry points, stegan_conv_prep_bf16*, the activation images -- means THIS type:
+ * the reference reaches the path through ``torch.autocast(dtype=torch.float16, enabled=cfg.train.mixed_precision)``
+ * (ste_gan/train.py:181,204); BASELINE configs 3 / 4 name bf16, config 5 fp16. */
+const char* stegan_operand_type(void);
 /* Host-only self check of the index helpers (magic division); returns 0 when correct. */
 int stegan_selftest_host(void);
 
@@ -525,6 +531,38 @@ int stegan_adamw_step(float* params, const float* grads, float* exp_avg, float* 
  * writes step-dependent scalars, so eager steps and graph replays may queue arbitrarily far ahead.
  */
 int stegan_adamw_advance(float* hyper_dev, double beta1, double beta2, void* stream);
+
+/*
+ * ---- loss scaling on the device (fp16 operand build; usable with any) -----------------------------------------------------
+ * torch.cuda.amp.GradScaler as the reference drives it -- ONE scaler for both optimisers: scaler.scale(loss_D).backward();
+ * scaler.step(optD); ... scaler.scale(loss_G).backward(); scaler.step(optG); scaler.update()  (ste_gan/train.py:151,198-199,
+ * 266-268) -- with every decision taken on the device, so that a captured step replays it:
+ *   state        device float[8]: [0] scale S, [1] 1 / S, [2] growth tracker (int32 bits), [3] non-finite gradients seen by
+ *                the check of the current optimiser step, [4] ... by any check since the last update, [5] skipped optimiser
+ *                steps so far (int32 bits).  The host initialises {S, 1 / S, 0, ...} once.
+ *   stegan_loss_grad_scale(scale_dev)
+ *                from now on every GRADIENT written by the loss entry points (stegan_pair_loss_*, stegan_multi_td_fwd_bwd*,
+ *                stegan_su_loss_fwd_bwd, stegan_phoneme_ce_fwd_bwd) is multiplied by *scale_dev, read when the kernel runs;
+ *                the loss values are not.  NULL turns it off.  Host-side state of the library (not thread-safe).
+ *   stegan_grad_scaler_check(grads, n, state)
+ *                = the inf / NaN test of scaler.step(): state[3] = state[4] = 1 when any of the n gradients is not finite
+ *                (state[3] is cleared first).  Run it on the gradients the optimiser is about to read, behind the
+ *                data-parallel all-reduce (which spreads a non-finite value to every rank).
+ *   stegan_adamw_advance_s / stegan_adamw_step_zs(..., state)
+ *                as stegan_adamw_advance / stegan_adamw_step_z with gradients multiplied by state[1] (unscale) -- or, when
+ *                state[3] != 0, a skipped step: no parameter, moment or step-count change; the gradients are still zeroed
+ *                when zero_grads is set.  state == NULL: the plain entry points.
+ *   stegan_grad_scaler_update(state, growth_factor, backoff_factor, growth_interval)
+ *                = scaler.update(): S *= backoff_factor and tracker = 0 when state[4] != 0, else ++tracker and S *=
+ *                growth_factor every growth_interval clean iterations (torch defaults: 65536, 2, 0.5, 2000); clears [3], [4].
+ */
+int stegan_loss_grad_scale(const float* scale_dev);
+int stegan_grad_scaler_check(const float* grads, int64_t n, float* state, void* stream);
+int stegan_grad_scaler_update(float* state, float growth_factor, float backoff_factor, int32_t growth_interval, void* stream);
+int stegan_adamw_advance_s(float* hyper_dev, double beta1, double beta2, const float* scaler_state, void* stream);
+int stegan_adamw_step_zs(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper_dev,
+                         float beta1, float beta2, float eps, float weight_decay, float grad_scale, int32_t zero_grads,
+                         const float* scaler_state, void* stream);
 
 /* ---- elementwise helpers of the backward pass --------------------------------------------- */
 /* dx[b,c,t] = dxe[b,c,2t] + dxe[b,c,2t+1]   (backward of nn.Upsample(scale_factor=2), conv.py:40,55) */

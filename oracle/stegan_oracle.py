@@ -53,22 +53,31 @@ PERIODS = (2, 3, 5, 7, 11)      # ste_gan/models/discriminator.py:127,163
 # whose group has fewer than 8 channels on either side (weight gradients: fewer than 16).  With the flag off (the default,
 # and always for the golden fixtures) every function below is the plain fp32 restatement.
 BF16_OPERANDS = False
+OPERAND_DTYPE = torch.bfloat16
 
 
 class bf16_operands:
+    """``with bf16_operands():`` bf16 operands (the build's "bf16" mode); ``with bf16_operands(torch.float16):`` the "f16"
+    mode (libstegan_hip_f16.so) -- same rounding points, the other 2-byte type.  fp16 training also needs the reference's
+    loss scaling: ``train_step(..., scaler=...)``."""
+
+    def __init__(self, dtype: torch.dtype = torch.bfloat16):
+        self.dtype = dtype
+
     def __enter__(self):
-        global BF16_OPERANDS
-        self._old, BF16_OPERANDS = BF16_OPERANDS, True
+        global BF16_OPERANDS, OPERAND_DTYPE
+        self._old = (BF16_OPERANDS, OPERAND_DTYPE)
+        BF16_OPERANDS, OPERAND_DTYPE = True, self.dtype
         return self
 
     def __exit__(self, *exc):
-        global BF16_OPERANDS
-        BF16_OPERANDS = self._old
+        global BF16_OPERANDS, OPERAND_DTYPE
+        BF16_OPERANDS, OPERAND_DTYPE = self._old
         return False
 
 
-def _r(t: Tensor) -> Tensor:
-    return t.to(torch.bfloat16).to(t.dtype)
+def _r(t: Tensor, dtype: Optional[torch.dtype] = None) -> Tensor:
+    return t.to(dtype or OPERAND_DTYPE).to(t.dtype)
 
 
 def _emu_flags(cin: int, cout: int, groups: int) -> Tuple[bool, bool, bool]:
@@ -84,6 +93,7 @@ class _ContractEmu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_eff, bias, w_raw, scale, conv, kw, uniform, flags):
         fwd_b = flags[0]
+        ctx.dtype = OPERAND_DTYPE                  # the backward pass may run after the ``with bf16_operands(...)`` block
         y = conv(_r(x) if fwd_b else x, _r(w_raw) if fwd_b else w_raw, None, **kw)
         shape = (1, -1) + (1,) * (y.dim() - 2)
         if scale is not None:
@@ -98,6 +108,7 @@ class _ContractEmu(torch.autograd.Function):
     def backward(ctx, dy):
         x, w_raw, scale = ctx.saved_tensors
         conv, kw, uniform, (_, bwd_b, wg_b) = ctx.conv, ctx.kw, ctx.uniform, ctx.flags
+        _r = lambda t: globals()["_r"](t, ctx.dtype)
         dx = dw = db = None
         wshape = (-1,) + (1,) * (w_raw.dim() - 1)
         with torch.enable_grad():
@@ -558,7 +569,8 @@ class LossWeights:          # configs/ste_gan_base_gantts.yaml:17-41
 def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_d: AdamWState,
                batch: Dict[str, Tensor], small_d: bool = True,
                speech_feature_type: str = "SPEECH_UNITS", weights: LossWeights = LossWeights(),
-               lr: float = 2e-4, keep_grads: bool = False, grad_sync=None) -> Dict[str, object]:
+               lr: float = 2e-4, keep_grads: bool = False, grad_sync=None,
+               scaler: Optional[Dict[str, float]] = None) -> Dict[str, object]:
     """One iteration of the hot loop, in place on g_sd / d_sd / optimiser state.
 
     Follows ste_gan/train.py:165-268 exactly, including the ordering facts of SURVEY.md 3.3:
@@ -568,7 +580,21 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
     (generator input; == su for Soft-SU), x_real (B,16T,8), sess (B,), phonemes (B,T).
     ``grad_sync(dict of grads) -> dict`` (optional) stands in for the data-parallel gradient average between
     backward and optimiser step (the reference itself is single-process).
+    ``scaler`` (optional): torch.cuda.amp.GradScaler as train.py:151,198-199,266-268 drives it, restated on a dict
+    {"scale", "growth_tracker"} (+ optional "growth_factor" 2, "backoff_factor" 0.5, "growth_interval" 2000), updated in
+    place: both losses are multiplied by the scale before backward, each optimiser step unscales its gradients and is
+    SKIPPED when one of them is not finite, and one update per iteration halves the scale after a skip or doubles it after
+    ``growth_interval`` clean iterations.  out["skipped"] = (D step skipped, G step skipped).
     """
+    S = float(scaler["scale"]) if scaler is not None else 1.0
+    skipped = [False, False]
+
+    def unscale(grads, which):
+        if scaler is None:
+            return grads
+        bad = any(not bool(torch.isfinite(g).all()) for g in grads.values())
+        skipped[which] = bad
+        return None if bad else {k: g / S for k, g in grads.items()}
     out: Dict[str, object] = {}
     g_params = {k: v.detach().requires_grad_(True) for k, v in g_sd.items()}
     d_keys = [k for k in d_sd if not is_sn_buffer(d_sd, k)]
@@ -588,14 +614,16 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
     d_real = discriminator_forward(d_params, x_real, small_d, True, sn)
     d_params.update(sn)
     loss_d = lsgan_loss(d_fake_det, 0.0) + lsgan_loss(d_real, 1.0)
-    d_grads = dict(zip(d_keys, torch.autograd.grad(loss_d, [d_params[k] for k in d_keys])))
+    d_grads = dict(zip(d_keys, torch.autograd.grad(loss_d * S, [d_params[k] for k in d_keys])))
     with torch.no_grad():
         for k in sn:
             d_sd[k] = sn[k].detach().clone()
     trainable = {k: d_sd[k] for k in d_keys}
     if grad_sync is not None:
         d_grads = grad_sync(d_grads)
-    adamw_step(trainable, d_grads, opt_d, lr=lr)
+    d_grads = unscale(d_grads, 0)
+    if d_grads is not None:
+        adamw_step(trainable, d_grads, opt_d, lr=lr)
     out["loss_d"] = float(loss_d)
 
     # ---- generator step (train.py:204-268)
@@ -622,10 +650,22 @@ def train_step(g_sd: SD, d_sd: SD, enc_sd: Optional[SD], opt_g: AdamWState, opt_
     loss_g = loss_g + weights.feat_match * fm
     out["loss_fm"], out["loss_g"] = float(fm), float(loss_g)
     g_keys = list(g_params)
-    g_grads = dict(zip(g_keys, torch.autograd.grad(loss_g, [g_params[k] for k in g_keys])))
+    g_grads = dict(zip(g_keys, torch.autograd.grad(loss_g * S, [g_params[k] for k in g_keys])))
     if grad_sync is not None:
         g_grads = grad_sync(g_grads)
-    adamw_step(g_sd, g_grads, opt_g, lr=lr)
+    g_grads = unscale(g_grads, 1)
+    if g_grads is not None:
+        adamw_step(g_sd, g_grads, opt_g, lr=lr)
+    if scaler is not None:                                     # scaler.update(), train.py:268
+        if skipped[0] or skipped[1]:
+            scaler["scale"] = S * float(scaler.get("backoff_factor", 0.5))
+            scaler["growth_tracker"] = 0
+        else:
+            scaler["growth_tracker"] = int(scaler.get("growth_tracker", 0)) + 1
+            if scaler["growth_tracker"] == int(scaler.get("growth_interval", 2000)):
+                scaler["scale"] = S * float(scaler.get("growth_factor", 2.0))
+                scaler["growth_tracker"] = 0
+    out["skipped"] = tuple(skipped)
     if keep_grads:
         out["g_grads"], out["d_grads"] = g_grads, d_grads
         out["x_pred"] = x_pred.detach()

@@ -10,6 +10,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STEGAN_HIP_LIB", os.path.join(_HERE, "libstegan_hip.so"))   # override: diagnostic builds only
+# the same sources built with fp16 as the matrix-core operand type (csrc/common.h: STEGAN_OPERAND_F16) -- same C ABI
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.environ.get("STEGAN_HIP_LIB_F16", os.path.join(_HERE, "libstegan_hip_f16.so"))}
 ABI_VERSION = 1
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
@@ -36,6 +38,7 @@ _D = C.POINTER(ConvDesc)
 # name -> argtypes; every symbol declared in include/stegan_hip.h must be listed here
 SIGNATURES = {
     "stegan_abi_version": [],
+    "stegan_operand_type": [],
     "stegan_selftest_host": [],
     "stegan_conv1d_fwd": [_D, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data": [_D, _P, _P, _P, _P, _P, _P, _P],
@@ -110,6 +113,11 @@ SIGNATURES = {
     "stegan_conv1d_bwd_data_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
+    "stegan_loss_grad_scale": [_P],
+    "stegan_grad_scaler_check": [_P, _I64, _P, _P],
+    "stegan_grad_scaler_update": [_P, C.c_float, C.c_float, _I32, _P],
+    "stegan_adamw_advance_s": [_P, C.c_double, C.c_double, _P, _P],
+    "stegan_adamw_step_zs": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P, _P],
     "stegan_conv1d_fwd_skinny": [_P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_skinny": [_D, _P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_weight_skinny": [_D, _P, _P, _P, _P, _P, _I64, _P],
@@ -137,20 +145,33 @@ INT64_RETURN = {"stegan_spectral_norm_workspace_floats": [_I32, _I32],
                 "stegan_kernel_timing_count": []}
 
 _lib = None
+_libs = {}
+_operand = "bf16"
 
 
 class SteganHipError(RuntimeError):
     pass
 
 
+def select_operand_type(kind: str) -> None:
+    """Which build of the library ``lib()`` hands out: "bf16" (libstegan_hip.so; also serves the fp32 parity path, whose
+    kernels do not depend on the operand type) or "f16" (libstegan_hip_f16.so).  ops.set_compute_dtype calls this."""
+    global _lib, _operand
+    if kind not in LIB_PATHS:
+        raise ValueError(f"operand type must be one of {sorted(LIB_PATHS)}, got {kind!r}")
+    _operand = kind
+    _lib = _libs.get(kind)
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATHS[_operand]
+        if not os.path.exists(path):
             raise SteganHipError(
-                f"{LIB_PATH} is missing: build it with `python -m ste_gan_amd.build` "
+                f"{path} is missing: build it with `python -m ste_gan_amd.build` "
                 "(ste_gan_amd has no CPU / eager fallback)")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, args in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the .so does not export it
             fn.argtypes = args
@@ -160,7 +181,10 @@ def lib() -> C.CDLL:
             fn.argtypes = args
             fn.restype = C.c_int64
         if handle.stegan_abi_version() != ABI_VERSION:
-            raise SteganHipError("libstegan_hip.so ABI version mismatch: rebuild")
+            raise SteganHipError(f"{path}: ABI version mismatch: rebuild")
+        handle.stegan_operand_type.restype = C.c_char_p
+        if handle.stegan_operand_type().decode() != _operand:
+            raise SteganHipError(f"{path} was built for {handle.stegan_operand_type().decode()} operands, not {_operand}: rebuild")
         # diagnostics (scripts/whatif2.py): STEGAN_SKIP=entry1,entry2 turns those entry points into no-ops that report
         # success -- what would the step cost without them?  RESULTS ARE WRONG when set.
         skip = [n for n in os.environ.get("STEGAN_SKIP", "").split(",") if n]
@@ -176,7 +200,7 @@ def lib() -> C.CDLL:
             for n in skip:
                 getattr(handle, n)              # typo guard: AttributeError for an unknown entry point
             handle = _Skipping(handle, skip)
-        _lib = handle
+        _lib = _libs[_operand] = handle
     return _lib
 
 

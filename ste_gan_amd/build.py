@@ -1,6 +1,8 @@
-"""Builds ste_gan_amd/libstegan_hip.so (gfx950 code objects) in-tree (the oracle is Python: nothing else to compile).
+"""Builds ste_gan_amd/libstegan_hip.so and libstegan_hip_f16.so (gfx950 code objects) in-tree (the oracle is Python: nothing
+else to compile).  Same sources, same C ABI; the second is compiled with -DSTEGAN_OPERAND_F16 -- the 2-byte operand type of
+the matrix-core kernels is fp16 instead of bf16 (csrc/common.h, BASELINE config 5).
 
-hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+hipcc cross-compiles without a GPU; the .so files travel to the GPU box with the repo snapshot.
 """
 from __future__ import annotations
 
@@ -12,6 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstegan_hip.so")
+LIB_F16 = os.path.join(HERE, "libstegan_hip_f16.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -27,13 +30,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "stegan_hip.h"))
-    objs, jobs = [], []
-    for s in srcs:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s[:-4] + ".o")
-        objs.append(obj)
-        if force or _newer(obj, [src] + hdrs):
-            jobs.append([HIPCC, *FLAGS, "-c", src, "-o", obj])
+    variants = [(LIB, ".o", []), (LIB_F16, ".f16.o", ["-DSTEGAN_OPERAND_F16"])]
+    jobs, links = [], []
+    for lib, ext, defs in variants:
+        objs = []
+        for s in srcs:
+            src = os.path.join(CSRC, s)
+            obj = os.path.join(CSRC, s[:-4] + ext)
+            objs.append(obj)
+            if force or _newer(obj, [src] + hdrs):
+                jobs.append([HIPCC, *FLAGS, *defs, "-c", src, "-o", obj])
+        links.append((lib, objs))
+    jobs.sort(key=lambda c: -os.path.getsize(c[-3]))          # the big translation units first
 
     def run(cmd):
         if verbose:
@@ -46,8 +54,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if force or jobs or _newer(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    for lib, objs in links:
+        if force or _newer(lib, objs):
+            run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
     return LIB
 
 

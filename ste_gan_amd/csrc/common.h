@@ -80,10 +80,36 @@ __device__ __forceinline__ void block_sync() {
     __syncthreads();
 }
 
+// THE HALF-PRECISION OPERAND TYPE of the matrix-core kernels: a build parameter of the library.  libstegan_hip.so is built with
+// bf16 operands (BASELINE configs 3 / 4: v_mfma_f32_32x32x16_bf16), libstegan_hip_f16.so from the same sources with
+// -DSTEGAN_OPERAND_F16 (BASELINE config 5, the reference's fp16 autocast: v_mfma_f32_32x32x16_f16, same rate).  Everything
+// that is not the rounding of an operand -- layouts, staging, the packed-halves ReLU (the sign bit is the int16 sign in both
+// formats), fp32 accumulation -- is the same code.  ("bf16" in names below means "the 2-byte operand type".)
+#ifdef STEGAN_OPERAND_F16
+typedef _Float16 hop_t;
+#define STEGAN_MFMA_H(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#define STEGAN_OPERAND_NAME "f16"
+#else
+typedef __bf16 hop_t;
+#define STEGAN_MFMA_H(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#define STEGAN_OPERAND_NAME "bf16"
+#endif
+
+// The value that gets rounded to the operand type is the FP32 value the caller computed.  With fp16 operands hipcc would fuse
+// `(half)(a * b + c)` into v_fma_mixlo_f16, which rounds the EXACT product once -- one ulp of fp16 away from
+// half(float(a * b + c)) in ~1e-4 of the cases, and then the weight copies and images would no longer be "the fp32 tensor,
+// rounded" (what the tests, the oracle's emulation and the fp32 masters all mean).  The empty asm pins the fp32 value.
+__device__ __forceinline__ float hop_src(float f) {
+#ifdef STEGAN_OPERAND_F16
+    asm volatile("" : "+v"(f));
+#endif
+    return f;
+}
+
 // one element of a bf16 activation image [B][CB = ceil(C / 8)][T][8 channels] (include/stegan_hip.h, "ACTIVATION IMAGES"): what
 // the elementwise producers write beside their fp32 output so that the conv kernel behind them stages it by LDS-DMA
 __device__ __forceinline__ void img_store(unsigned short* __restrict__ img, int CB, int T, int b, int c, int t, float v) {
-    img[(((size_t)b * CB + (c >> 3)) * T + t) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    img[(((size_t)b * CB + (c >> 3)) * T + t) * 8 + (c & 7)] = __builtin_bit_cast(unsigned short, (hop_t)hop_src(v));
 }
 
 // wave64 sum

@@ -38,8 +38,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef hop_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef hop_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -601,7 +601,7 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
     _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                            \
         const bf16x8 bj_ = HB_XFRAG(b_[j]);                                                                     \
         _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bj_, a_[i], acc[i][j], 0, 0, 0);                \
+            acc[i][j] = STEGAN_MFMA_H(bj_, a_[i], acc[i][j]);                                                 \
     }
     // one chunk: S k-steps, operands of step s + 1 read from LDS while the MFMAs of step s run
 #define HB_SCHED if constexpr (TM * TN == 1 && SCHED_ON) __builtin_amdgcn_sched_barrier(0);
@@ -913,7 +913,7 @@ struct PrepH {
 };
 
 __device__ __forceinline__ unsigned short to_bf16(float f) {
-    return __builtin_bit_cast(unsigned short, (__bf16)f);
+    return __builtin_bit_cast(unsigned short, (hop_t)hop_src(f));
 }
 
 // Tiled copy: a block reads ROWS output channels x CIT input channels x K taps of the (Cout, Cin_g, K) tensor -- ROWS

@@ -65,7 +65,7 @@ struct DirP {
 };
 
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-    return __builtin_bit_cast(unsigned short, (__bf16)f);
+    return __builtin_bit_cast(unsigned short, (hop_t)hop_src(f));
 }
 
 __device__ __forceinline__ void epilogue_store(const DirP& p, float v, int b, int ch, int to) {

@@ -27,8 +27,8 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef hop_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef hop_t bf16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -434,7 +434,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WH& h, float* __restr
                 const bf16x8 bx_ = XH ? __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, b_[k][j]), relu_fl)) \
                                       : b_[k][j];      /* image path: the input ReLU at the operand */         \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
-                    acc[i][j][k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[i], bx_, acc[i][j][k], 0, 0, 0);  \
+                    acc[i][j][k] = STEGAN_MFMA_H(a_[i], bx_, acc[i][j][k]);                                   \
             }
         bf16x8 aA[TM], bA[KT][TN], aB[TM], bB[KT][TN];
         if (h.NST > 0) WG_READ(aA, bA, 0)

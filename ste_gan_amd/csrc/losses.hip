@@ -6,6 +6,10 @@
 
 namespace {
 
+// Loss scaling (stegan_loss_grad_scale): while set, every GRADIENT a loss entry point writes is multiplied by *g_gscale, read
+// on the device when the kernel runs (so a captured graph follows the scaler's updates); the loss VALUES are not scaled.
+const float* g_gscale = nullptr;
+
 __device__ __forceinline__ float block_sum_256(float v, float* red) {
     v = wave_sum(v);
     block_sync();
@@ -20,9 +24,11 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, const float* __restrict__ b, float target, long n,
                                                int mode, float w_over_n, float* __restrict__ loss_slot,
                                                float* __restrict__ da, int vec, long bid, long nblocks,
+                                               const float* __restrict__ gscale,
                                                long split = (1l << 62), float target2 = 0.f) {
     __shared__ float red[4];
     float s = 0.f;
+    const float gw = gscale ? w_over_n * *gscale : w_over_n;      // the gradient's factor (loss scaling); the value keeps w_over_n
     // HBM-bound (read a, b; write da): 16 bytes per lane when the three arrays are 16-byte aligned
     const long n4 = vec ? (n >> 2) : 0;
     for (long i = bid * 256 + threadIdx.x; i < n4; i += nblocks * 256) {
@@ -35,8 +41,8 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
         float g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (mode == 0) { s += fabsf(d[k]); g[k] = d[k] > 0.f ? w_over_n : (d[k] < 0.f ? -w_over_n : 0.f); }
-            else { s += d[k] * d[k]; g[k] = 2.f * d[k] * w_over_n; }
+            if (mode == 0) { s += fabsf(d[k]); g[k] = d[k] > 0.f ? gw : (d[k] < 0.f ? -gw : 0.f); }
+            else { s += d[k] * d[k]; g[k] = 2.f * d[k] * gw; }
         }
         if (da) reinterpret_cast<float4*>(da)[i] = make_float4(g[0], g[1], g[2], g[3]);
     }
@@ -44,10 +50,10 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
         const float d = a[i] - (b ? b[i] : (i < split ? target : target2));
         if (mode == 0) {
             s += fabsf(d);
-            if (da) da[i] = d > 0.f ? w_over_n : (d < 0.f ? -w_over_n : 0.f);
+            if (da) da[i] = d > 0.f ? gw : (d < 0.f ? -gw : 0.f);
         } else {
             s += d * d;
-            if (da) da[i] = 2.f * d * w_over_n;
+            if (da) da[i] = 2.f * d * gw;
         }
     }
     s = block_sum_256(s, red);
@@ -56,8 +62,9 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
 
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         float target, long n, int mode, float w_over_n,
-                                                        float* __restrict__ loss_slot, float* __restrict__ da, int vec) {
-    pair_loss_body(a, b, target, n, mode, w_over_n, loss_slot, da, vec, blockIdx.x, gridDim.x);
+                                                        float* __restrict__ loss_slot, float* __restrict__ da, int vec,
+                                                        const float* __restrict__ gscale) {
+    pair_loss_body(a, b, target, n, mode, w_over_n, loss_slot, da, vec, blockIdx.x, gridDim.x, gscale);
 }
 
 // Up to PL_MULTI pairs in ONE launch (the ~35 terms of the feature-matching sum, train.py:257-262: one after the other
@@ -66,6 +73,7 @@ constexpr int PL_MULTI = 64;
 struct PairMulti {
     int n, mode;
     float* loss_slot;
+    const float* gscale;
     int first[PL_MULTI + 1];
     struct E { const float* a; const float* b; float* da; long n, split; float w_over_n, target, target2; int vec; } e[PL_MULTI];
 };
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void pair_loss_multi_kernel(const PairMulti m)
     }
     const PairMulti::E& e = m.e[lo];
     pair_loss_body(e.a, e.b, e.target, e.n, m.mode, e.w_over_n, m.loss_slot, e.da, e.vec, (long)blockIdx.x - m.first[lo],
-                   (long)m.first[lo + 1] - m.first[lo], e.split, e.target2);
+                   (long)m.first[lo + 1] - m.first[lo], m.gscale, e.split, e.target2);
 }
 
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -140,7 +148,9 @@ __device__ __forceinline__ void boxN_adjoint(const float* dy, float* dsrc, int T
 __global__ __launch_bounds__(256) void multi_td_kernel(const float* __restrict__ x_real, const float* __restrict__ x_gen,
                                                        int T, int Cc, TDScale s0, TDScale s1, TDScale s2, float weight,
                                                        float* __restrict__ partial, float* __restrict__ dx_gen,
-                                                       int maxF, int AW, float* __restrict__ scratch) {
+                                                       int maxF, int AW, float* __restrict__ scratch,
+                                                       const float* __restrict__ gscale) {
+    if (gscale) weight *= *gscale;       // enters the gradient coefficients only (td_finish_kernel weighs the value)
     extern __shared__ float sm_dyn[];
     // layout: xr, xg, low_r, low_g, rect_r, rect_g, tmp, dlow, drect  (9*T) + frame coefs 4*maxF -- in LDS, or, for rows too
     // long for it (whole-utterance validation), in a global scratch row of the same layout (block-private: the barriers
@@ -320,7 +330,9 @@ __global__ __launch_bounds__(256) void td_finish_kernel(const float* __restrict_
 // speech-unit loss: mean_rows || t - p + eps ||_2 ; one wave per row
 __global__ __launch_bounds__(256) void su_loss_kernel(const float* __restrict__ tgt, const float* __restrict__ pred,
                                                       int rows, int D, float eps, float w_over_rows,
-                                                      float* __restrict__ partial, float* __restrict__ dpred) {
+                                                      float* __restrict__ partial, float* __restrict__ dpred,
+                                                      const float* __restrict__ gscale) {
+    if (gscale) w_over_rows *= *gscale;  // (gradient only: sum_partials_kernel weighs the value)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -341,7 +353,9 @@ __global__ __launch_bounds__(256) void su_loss_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void phoneme_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ target,
                                                          int rows, int P, int silence, float w_over_rows,
                                                          float* __restrict__ partial, int* __restrict__ counters,
-                                                         float* __restrict__ dlogits, long long* __restrict__ argmax_out) {
+                                                         float* __restrict__ dlogits, long long* __restrict__ argmax_out,
+                                                         const float* __restrict__ gscale) {
+    if (gscale) w_over_rows *= *gscale;  // (gradient only)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -395,12 +409,17 @@ inline int nblk(long n) {
 
 }  // namespace
 
+extern "C" int stegan_loss_grad_scale(const float* scale_dev) {
+    g_gscale = scale_dev;
+    return STEGAN_OK;
+}
+
 extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float target, int64_t n, int32_t mode,
                                         float weight, float* loss_slot, float* da, void* stream) {
     STEGAN_CHECK_ARG(a && n > 0 && (mode == 0 || mode == 1));
     const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)da) % 16) == 0;
     hipLaunchKernelGGL(pair_loss_kernel, dim3(nblk(vec ? (n + 3) / 4 : n)), dim3(256), 0, (hipStream_t)stream, a, b, target,
-                       (long)n, mode, weight / (float)n, loss_slot, da, vec);
+                       (long)n, mode, weight / (float)n, loss_slot, da, vec, g_gscale);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }
@@ -413,7 +432,7 @@ extern "C" int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const
     for (int base = 0; base < n; base += PL_MULTI) {
         PairMulti m;
         m.n = n - base < PL_MULTI ? n - base : PL_MULTI;
-        m.mode = mode; m.loss_slot = loss_slot;
+        m.mode = mode; m.loss_slot = loss_slot; m.gscale = g_gscale;
         int blocks = 0;
         for (int i = 0; i < m.n; ++i) {
             const int j = base + i;
@@ -540,7 +559,7 @@ extern "C" int stegan_multi_td_fwd_bwd_ex(const float* x_real, const float* x_ge
         attr_set = true;
     }
     hipLaunchKernelGGL(multi_td_kernel, dim3(B * C), dim3(256), lds, s, x_real, x_gen, T, C, sc[0], sc[1], sc[2], weight,
-                       workspace, dx_gen, maxF, avg_window, scr);
+                       workspace, dx_gen, maxF, avg_window, scr, g_gscale);
     hipLaunchKernelGGL(td_finish_kernel, dim3(1), dim3(256), 0, s, workspace, B * C, weight, loss_slot, per_scale);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
@@ -600,7 +619,7 @@ extern "C" int stegan_su_loss_fwd_bwd(const float* target, const float* pred, in
     STEGAN_CHECK_ARG(target && pred && loss_slot && workspace && rows > 0 && D > 0);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(su_loss_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, target, pred, rows, D, 1e-6f,
-                       weight / (float)rows, workspace, dpred);
+                       weight / (float)rows, workspace, dpred, g_gscale);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, rows, weight / (float)rows, loss_slot);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
@@ -612,7 +631,8 @@ extern "C" int stegan_phoneme_ce_fwd_bwd(const float* logits, const int64_t* tar
     STEGAN_CHECK_ARG(logits && targets && loss_slot && workspace && rows > 0 && P > 0 && P <= 64);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(phoneme_ce_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, logits, (const long long*)targets,
-                       rows, P, silence_index, weight / (float)rows, workspace, counters, dlogits, (long long*)argmax_out);
+                       rows, P, silence_index, weight / (float)rows, workspace, counters, dlogits, (long long*)argmax_out,
+                       g_gscale);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, workspace, rows, weight / (float)rows, loss_slot);
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;

@@ -200,6 +200,7 @@ extern "C" int stegan_fold_upsample2(const float* dxe, float* dx, int64_t rows, 
 }
 
 extern "C" int stegan_abi_version(void) { return STEGAN_ABI_VERSION; }
+extern "C" const char* stegan_operand_type(void) { return STEGAN_OPERAND_NAME; }
 
 extern "C" int stegan_selftest_host(void) {
     // magic division must be exact for every divisor / dividend range the kernels use

@@ -127,8 +127,8 @@ class ConvProfiler:
         activations and their gradients read as bf16 images (2 B; 4 B in fp32 mode), weights 2 B (4 B), results written as
         fp32 plus -- in bf16 mode -- the bf16 image for the next layer (6 B); weight gradients fp32."""
         mode, B, Cin, Cout, K, stride, dil, groups, up, Tin, Tout = shape[:11]
-        e = 2 if COMPUTE_DTYPE == "bf16" else 4
-        o = 6 if COMPUTE_DTYPE == "bf16" else 4
+        e = 2 if HALF else 4
+        o = 6 if HALF else 4
         w, x, y = Cout * (Cin // groups) * K, B * Cin * Tin, B * Cout * Tout
         if mode == 0:
             return e * (x + w) + o * y
@@ -216,30 +216,40 @@ def _workspace(device, floats: int) -> Tensor:
 
 WEIGHT_EPOCH = 0      # bumped by every FusedAdamW launch: prepared (transposed) weight copies older than this are stale
 
-# Arithmetic type of the convolution operands: "f32" (the parity path: exact fp32 MFMA) or "bf16" (BASELINE configs 3-5:
-# both operands rounded to bf16 while they are staged, fp32 accumulation, fp32 activations / master weights / optimiser
-# state -- csrc/conv_bf16.hip).  The reference reaches its reduced-precision path through ``cfg.train.mixed_precision``
-# (torch.autocast, train.py:151,181,204); the trainer maps that flag onto this switch.
+# Arithmetic type of the convolution operands: "f32" (the parity path: exact fp32 MFMA), "bf16" (BASELINE configs 3 / 4) or
+# "f16" (BASELINE config 5, the reference's own autocast dtype): both operands rounded to the 2-byte type while they are
+# staged, fp32 accumulation, fp32 activations / master weights / optimiser state -- csrc/conv_bf16.hip, whose operand type is
+# a build parameter: "f16" loads libstegan_hip_f16.so (same sources, same C ABI; _lib.select_operand_type).  The reference
+# reaches its reduced-precision path through ``cfg.train.mixed_precision`` (torch.autocast, train.py:151,181,204); the
+# trainer maps that flag (and ``cfg.train.mixed_precision_dtype``) onto this switch.  fp16's 5-bit exponent needs the
+# reference's loss scaling too: train.GradScaler (GradScaler semantics on the device, train.py:151,198-199,266-268).
+# Everything named "bf16" below serves both 2-byte types; HALF says one of them is on, HALF_DTYPE is its torch dtype.
 COMPUTE_DTYPE = "f32"
+HALF = False
+HALF_DTYPE = torch.bfloat16
 
 
 def set_compute_dtype(name: str) -> None:
-    global COMPUTE_DTYPE
-    if name not in ("f32", "bf16"):
-        raise ValueError(f"compute dtype must be 'f32' or 'bf16', got {name!r}")
+    global COMPUTE_DTYPE, HALF, HALF_DTYPE
+    if name not in ("f32", "bf16", "f16"):
+        raise ValueError(f"compute dtype must be 'f32', 'bf16' or 'f16', got {name!r}")
     if name != COMPUTE_DTYPE:
         COMPUTE_DTYPE = name
-        bump_weight_epoch()            # prepared weight copies carry (or lack) their bf16 companions per mode
+        HALF = name != "f32"
+        if HALF:
+            HALF_DTYPE = torch.float16 if name == "f16" else torch.bfloat16
+        _lib.select_operand_type(name if HALF else "bf16")     # (the fp32 path's kernels are the same in both builds)
+        bump_weight_epoch()            # prepared weight copies carry (or lack) their 2-byte companions per mode
 
 
 def bf16_enabled() -> bool:
-    return COMPUTE_DTYPE == "bf16"
+    return HALF
 
 
 def _bf16_of(w: Optional[Tensor]) -> Optional[Tensor]:
     """The bf16 companion of a prepared fp32 weight copy (attribute ``h``, attached by prep_weights / ConvPack), or None
     in fp32 mode."""
-    return getattr(w, "h", None) if (w is not None and COMPUTE_DTYPE == "bf16") else None
+    return getattr(w, "h", None) if (w is not None and HALF) else None
 
 
 # ---- bf16 activation images (round 3) -------------------------------------------------------------------------------
@@ -256,8 +266,8 @@ def _image_of(t: Optional[Tensor], channels: int, length: int) -> Optional[Tenso
     """The bf16 image attached to ``t`` when it matches (B, ceil(C/8), T, 8) AND ``t`` has not been written in place since
     the image was attached (autograd's gradient buffers add_ into the tensor they hold when it is the last reference; a
     user's in-place op does the same): the image would then show the old values.  Else None."""
-    h = getattr(t, "h", None) if (t is not None and IMAGES and COMPUTE_DTYPE == "bf16") else None
-    if h is None or h.dtype != torch.bfloat16 or not h.is_contiguous():
+    h = getattr(t, "h", None) if (t is not None and IMAGES and HALF) else None
+    if h is None or h.dtype != HALF_DTYPE or not h.is_contiguous():
         return None
     if tuple(h.shape) != (t.shape[0], (channels + 7) // 8, length, 8) or h.device != t.device:
         return None
@@ -282,9 +292,9 @@ def _attach_image(t: Tensor, h: Optional[Tensor]) -> None:
 def _new_image(like: Tensor, channels: int, groups: int, length: int) -> Optional[Tensor]:
     """An empty image for a (B, channels, length) output, or None when the layer does not qualify (whole 8-channel blocks
     per group) or images are off."""
-    if not (IMAGES and COMPUTE_DTYPE == "bf16") or channels % 8 or (channels // groups) % 8 or channels < 16:
+    if not (IMAGES and HALF) or channels % 8 or (channels // groups) % 8 or channels < 16:
         return None
-    return torch.empty((like.shape[0], channels // 8, length, 8), device=like.device, dtype=torch.bfloat16)
+    return torch.empty((like.shape[0], channels // 8, length, 8), device=like.device, dtype=HALF_DTYPE)
 
 
 # ---- zeroed scratch for one train step ---------------------------------------------------------------------------------
@@ -396,13 +406,13 @@ def prep_weights(w3: Tensor, cfg: ConvCfg, bufs=None, scale: Optional[Tensor] = 
     # bf16 mode keeps ONLY the bf16 copies current (the fp32 buffers then merely carry them as ``.h``): every conv runs on
     # the bf16 or the single-output-channel kernels, and a shape both decline goes to the implicit-GEMM kernel, which reads
     # the raw tensor -- conv1d_fwd / conv1d_bwd_data never hand the fp32 copies to a kernel in that mode
-    if COMPUTE_DTYPE != "bf16":
+    if not HALF:
         check(L.stegan_conv_prep(C.byref(d), _p(w3), _p(scale), _p(bufs[0]), _p(bufs[1]), _stream()), "stegan_conv_prep")
-    if COMPUTE_DTYPE == "bf16":
+    if HALF:
         for which, b in enumerate(bufs):
             if getattr(b, "h", None) is None:
                 # zeroed ONCE: the prep kernel writes live elements only (padding rows / channels / the zero tap plane stay 0)
-                b.h = torch.zeros(int(L.stegan_conv_prep_bf16_elems(C.byref(d), which)), device=w3.device, dtype=torch.bfloat16)
+                b.h = torch.zeros(int(L.stegan_conv_prep_bf16_elems(C.byref(d), which)), device=w3.device, dtype=HALF_DTYPE)
         check(L.stegan_conv_prep_bf16(C.byref(d), _p(w3), _p(scale), _p(bufs[0].h), _p(bufs[1].h), _stream()),
               "stegan_conv_prep_bf16")
     return bufs
@@ -477,7 +487,7 @@ def conv1d_fwd(x: Tensor, w: Tensor, scale: Optional[Tensor], bias: Optional[Ten
             check(rc, "stegan_conv1d_fwd_hx")
             _attach_image(y, yh)
             return y
-    if wf is not None and COMPUTE_DTYPE != "bf16":       # (bf16 mode does not maintain the fp32 copies: prep_weights)
+    if wf is not None and not HALF:       # (bf16 mode does not maintain the fp32 copies: prep_weights)
         ws = _workspace(x.device, y.numel() * _SPLITK_MAX)
         rc = _timed(d, 0, lambda: _lib.lib().stegan_conv1d_fwd_t(C.byref(d), _p(x), _p(wf), _p(scale), _p(bias),
                                                                  _p(residual), _p(y), _p(ws), ws.numel(), _stream()),
@@ -550,7 +560,7 @@ def conv1d_bwd_data(dy: Tensor, w: Tensor, scale: Optional[Tensor], mask_src: Op
             check(rc, "stegan_conv1d_bwd_data_hx")
             _attach_image(dx, dxh)
             return dx
-    if wb is not None and COMPUTE_DTYPE != "bf16":
+    if wb is not None and not HALF:
         ws = _workspace(dy.device, dx.numel() * _SPLITK_MAX)
         us = scale if uniform_scale else None
         rc = _timed(d, 1, lambda: _lib.lib().stegan_conv1d_bwd_data_t(C.byref(d), _p(dy), _p(wb), _p(us), _p(mask_src),
@@ -606,7 +616,7 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
         if rc != 1:
             check(rc, "stegan_conv1d_bwd_weight_skinny")
             return
-    if COMPUTE_DTYPE == "bf16":
+    if HALF:
         xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
         if IMG_STATS is not None:
             IMG_STATS.setdefault((2, xh is not None and dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
@@ -656,7 +666,7 @@ _WG_NEXT = [0]
 
 
 def wgrad_async(on: bool) -> None:
-    _WG_ON[0] = bool(on) and WGRAD_STREAMS > 0 and (COMPUTE_DTYPE == "bf16" or F32_STREAMS)
+    _WG_ON[0] = bool(on) and WGRAD_STREAMS > 0 and (HALF or F32_STREAMS)
 
 
 F32_STREAMS = os.environ.get("STEGAN_F32_STREAMS", "1") == "1"      # the discriminator fork and the generator's weight-gradient
@@ -880,7 +890,7 @@ def new_act_fuse() -> Optional["ActFuse"]:
     activation derivatives, as autograd's general contract needs."""
     # (bf16 mode only: the fp32 kernels have no such epilogue -- they would run per problem and post-apply the derivative,
     # more launches than the layers' own act_bwd)
-    return ActFuse() if (ACT_FUSE and _ACT_FUSE_SCOPE[0] > 0 and torch.is_grad_enabled() and COMPUTE_DTYPE == "bf16") else None
+    return ActFuse() if (ACT_FUSE and _ACT_FUSE_SCOPE[0] > 0 and torch.is_grad_enabled() and HALF) else None
 
 
 def _ptr_array(items):
@@ -920,7 +930,7 @@ def conv1d_fwd_multi(xs, cfgs, wfs, scales, biases, raws=None):
                 _attach_image(y, yh)
             return ys
         return None                     # per-problem launches (each picks bf16 or fp32 on its own)
-    if COMPUTE_DTYPE == "bf16":
+    if HALF:
         return None                     # (the fp32 copies are not maintained in bf16 mode)
     rc = _lib.lib().stegan_conv1d_fwd_multi(n, dptr, _ptr_array(xs), _ptr_array(wfs), _ptr_array(scales), _ptr_array(biases),
                                             None, _ptr_array(ys), _stream())
@@ -971,7 +981,7 @@ def conv1d_bwd_data_multi(dys, cfgs, wbs, tins, raws=None, scales=None, act_srcs
                 _attach_image(t, th)
             return dxs
         return None
-    if COMPUTE_DTYPE == "bf16" or fuse:
+    if HALF or fuse:
         return None
     rc = _lib.lib().stegan_conv1d_bwd_data_multi(n, dptr, _ptr_array(dys), _ptr_array(wbs), None, None, _ptr_array(dxs),
                                                  _stream())

@@ -169,8 +169,8 @@ class ConvPack:
             nf, nb = int(L.stegan_conv_prep_bf16_elems(C.byref(d), 0)), int(L.stegan_conv_prep_bf16_elems(C.byref(d), 1))
             if c.cfg.k >= 48:
                 raise ValueError("ste_gan_amd: bf16 weight copies support kernel sizes < 48")
-            wf.h = torch.zeros(nf, device=dev, dtype=torch.bfloat16)     # zero ONCE: the prep kernel writes live elements only
-            wb.h = torch.zeros(nb, device=dev, dtype=torch.bfloat16)
+            wf.h = torch.zeros(nf, device=dev, dtype=ops.HALF_DTYPE)     # zero ONCE: the prep kernel writes live elements only
+            wb.h = torch.zeros(nb, device=dev, dtype=ops.HALF_DTYPE)
             G = c.cfg.groups
             cog, cig, K = c.cfg.cout // G, c.cfg.cin // G, c.cfg.k
             up = lambda a, b: (a + b - 1) // b * b
@@ -180,6 +180,7 @@ class ConvPack:
         raw = b"".join(struct.pack("<4q8i2q", *r) for r in rows)
         self.t_prep_h = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.prep_h_blocks = max(1, min(4096, most))              # tiles of the largest conv (grid-stride beyond that)
+        self._h_dtype = ops.HALF_DTYPE
 
     def prepare(self):
         """Scales + transposed copies for the CURRENT weights (2 launches for the whole network; 3 in bf16 mode)."""
@@ -196,7 +197,7 @@ class ConvPack:
         if not ops.bf16_enabled():          # bf16 mode maintains only the bf16 copies (ops.prep_weights)
             check(L.stegan_conv_prep_multi(self.n, P(self.t_prep), self.max_tiles, s), "stegan_conv_prep_multi")
         if ops.bf16_enabled():
-            if self.t_prep_h is None:
+            if self.t_prep_h is None or self._h_dtype != ops.HALF_DTYPE:
                 self._build_bf16_table()
             check(L.stegan_conv_prep_bf16_multi(self.n, P(self.t_prep_h), self.prep_h_blocks, s), "stegan_conv_prep_bf16_multi")
         self.prepared_version = key
@@ -289,32 +290,44 @@ class FusedAdamW:
         self.step_count = 0
         self._set_device_step(0)
 
-    def stage_hyper(self):
-        """Advance the step counter and the bias corrections on the device (one tiny launch, graph-capturable)."""
+    def stage_hyper(self, scaler: "GradScaler" = None):
+        """Advance the step counter and the bias corrections on the device (one tiny launch, graph-capturable).  With a
+        ``scaler`` the device decides whether this step counts (skip on non-finite gradients); ``step_count`` on the host
+        then counts ATTEMPTED steps -- ``device_step_count()`` reads the applied ones."""
         self.step_count += 1
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
-        check(_lib.lib().stegan_adamw_advance(C.c_void_p(self._hyper.data_ptr()), float(self.betas[0]), float(self.betas[1]),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_advance")
+        check(_lib.lib().stegan_adamw_advance_s(C.c_void_p(self._hyper.data_ptr()), float(self.betas[0]), float(self.betas[1]),
+                                                C.c_void_p(scaler.state.data_ptr()) if scaler is not None else None,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_advance_s")
 
-    def launch(self, grad_scale: float = 1.0):
+    def device_step_count(self) -> int:
+        """The step count the device holds (a host sync): differs from ``step_count`` by the steps a GradScaler skipped."""
+        return int(self._hyper.view(torch.int32)[3].item())
+
+    def launch(self, grad_scale: float = 1.0, scaler: "GradScaler" = None):
         f = self.flat
-        check(_lib.lib().stegan_adamw_step_z(
+        check(_lib.lib().stegan_adamw_step_zs(
             C.c_void_p(f.flat.data_ptr()), C.c_void_p(f.grad.data_ptr()), C.c_void_p(self.exp_avg.data_ptr()),
             C.c_void_p(self.exp_avg_sq.data_ptr()), f.numel, C.c_void_p(self._hyper.data_ptr()),
             self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale, int(f.zero_in_step),
-            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step_z")
+            C.c_void_p(scaler.state.data_ptr()) if scaler is not None else None,
+            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_adamw_step_zs")
         self.flat.clean = bool(f.zero_in_step)      # (zero-on-consume: .grad reads 0 from here on, see set_zero_in_step)
         self.flat.epoch += 1           # parameters changed behind torch's back: this network's prepared copies are stale
         if self.pack is not None:
             self.pack.invalidate()
 
-    def step(self, grad_scale: float = 1.0, finalized: bool = False):
+    def step(self, grad_scale: float = 1.0, finalized: bool = False, scaler: "GradScaler" = None):
+        """``scaler`` (GradScaler below) = ``scaler.step(optimizer)`` of the reference (train.py:198, 266): the gradients are
+        tested for inf / NaN and unscaled inside the AdamW kernel, or the whole step is skipped -- all on the device."""
         if not finalized:
             self.finalize_grads()
         self.flat.gather_grads()
-        self.stage_hyper()
-        self.launch(grad_scale)
+        if scaler is not None:
+            scaler.check(self.flat.grad)
+        self.stage_hyper(scaler)
+        self.launch(grad_scale, scaler)
 
     # ---- torch.optim.AdamW compatible checkpoint format -------------------------------------
     def state_dict(self):
@@ -349,6 +362,66 @@ class FusedAdamW:
         self.step_count = steps.pop() if steps else 0
         self._set_device_step(self.step_count)
         self._lr_on_device = None
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler as ste_gan/train.py:151,198-199,266-268 drives it, with its state and every decision on the
+    device (include/stegan_hip.h, "loss scaling on the device") so that a captured train step replays it:
+
+        scaler.attach()                       # the loss kernels multiply the gradients they write by the scale
+        ... loss_D.backward() ...; optD.step(scaler=scaler)        # = scaler.scale(loss_D).backward(); scaler.step(optD)
+        ... loss_G.backward() ...; optG.step(scaler=scaler)
+        scaler.update()                       # once per iteration: back off after a skipped step, grow every `interval`
+
+    Needed by the fp16 operand mode (gradients below 6e-8 vanish when they are rounded to fp16 operands, above 65504 they
+    become inf); in the fp32 and bf16 modes a power-of-two scale is exact and changes nothing."""
+
+    def __init__(self, device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.state = torch.zeros(8, device=device, dtype=torch.float32)
+        self._set(float(init_scale), 0)
+        self._attached_to = None
+
+    def _set(self, scale: float, tracker: int):
+        self.state[0:2] = torch.tensor([scale, 1.0 / scale], dtype=torch.float32)
+        self.state.view(torch.int32)[2:3].fill_(int(tracker))
+
+    def attach(self) -> None:
+        lib = _lib.lib()
+        check(lib.stegan_loss_grad_scale(C.c_void_p(self.state.data_ptr())), "stegan_loss_grad_scale")
+        self._attached_to = lib
+
+    def detach(self) -> None:
+        if self._attached_to is not None:
+            self._attached_to.stegan_loss_grad_scale(None)
+            self._attached_to = None
+
+    def check(self, grads: torch.Tensor) -> None:
+        check(_lib.lib().stegan_grad_scaler_check(C.c_void_p(grads.data_ptr()), grads.numel(), C.c_void_p(self.state.data_ptr()),
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "stegan_grad_scaler_check")
+
+    def update(self) -> None:
+        check(_lib.lib().stegan_grad_scaler_update(C.c_void_p(self.state.data_ptr()), self.growth_factor, self.backoff_factor,
+                                                   self.growth_interval, C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              "stegan_grad_scaler_update")
+
+    # ---- host views (each a device sync: logging, checkpoints, tests)
+    def get_scale(self) -> float:
+        return float(self.state[0].item())
+
+    def skipped_steps(self) -> int:
+        return int(self.state.view(torch.int32)[5].item())
+
+    def state_dict(self):
+        """Same keys as torch.cuda.amp.GradScaler.state_dict()."""
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self.state.view(torch.int32)[2].item())}
+
+    def load_state_dict(self, sd):
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+        self._set(float(sd["scale"]), int(sd["_growth_tracker"]))
 
 
 class ExponentialLR:

@@ -72,8 +72,15 @@ class GANTrainStep:
     """One iteration of ``ste_gan/train.py:165-268`` on one GPU (one rank of a data-parallel job)."""
 
     def __init__(self, cfg, netG, netD, emg_encoder_loss: Optional[EMGEncoderLoss], multi_td_loss,
-                 optG: FusedAdamW, optD: FusedAdamW, process_group=None):
+                 optG: FusedAdamW, optD: FusedAdamW, process_group=None, scaler=None):
+        """``scaler`` (optim.GradScaler): the reference's loss scaling (train.py:151,198-199,266-268), decided on the device.
+        The fp16 operand mode gets one by default (torch's defaults: 65536, x2 every 2000 clean iterations, /2 after a
+        skipped step); in the fp32 / bf16 modes a power-of-two scale is exact and none is made."""
         self.cfg = cfg
+        if scaler is None and ops.COMPUTE_DTYPE == "f16":
+            from .optim import GradScaler
+            scaler = GradScaler(optG.flat.flat.device)
+        self.scaler = scaler
         self.netG, self.netD = netG, netD
         self.emg_encoder_loss, self.multi_td_loss = emg_encoder_loss, multi_td_loss
         self.optG, self.optD = optG, optD
@@ -125,6 +132,8 @@ class GANTrainStep:
         ops.zero_pool_abort()
         ops.wgrad_abort()
         self._st = None
+        if self.scaler is not None:
+            self.scaler.detach()
         for opt in (self.optG, self.optD):
             opt.discard_grads()
 
@@ -143,6 +152,8 @@ class GANTrainStep:
 
     def phase_d(self, batch_dict: Dict[str, torch.Tensor]) -> None:
         """Generator forward, the D-independent losses (side stream), the discriminator step up to its gradients."""
+        if self.scaler is not None:
+            self.scaler.attach()               # host side: the loss kernels launched from here on scale the gradients they write
         self._p_fwd(batch_dict)
         st = self._st
         # ---- D-independent generator losses (multi-TD, frozen EMG encoder) and THEIR gradient w.r.t. the generated EMG.
@@ -314,9 +325,9 @@ class GANTrainStep:
         if t.loss_adversarial:
             if self.comm is not None:
                 self.comm.wait(getattr(self, "_d_handle", None))
-                self.optD.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
+                self.optD.step(grad_scale=1.0 / self.comm.world_size, finalized=True, scaler=self.scaler)
             else:
-                self.optD.step(finalized=True)                                           # D weights change HERE
+                self.optD.step(finalized=True, scaler=self.scaler)                       # D weights change HERE
             ops.mark("D optimiser done")
 
         # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
@@ -413,12 +424,16 @@ class GANTrainStep:
         """The generator's optimiser step (after its gradient exchange)."""
         if self.comm is not None:
             self.comm.wait(getattr(self, "_g_handle", None))
-            self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True)
+            self.optG.step(grad_scale=1.0 / self.comm.world_size, finalized=True, scaler=self.scaler)
         else:
-            self.optG.step(finalized=True)
+            self.optG.step(finalized=True, scaler=self.scaler)
         ops.mark("G optimiser done")
         ops.zero_pool_end()
         out = self._st["out"]
+        if self.scaler is not None:
+            self.scaler.update()                                   # once per iteration, behind both steps (train.py:268)
+            self.scaler.detach()
+            out["loss_scale"] = self.scaler.state[0]               # (a view of the live state: the scale of the NEXT step)
         self._st = None                     # drop the step's tensors
         self.last = out
         return out
@@ -687,7 +702,13 @@ def train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debug
     """``cfg.train.mixed_precision`` selects the compute mode for the duration of the run (see the module docstring);
     the mode in force before the call is restored afterwards.  Everything else: :func:`_train`."""
     previous = ops.COMPUTE_DTYPE
-    ops.set_compute_dtype("bf16" if bool(cfg.train.get("mixed_precision", False)) else "f32")
+    # cfg.train.mixed_precision is the reference's switch (fp16 autocast + GradScaler, train.py:151,181,204); which 2-byte
+    # operand type it means here: cfg.train.mixed_precision_dtype = "bf16" (default: BASELINE configs 3 / 4, no loss scaling
+    # needed) or "f16" (BASELINE config 5: fp16 operands + the device-side GradScaler)
+    half = str(cfg.train.get("mixed_precision_dtype", "bf16"))
+    if half not in ("bf16", "f16"):
+        raise ValueError(f"cfg.train.mixed_precision_dtype must be 'bf16' or 'f16', got {half!r}")
+    ops.set_compute_dtype(half if bool(cfg.train.get("mixed_precision", False)) else "f32")
     try:
         return _train(cfg, model_directory, checkpoint, torch_device, debug, emg_enc_ckpt, loaders)
     finally:

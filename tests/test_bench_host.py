@@ -74,15 +74,15 @@ def test_committed_counter_summaries_carry_the_fields_bench_reads():
 
 def test_conv_profiler_algorithmic_bytes():
     from ste_gan_amd import ops
-    old = ops.COMPUTE_DTYPE
+    old = (ops.COMPUTE_DTYPE, ops.HALF)
     try:
         shape = (0, 64, 768, 768, 3, 1, 1, 1, 1, 12, 12, 1, 0, 0)          # forward 768 -> 768, k3, T = 12
         x = y = 64 * 768 * 12
         w = 768 * 768 * 3
-        ops.COMPUTE_DTYPE = "bf16"
+        ops.COMPUTE_DTYPE, ops.HALF = "bf16", True
         assert ops.ConvProfiler.alg_bytes(shape) == 2 * (x + w) + 6 * y    # bf16 operands, fp32 + image result
         assert ops.ConvProfiler.alg_bytes((2,) + shape[1:]) == 2 * (x + y) + 4 * w
-        ops.COMPUTE_DTYPE = "f32"
+        ops.COMPUTE_DTYPE, ops.HALF = "f32", False
         assert ops.ConvProfiler.alg_bytes((1,) + shape[1:]) == 4 * (y + w) + 4 * x
     finally:
-        ops.COMPUTE_DTYPE = old
+        ops.COMPUTE_DTYPE, ops.HALF = old

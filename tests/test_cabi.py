@@ -9,16 +9,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "stegan_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(stegan_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t|const char\*)\s+(stegan_\w+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported_and_bound():
     from ste_gan_amd import _lib
     syms = declared_symbols()
     assert len(syms) >= 30
-    handle = ctypes.CDLL(_lib.LIB_PATH)
-    for s in syms:
-        assert hasattr(handle, s), f"{s} declared in include/stegan_hip.h but not exported by libstegan_hip.so"
+    for kind, path in _lib.LIB_PATHS.items():                  # the bf16 and the fp16 build of the same sources
+        handle = ctypes.CDLL(path)
+        for s in syms:
+            assert hasattr(handle, s), f"{s} declared in include/stegan_hip.h but not exported by {os.path.basename(path)}"
+        handle.stegan_operand_type.restype = ctypes.c_char_p
+        assert handle.stegan_operand_type().decode() == kind
     bound = set(_lib.SIGNATURES) | set(_lib.INT64_RETURN)
     assert set(syms) == bound, f"ctypes binding out of sync with the header: {set(syms) ^ bound}"
 
@@ -29,11 +32,12 @@ def test_every_exported_entry_point_is_declared():
     import subprocess
     from ste_gan_amd import _lib
     nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
-    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("stegan_")}
-    assert exported, "no stegan_* symbols found"
-    undeclared = exported - set(declared_symbols())
-    assert not undeclared, f"exported but not declared in include/stegan_hip.h: {sorted(undeclared)}"
+    for path in _lib.LIB_PATHS.values():
+        out = subprocess.run([nm, "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("stegan_")}
+        assert exported, "no stegan_* symbols found"
+        undeclared = exported - set(declared_symbols())
+        assert not undeclared, f"{os.path.basename(path)} exports what include/stegan_hip.h does not declare: {sorted(undeclared)}"
 
 
 def test_library_loads_and_selftest():

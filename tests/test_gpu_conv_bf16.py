@@ -13,6 +13,14 @@ from test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
+# the 2-byte operand type under test: tests/test_gpu_conv_f16.py re-runs this module's kernel tests with ("f16", torch.float16)
+# (libstegan_hip_f16.so: the same sources built with fp16 operands)
+OPERAND = ("bf16", torch.bfloat16)
+# tolerance of the comparison with the fp64 contraction of rounded operands, relative to the result's scale: what the fp32
+# accumulation inside the MFMA leaves.  (fp16 products carry 22 significant bits against bf16's 16, so the MFMA's fp32 sums
+# round more of them away: the f16 module runs with 2x this.)
+TOL = 2e-5
+
 EXTRA = [
     (64, 96, 96, 3, 1, 27, 27, 1, 1, True, 192),     # 128 x 128 tiles, d = 27 halo, N = 12288
     (64, 192, 96, 3, 1, 1, 1, 1, 2, True, 96),       # upsample, 128-column tiles
@@ -32,7 +40,7 @@ RAGGED = [c for c in CASES + EXTRA if c[10] % 4 != 0 and c[1] // c[7] >= 8 and c
 
 
 def bf16r(t):
-    return t.to(torch.bfloat16).to(torch.float64)
+    return t.to(OPERAND[1]).to(torch.float64)
 
 
 def make_image(t):
@@ -41,7 +49,7 @@ def make_image(t):
     CB = (C + 7) // 8
     full = torch.zeros(B, CB * 8, T, device=t.device, dtype=t.dtype)
     full[:, :C] = t
-    return full.view(B, CB, 8, T).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+    return full.view(B, CB, 8, T).permute(0, 1, 3, 2).contiguous().to(OPERAND[1])
 
 
 @pytest.mark.parametrize("cfg", CASES + EXTRA, ids=lambda c: "x".join(map(str, c)))
@@ -90,10 +98,10 @@ def test_conv_bf16_fwd_bwd_data(cfg, images=False):
 
     dev = "cuda"
     xg, wg, sg, bg, rg, dyg, addg = (t.to(dev) for t in (x, w, scale, bias, res, dy, add))
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         wf, wb = ops.prep_weights(wg, c, None, sg)
-        assert wf.h.dtype == torch.bfloat16 and wb.h is not None
+        assert wf.h.dtype == OPERAND[1] and wb.h is not None
         if images:
             ops._attach_image(xg, make_image(xg)); ops._attach_image(dyg, make_image(dyg))
             assert ops._image_of(xg, Cin, Tin) is not None
@@ -115,7 +123,7 @@ def test_conv_bf16_fwd_bwd_data(cfg, images=False):
         got = got.double().cpu()
         scale_ = float(f32.abs().max())
         if kern == "bf16":
-            assert float((got - ref).abs().max()) <= 2e-5 * scale_, (kern, float((got - ref).abs().max()), scale_)
+            assert float((got - ref).abs().max()) <= TOL * scale_, (kern, float((got - ref).abs().max()), scale_)
             assert float((got - f32).abs().max()) <= 3e-2 * scale_
         else:                                             # shape left to the exact fp32 kernel
             assert float((got - f32).abs().max()) <= 2e-5 * scale_
@@ -158,7 +166,7 @@ def test_conv_bf16_bwd_weight(cfg, images=False):
     db_ref = dy.double().sum((0, 2))
     dw = torch.full((Cout, Cin // g, K), 0.25, device="cuda")
     db = torch.full((Cout,), -1.0, device="cuda")
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         xg, dyg = x.cuda(), dy.cuda()
         if images:
@@ -176,7 +184,7 @@ def test_conv_bf16_bwd_weight(cfg, images=False):
     got = dw.double().cpu() - 0.25
     scale_ = float(dw_f32.abs().max())
     if kern == "bf16":
-        assert float((got - dw_ref).abs().max()) <= 3e-5 * scale_ + 1e-6, (float((got - dw_ref).abs().max()), scale_)
+        assert float((got - dw_ref).abs().max()) <= 1.5 * TOL * scale_ + 1e-6, (float((got - dw_ref).abs().max()), scale_)
         assert float((got - dw_f32).abs().max()) <= 3e-2 * scale_
     else:
         assert float((got - dw_f32).abs().max()) <= 1e-4 * scale_
@@ -191,7 +199,7 @@ def test_prep_bf16_layout():
     gen = torch.Generator().manual_seed(5)
     w = torch.randn(Cout, Cin // g, K, generator=gen)
     sc = 0.5 + torch.rand(Cout, generator=gen)
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         wf, wb = ops.prep_weights(w.cuda(), c, None, sc.cuda())
         wfh, wbh = wf.h.cpu(), wb.h.cpu()
@@ -207,8 +215,8 @@ def test_prep_bf16_layout():
         blk = w[gi * cog:(gi + 1) * cog]                                  # (cog, cig, K)
         want_f[gi, :K, :cog, :cig] = blk.permute(2, 0, 1)
         want_b[gi, :K, :cig, :cog] = (blk * sc[gi * cog:(gi + 1) * cog].view(-1, 1, 1)).permute(2, 1, 0)
-    assert torch.equal(wfh, want_f.to(torch.bfloat16))
-    assert torch.equal(wbh, want_b.to(torch.bfloat16))
+    assert torch.equal(wfh, want_f.to(OPERAND[1]))
+    assert torch.equal(wbh, want_b.to(OPERAND[1]))
 
 
 def test_gradients_summed_by_autograd_do_not_use_a_stale_image():
@@ -220,7 +228,7 @@ def test_gradients_summed_by_autograd_do_not_use_a_stale_image():
     from ste_gan_amd import ops
     from ste_gan_amd.layers.conv import WNConv1d
     torch.manual_seed(11)
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         conv0 = WNConv1d(64, 64, 3, padding=1).cuda()
         conv1 = WNConv1d(64, 96, 3, padding=1).cuda()
@@ -252,7 +260,7 @@ def test_activation_backward_writes_the_image_for_any_row_length(shape):
     from ste_gan_amd import ops
     from ste_gan_amd._lib import ACT_LRELU
     torch.manual_seed(sum(shape))
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         dy, add, y = (torch.randn(*shape, device="cuda") for _ in range(3))
         want = (dy + add) * torch.where(y > 0, 1.0, 0.1)
@@ -279,7 +287,7 @@ def test_weight_gradient_accumulates_onto_a_non_constant_dw(slices, monkeypatch)
     hx = F.interpolate(F.relu(x), scale_factor=2.0, mode="nearest")
     w0 = torch.zeros(Cout, Cin, K, dtype=torch.float64, requires_grad=True)
     (ref,) = torch.autograd.grad(F.conv1d(bf16r(hx), w0, None, padding=1), w0, bf16r(dy))
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(OPERAND[0])
     try:
         for images in (False, True):
             init = torch.randn(Cout, Cin, K, generator=gen)

@@ -213,6 +213,8 @@ def test_bf16_image_is_dropped_after_an_in_place_write(monkeypatch):
     then shows the old values, so the in-place version recorded when it was attached must still match."""
     from ste_gan_amd import ops
     monkeypatch.setattr(ops, "COMPUTE_DTYPE", "bf16")
+    monkeypatch.setattr(ops, "HALF", True)
+    monkeypatch.setattr(ops, "HALF_DTYPE", torch.bfloat16)
     monkeypatch.setattr(ops, "IMAGES", True)
     t = torch.zeros(2, 16, 12)
     h = torch.zeros(2, 2, 12, 8, dtype=torch.bfloat16)
@@ -224,6 +226,11 @@ def test_bf16_image_is_dropped_after_an_in_place_write(monkeypatch):
     u = torch.zeros(2, 16, 12)
     u.h = h                                               # attached by hand, no version: not trusted
     assert ops._image_of(u, 16, 12) is None
+    # an image of the OTHER 2-byte type (left over from before a mode switch) is not an image of this mode
+    v = torch.zeros(2, 16, 12)
+    ops._attach_image(v, h)
+    monkeypatch.setattr(ops, "HALF_DTYPE", torch.float16)
+    assert ops._image_of(v, 16, 12) is None
 
 
 def test_zero_on_consume_flags():

@@ -71,3 +71,43 @@ def test_rounding_points_of_a_bf16_contraction():
     torch.testing.assert_close(db, dy.sum((0, 2)), rtol=1e-5, atol=1e-5)
     # and it is not the fp32 result
     assert float((y - O._wn_conv1d(sd, "c", x, padding=1)).abs().max()) > 1e-4
+
+
+def _fixture_step(scaler=None, dtype=None):
+    import copy
+    import cases
+    from oracle import shapes as oshapes
+    from oracle.detfill import fill_state_dict
+    name = next(iter(cases.STEP_CASES))
+    ch, (ms, nl, ff), B, T, steps = cases.STEP_CASES[name]
+    g = fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", ch)); d = fill_state_dict(oshapes.discriminator_shapes(True))
+    e = fill_state_dict(oshapes.encoder_shapes(ms, 3, nl, dim_feedforward=ff))
+    dt = {k: v for k, v in d.items() if not O.is_sn_buffer(d, k)}
+    g0, d0 = copy.deepcopy(g), copy.deepcopy(d)
+    og, od = O.adamw_init(g), O.adamw_init(dt)
+    b = cases.step_batch(name, 0)
+    if dtype is None:
+        o = O.train_step(g, d, e, og, od, b, scaler=scaler)
+    else:
+        with O.bf16_operands(dtype):
+            o = O.train_step(g, d, e, og, od, b, scaler=scaler)
+    return o, (g0, d0), (g, d), (og, od)
+
+
+def test_grad_scaler_restatement():
+    """train_step(scaler=...) = torch.cuda.amp.GradScaler as ste_gan/train.py:151,198-199,266-268 drives it."""
+    # fp32 arithmetic: a power-of-two scale changes nothing but the growth tracker
+    plain, _, (g1, d1), _ = _fixture_step()
+    sc = {"scale": 1024.0, "growth_tracker": 0, "growth_interval": 1}
+    scaled, _, (g2, d2), _ = _fixture_step(sc)
+    assert scaled["skipped"] == (False, False) and sc["scale"] == 2048.0 and sc["growth_tracker"] == 0
+    assert scaled["loss_g"] == plain["loss_g"] and scaled["loss_d"] == plain["loss_d"]        # the values are not scaled
+    for k in g1:
+        torch.testing.assert_close(g1[k], g2[k], rtol=1e-6, atol=1e-7)
+    # fp16 operands with a scale that overflows them: both optimiser steps skipped, nothing moves, the scale is halved
+    sc = {"scale": 2.0 ** 40, "growth_tracker": 7}
+    o, (g0, d0), (g3, d3), (og, od) = _fixture_step(sc, torch.float16)
+    assert o["skipped"] == (True, True) and sc["scale"] == 2.0 ** 39 and sc["growth_tracker"] == 0
+    assert og.step == 0 and od.step == 0
+    assert all(torch.equal(g0[k], g3[k]) for k in g0)
+    assert all(torch.equal(d0[k], d3[k]) for k in d0 if not O.is_sn_buffer(d0, k))

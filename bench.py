@@ -31,14 +31,14 @@ import torch.distributed as dist  # noqa: E402
 
 B, T_SU, T_EMG = 64, 12, 192
 MFMA_PEAK_TFLOPS = {"f32": 157.3,   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-                    "bf16": 2500.0}  # ... v_mfma_f32_32x32x16_bf16, dense (~2.5 PF; never the 2:1-sparsity figure)
+                    "bf16": 2500.0, "f16": 2500.0}  # ... v_mfma_f32_32x32x16_bf16, dense (~2.5 PF; never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
 STEP_GFLOP = 1016.9                 # required nominal work of one step at B=64, T_emg=192 (508.4 GMAC)
 STEP_GBYTES_F32 = 6.58              # ... layer-boundary traffic, every activation written and read once as fp32 (SURVEY's fp32 model)
 STEP_GBYTES_BF16 = 3.79             # ... with 2-byte activations / weights and fp32 optimiser traffic: the model behind SURVEY's
                                     # 26.0 M frames/s HBM bound for config 3, the figure BASELINE.json's target is phrased in
-FRAMES_HBM_BOUND = {"bf16": 26.0e6, "f32": 14.9e6}     # SURVEY.md section 8d, frames/s on one GPU
-FRAMES_MFMA_BOUND = {"bf16": 30.4e6, "f32": 1.90e6}
+FRAMES_HBM_BOUND = {"bf16": 26.0e6, "f16": 26.0e6, "f32": 14.9e6}     # SURVEY.md section 8d, frames/s on one GPU
+FRAMES_MFMA_BOUND = {"bf16": 30.4e6, "f16": 30.4e6, "f32": 1.90e6}
 
 
 def load_pmc():
@@ -108,13 +108,13 @@ def step_rooflines(sec_per_step, dtype, frames_per_s):
     2-byte-storage variants), never bytes the kernels happened to move.  What they DID move (PMC: 2 x FETCH_SIZE + WRITE_SIZE
     over every kernel of a step -- bf16 images beside the fp32 tensors, split-K and weight-gradient slabs, re-reads the
     XCD L2s did not absorb) is reported separately, as ``moved_*``, with the profile it was read from."""
-    gb = STEP_GBYTES_BF16 if dtype == "bf16" else STEP_GBYTES_F32
+    gb = STEP_GBYTES_BF16 if dtype in ("bf16", "f16") else STEP_GBYTES_F32
     r = {"algorithmic_gflop": STEP_GFLOP,
          "algorithmic_gbytes_fp32_model": STEP_GBYTES_F32, "algorithmic_gbytes_bf16_model": STEP_GBYTES_BF16,
          "per_gpu_tflops": round(STEP_GFLOP / (1e3 * sec_per_step), 2),
          "mfma_frac": round(STEP_GFLOP / (1e3 * sec_per_step) / MFMA_PEAK_TFLOPS[dtype], 4),
          "hbm_frac": round(gb / sec_per_step / HBM_PEAK_GBS, 4),
-         "hbm_frac_model": "bf16 storage (3.79 GB/step)" if dtype == "bf16" else "fp32 storage (6.58 GB/step)",
+         "hbm_frac_model": "2-byte operand storage (3.79 GB/step)" if dtype in ("bf16", "f16") else "fp32 storage (6.58 GB/step)",
          "hbm_frac_fp32_model": round(STEP_GBYTES_F32 / sec_per_step / HBM_PEAK_GBS, 4),
          "hbm_frac_bf16_model": round(STEP_GBYTES_BF16 / sec_per_step / HBM_PEAK_GBS, 4),
          "frames_frac_of_hbm_bound": round(frames_per_s / FRAMES_HBM_BOUND[dtype], 4),
@@ -250,7 +250,7 @@ def gen_infer(args, cfg, device, quiet=False):
     line = {"metric": "EMG frames/sec, generator-only inference at B=64 chunk=200 (BASELINE config 2)",
             "value": round(B * T_EMG * args.steps / dt, 1), "unit": "EMG frames/s", "n_gpus": 1,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "dtype": "bf16" if _ops.bf16_enabled() else "f32", "data": "synthetic",
+            "higher_is_better": True, "dtype": _ops.COMPUTE_DTYPE, "data": "synthetic",
             "config": {"workload": f"Generator.generate, B=64, T_su=12 -> T_emg=192, {mode}, {launch}"},
             "algorithmic_tflops": round(2 * 53.02e9 * args.steps / dt / 1e12, 2)}
     if not quiet:
@@ -295,9 +295,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 parity-path timing beside a bf16 run")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of replaying the captured hipGraph")
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "f16"], default="bf16",
                     help="arithmetic type of the convolution operands (accumulation, activations, weights and optimiser state "
-                         "stay fp32): f32 = parity path, bf16 = BASELINE config 3")
+                         "stay fp32): f32 = parity path, bf16 = BASELINE config 3 (the metric's), f16 = the same step on the fp16 "
+                         "build of the kernels with the device-side GradScaler (BASELINE config 5's arithmetic)")
     ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
                     help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
@@ -505,7 +506,9 @@ def main():
                 "config": {"workload": "full GAN train step (G + small MPD/MSD D + multi-TD/SU/phoneme/FM losses + 2x AdamW), "
                                        "B=64/GPU, chunk=200 -> T_su=12, T_emg=192, " +
                                        ("bf16 conv operands, fp32 accumulation / activations / weights (BASELINE config 3)"
-                                        if args.dtype == "bf16" else "fp32 parity path"),
+                                        if args.dtype == "bf16" else
+                                        "fp16 conv operands + device-side GradScaler, fp32 accumulation / activations / weights"
+                                        if args.dtype == "f16" else "fp32 parity path"),
                            "global_batch": world * B, "parallelism": f"dp{world}",
                            "launch": ("eager" if not graphed else "hipGraph replay" if world == 1 else
                                       "1 hipGraph per step, the 2 RCCL all-reduces captured inside it" if getattr(step, "ddp_mode", None) == "single"

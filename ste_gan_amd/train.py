@@ -512,15 +512,17 @@ class GraphedTrainStep:
             self.graphs = None
         else:
             self.graph, self.graphs = None, None
-            # ---- torch.distributed.  "single" (default with RCCL): ONE graph for the whole step with the two gradient
-            # all-reduces CAPTURED inside it, on the communication stream (RCCL collectives are capturable like NCCL's:
-            # scripts/rccl_capture_probe.py).  No graph boundary drains the streams (0.45 ms of a 6.8 ms step with three
-            # graphs), and the exchanges overlap whatever does not depend on them by construction: the D-gradient exchange
-            # runs beside the tail of the side branch (multi-TD + frozen encoder), which only the generator's backward pass
-            # awaits.  "three": the phases as three graphs around two eagerly launched exchanges -- the arrangement of
-            # rounds 2-3, kept for backends whose collectives cannot be captured (gloo) and as the fallback when the
-            # single capture raises.  STEGAN_DDP_GRAPH=single|three forces one.
-            want = os.environ.get("STEGAN_DDP_GRAPH", "single" if dist.get_backend(step.comm.group) == "nccl" else "three")
+            # ---- torch.distributed.  "three" (default): the phases as three graphs around two eagerly launched exchanges, the
+            # arrangement of rounds 2-3.  "single" (STEGAN_DDP_GRAPH=single, RCCL only): ONE graph for the whole step with the two
+            # gradient all-reduces CAPTURED inside it, on the communication stream (RCCL collectives are capturable like
+            # NCCL's: scripts/rccl_capture_probe.py).  No graph boundary drains the streams (0.45 ms of a 6.8 ms step with three
+            # graphs; 6.19 against 6.66 ms with a 1-rank group), and the exchanges overlap whatever does not depend on them by
+            # construction.  It is NOT the default: in one of about six runs the process died with a silent SIGABRT (no HIP,
+            # RCCL or c10d message) during the capture, after the first collective had been captured -- a crash at N > 1 costs
+            # a whole run, 0.5 ms does not.  Falls back to "three" when the capture raises.
+            want = os.environ.get("STEGAN_DDP_GRAPH", "three")
+            if want == "single" and dist.get_backend(step.comm.group) != "nccl":
+                want = "three"                                   # (gloo's collectives cannot be captured)
             if want == "single":
                 try:
                     step._d_handle = step._g_handle = None

@@ -32,3 +32,15 @@ for _ in range(reps):
 acc /= reps
 for nm, t in sorted(zip(names, acc), key=lambda kv: kv[1]):
     print(f"{t:9.1f} us  {nm}")
+
+# host side: how long does hipGraphLaunch take to SUBMIT a replay (the GPU runs behind it)?
+import time
+torch.cuda.synchronize()
+hs = []
+for _ in range(20):
+    t0 = time.perf_counter()
+    step.graph.replay()
+    hs.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+print(f"host time of graph.replay(): median {1e3 * sorted(hs)[len(hs) // 2]:.3f} ms, min {1e3 * min(hs):.3f} ms "
+      f"(the GPU time of a step is the last mark above)")

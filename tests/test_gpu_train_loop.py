@@ -134,6 +134,29 @@ def test_graph_replay_in_the_training_loop_matches_eager_launches(tmp_path, monk
             assert rel <= 1e-2, (k, rel)
 
 
+def test_train_loop_in_fp16_mode(tmp_path):
+    """cfg.train.mixed_precision_dtype = "f16": the trainer runs on the fp16 build of the kernels with the device-side
+    GradScaler (BASELINE config 5's arithmetic; eager first batch, graph replays after), leaves finite weights and the
+    reference's files behind, and restores the compute mode and the default library on the way out."""
+    from ste_gan_amd import _lib, ops
+    from ste_gan_amd.train import train
+    _corpus(tmp_path / "corpus")
+    enc_ckpt = tmp_path / "enc.pt"
+    torch.save(fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128)), enc_ckpt)
+    cfg = _cfg(tmp_path, max_steps=5)
+    cfg.train.mixed_precision_dtype = "f16"
+    out = tmp_path / "run16"
+    out.mkdir()
+    train(cfg, out, None, "cuda", debug=False, emg_enc_ckpt=enc_ckpt)
+    assert ops.COMPUTE_DTYPE == "f32" and _lib.lib().stegan_operand_type() == b"bf16"
+    assert {".done", "netG-final.pt", "netD-final.pt", "checkpoint-final.pt"} <= {p.name for p in out.iterdir()}
+    for f in ("netG-final.pt", "netD-final.pt"):
+        assert all(torch.isfinite(v.float()).all() for v in torch.load(out / f).values())
+    cfg.train.mixed_precision_dtype = "fp8"
+    with pytest.raises(ValueError, match="mixed_precision_dtype"):
+        train(cfg, out, None, "cuda", debug=False, emg_enc_ckpt=enc_ckpt)
+
+
 def test_train_loop_two_ranks_with_graph_replay(tmp_path):
     """train() under torch.distributed (2 ranks on the box's one card, gloo): rank-sharded loaders, the three-graph replay of
     the step around the two gradient all-reduces, validation / checkpoints on rank 0 behind barriers."""

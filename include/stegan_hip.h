@@ -619,6 +619,10 @@ int stegan_act_bwd_add(const float* dy, const float* add, const float* y, float*
 int stegan_act_bwd_add_multi(int32_t m, const float* const* dy, const float* const* add, const float* const* y,
                              float* const* out, const int64_t* n, int32_t act, void* stream);
 
+/* out = in[0] + in[1] (+ in[2] + in[3]) elementwise, summed left to right (n_in in 2..4; `in` a HOST array of device
+ * pointers; out may alias in[0]): the gradient of a tensor with several autograd consumers in one launch and a fixed order,
+ * where the reference's autograd engine issues one ATen add per extra consumer (ops.fan_out). */
+int stegan_sum_n(int32_t n_in, const float* const* in, float* out, int64_t numel, void* stream);
 /* out[i] = sum_j coeff[i * n_in + j] * *in[j] (n_in, n_out <= 8; HOST arrays of device pointers / coefficients): the loss
  * terms of a step combined into its reported scalars in one launch (train.py:213-264, loss_G += weight * term). */
 int stegan_scalar_combine(int32_t n_in, const float* const* in, int32_t n_out, float* const* out, const float* coeff,

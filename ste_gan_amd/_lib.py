@@ -113,6 +113,7 @@ SIGNATURES = {
     "stegan_conv1d_bwd_data_multi": [_I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_assemble_batch": [C.POINTER(Corpus), _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P],
     "stegan_adamw_advance": [_P, C.c_double, C.c_double, _P],
+    "stegan_sum_n": [_I32, _P, _P, _I64, _P],
     "stegan_loss_grad_scale": [_P],
     "stegan_grad_scaler_check": [_P, _I64, _P, _P],
     "stegan_grad_scaler_update": [_P, C.c_float, C.c_float, _I32, _P],

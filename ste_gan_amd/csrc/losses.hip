@@ -471,6 +471,54 @@ extern "C" int stegan_scale_by_scalar(const float* x, const float* scalar_dev, f
     return STEGAN_OK;
 }
 
+// out = in[0] + in[1] (+ in[2] + in[3]), left to right: the sum of the gradients of a tensor with several consumers (the
+// generated EMG feeds the period branch, the scale branch and the D-independent losses; a scale input feeds its
+// discriminator and the next pooling; the encoder's last layer feeds both heads) -- what the autograd engine would do with one
+// ATen add per extra consumer, as ONE launch in a fixed order (ops.fan_out).
+namespace {
+struct SumN { const float* in[4]; int n; };
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumN a, float* __restrict__ out, long n, int vec) {
+    if (vec) {
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 s = reinterpret_cast<const float4*>(a.in[0])[i];
+            for (int j = 1; j < a.n; ++j) {
+                const float4 v = reinterpret_cast<const float4*>(a.in[j])[i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            reinterpret_cast<float4*>(out)[i] = s;
+        }
+        for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            float s = a.in[0][i];
+            for (int j = 1; j < a.n; ++j) s += a.in[j][i];
+            out[i] = s;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+            float s = a.in[0][i];
+            for (int j = 1; j < a.n; ++j) s += a.in[j][i];
+            out[i] = s;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int stegan_sum_n(int32_t n_in, const float* const* in, float* out, int64_t numel, void* stream) {
+    STEGAN_CHECK_ARG(n_in >= 2 && n_in <= 4 && in && out && numel > 0);
+    SumN a;
+    a.n = n_in;
+    uintptr_t al = (uintptr_t)out;
+    for (int j = 0; j < 4; ++j) {
+        a.in[j] = j < n_in ? in[j] : nullptr;
+        if (j < n_in) { STEGAN_CHECK_ARG(in[j]); al |= (uintptr_t)in[j]; }
+    }
+    const int vec = (al % 16) == 0;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(nblk(vec ? (numel + 3) / 4 : numel)), dim3(256), 0, (hipStream_t)stream, a, out,
+                       (long)numel, vec);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
 // out[i] = sum_j coeff[i * n_in + j] * *in[j]: the loss terms of a step combined into its reported scalars (the weighted
 // total, the unweighted terms) in ONE one-thread launch instead of a chain of 0-dim torch mul / add / div kernels
 // (train.py:213-264: loss_G += w * term).  n_in, n_out <= 8.

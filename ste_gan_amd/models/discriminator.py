@@ -160,7 +160,8 @@ class _MultiDisc(nn.Module):
 
     def _forward(self, x, sn_pre, fork: bool):
         self._prepare_weights()                # on the calling stream, BEFORE the fork: both branches read the copies
-        xs = self._scale_inputs(ops.btc_to_bct(x))                 # before the fork: both streams read them
+        x_scale, x = ops.fan_out(x, 2)         # two consumers (scale branch, period branch): their gradients meet in one sum
+        xs = self._scale_inputs(ops.btc_to_bct(x_scale))           # before the fork: both streams read them
         main, side = self._fork() if fork else (torch.cuda.current_stream(), None)
         n_side = self._scales_on_side() if side is not None else 0
         scale = [None] * len(self.multi_scale_disc)
@@ -208,7 +209,9 @@ class _MultiDisc(nn.Module):
         more after the last scale and discards the result)."""
         out = [xs]
         for _ in range(len(self.multi_scale_disc) - 1):
-            out.append(ops.avgpool421(out[-1]))
+            here, down = ops.fan_out(out[-1], 2)                   # this scale's discriminator | the next pooling
+            out[-1] = here
+            out.append(ops.avgpool421(down))
         return out
 
     def _prepare_weights(self):

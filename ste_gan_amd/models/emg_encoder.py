@@ -125,9 +125,10 @@ class EMGEncoderTransformer(EMGEncoder):
         x = self.conv_blocks(x)
         x = ops.frozen_conv1d(x, self.w_raw_in.weight.unsqueeze(-1), None, self.w_raw_in.bias, None, ops.ConvCfg(M, M, 1))
         x = self.transformer(x)
+        x, x_aux = ops.fan_out(x, 2)                  # both heads read the last layer: one sum of their input gradients
         su = ops.frozen_conv1d(x, self.w_out.weight.unsqueeze(-1), None, self.w_out.bias, None,
                                ops.ConvCfg(M, self.num_outs, 1, out_btc=True))
-        ph = ops.frozen_conv1d(x, self.w_aux.weight.unsqueeze(-1), None, self.w_aux.bias, None,
+        ph = ops.frozen_conv1d(x_aux, self.w_aux.weight.unsqueeze(-1), None, self.w_aux.bias, None,
                                ops.ConvCfg(M, self.num_aux_outs, 1, out_btc=True))
         return su, ph
 

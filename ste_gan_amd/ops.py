@@ -1831,6 +1831,46 @@ def scalar_combine(ins, rows):
     return views
 
 
+class _FanOutFn(torch.autograd.Function):
+    """n aliases of x, one per consumer; backward = ONE fixed-order sum of the consumers' gradients (stegan_sum_n) instead of
+    the autograd engine's ATen add per extra consumer."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        outs = tuple(x.view_as(x) for _ in range(n))
+        h = _image_of(x, x.shape[1], x.shape[2]) if x.dim() == 3 else None
+        if h is not None:
+            for o in outs:
+                _attach_image(o, h)                 # the aliases are the same bytes: the producer's image serves them all
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [_gpu_f32(g, "grad") for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        out = torch.empty_like(live[0])
+        acc = live
+        while len(acc) > 1:                          # (more than four consumers: in groups, left to right)
+            head, acc = acc[:4], acc[4:]
+            check(_lib.lib().stegan_sum_n(len(head), _ptr_array(head), _p(out), out.numel(), _stream()), "stegan_sum_n")
+            acc = [out] + acc
+        return out, None
+
+
+FAN_OUT = os.environ.get("STEGAN_FAN_OUT", "1") != "0"
+
+
+def fan_out(x: Tensor, n: int):
+    """``n`` aliases of ``x`` for its ``n`` autograd consumers (a tuple; ``x`` itself n times when no gradient flows, on the
+    CPU, or with STEGAN_FAN_OUT=0 -- the engine's own accumulation then)."""
+    if not (FAN_OUT and n > 1 and x.is_cuda and x.requires_grad and torch.is_grad_enabled()):
+        return (x,) * n
+    return _FanOutFn.apply(x, n)
+
+
 _ONES: dict = {}
 
 

@@ -336,12 +336,15 @@ class GANTrainStep:
         fold = self.fold_fm and bool(t.loss_feat_match_error)
         if fold:
             _ops.fm_fold_begin()         # the feature maps' producers add the feature-matching gradients themselves
+        # the generated EMG has two gradient sources -- the discriminators here and the side branch's gradient, handed to
+        # autograd as a root in _p_g2: they meet in ONE hand-written sum (ops.fan_out) instead of the engine's ATen add
+        x_for_d, st["x_pred_root"] = ops.fan_out(x_pred_t, 2)
         try:
             if fold:                          # feature-matching gradients are parked, not returned to autograd (ops.ActFuse)
                 with ops.act_fuse_scope():
-                    D_fake = netD(x_pred_t)
+                    D_fake = netD(x_for_d)
             else:
-                D_fake = netD(x_pred_t)
+                D_fake = netD(x_for_d)
             ops.mark("G step: D(fake) done")
             if "no_dreal_g" in _ops.WHATIF:          # what-if (scripts/whatif.py): the pass skipped, WRONG values
                 D_real = [[f.detach() for f in sc] for sc in D_fake]
@@ -387,7 +390,7 @@ class GANTrainStep:
                 if v.requires_grad:
                     roots.append(v); grads.append(one)
             if g_side is not None:
-                roots.append(x_pred_t); grads.append(g_side)
+                roots.append(st.pop("x_pred_root", x_pred_t)); grads.append(g_side)
             if roots:
                 _ops.wgrad_async(True)         # generator backward: weight gradients beside the input-gradient chain
                 try:

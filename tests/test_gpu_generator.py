@@ -134,3 +134,29 @@ def test_embed_concat_kernel_vs_torch(two):
     torch.testing.assert_close(gw[0], w1.grad, rtol=1e-5, atol=1e-5)
     if two:
         torch.testing.assert_close(gw[1], w2.grad, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,shape", [(2, (4, 8, 96)), (3, (2, 192, 8)), (4, (3, 16, 13)), (6, (2, 5, 7))], ids=str)
+def test_fan_out_sums_consumer_gradients_in_one_launch(n, shape):
+    """ops.fan_out: n aliases of a tensor, the consumers' gradients summed left to right by stegan_sum_n (one launch per
+    four consumers) instead of the autograd engine's ATen add per extra consumer: same bits as the explicit sum, aliases
+    share the producer's bytes (and its bf16 image), and nothing is made when no gradient flows."""
+    from ste_gan_amd import ops
+    torch.manual_seed(n)
+    x = torch.randn(*shape, device="cuda", requires_grad=True)
+    outs = ops.fan_out(x, n)
+    assert len(outs) == n and all(o.data_ptr() == x.data_ptr() and o is not x for o in outs)
+    gs = [torch.randn(*shape, device="cuda") for _ in range(n)]
+    torch.autograd.backward(list(outs), gs)
+    want = gs[0].clone()
+    for g in gs[1:]:
+        want += g
+    assert torch.equal(x.grad, want)
+    # a consumer that never produced a gradient is skipped; a single live one is passed through
+    x.grad = None
+    outs = ops.fan_out(x, 3)
+    outs[1].mul(2.0).sum().backward()
+    assert torch.equal(x.grad, torch.full_like(x, 2.0))
+    with torch.no_grad():
+        assert ops.fan_out(x, 2) == (x, x)
+    assert ops.fan_out(x.detach(), 2)[0] is not None and ops.fan_out(x.detach(), 2)[0].requires_grad is False

@@ -295,6 +295,8 @@ class FusedAdamW:
         ``scaler`` the device decides whether this step counts (skip on non-finite gradients); ``step_count`` on the host
         then counts ATTEMPTED steps -- ``device_step_count()`` reads the applied ones."""
         self.step_count += 1
+        if scaler is not None:
+            self._may_skip = True              # the device may skip steps from here on: checkpoints read ITS count
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         check(_lib.lib().stegan_adamw_advance_s(C.c_void_p(self._hyper.data_ptr()), float(self.betas[0]), float(self.betas[1]),
@@ -332,9 +334,11 @@ class FusedAdamW:
     # ---- torch.optim.AdamW compatible checkpoint format -------------------------------------
     def state_dict(self):
         state = {}
-        if self.step_count > 0:
+        # (with a GradScaler the device skips steps the host cannot know of: the applied count lives there)
+        steps = self.device_step_count() if getattr(self, "_may_skip", False) else self.step_count
+        if steps > 0:
             for i, (p, o) in enumerate(zip(self.flat.params, self.flat.offsets)):
-                state[i] = {"step": torch.tensor(float(self.step_count)),
+                state[i] = {"step": torch.tensor(float(steps)),
                             "exp_avg": self.exp_avg[o:o + p.numel()].view_as(p).clone(),
                             "exp_avg_sq": self.exp_avg_sq[o:o + p.numel()].view_as(p).clone()}
         g = self.param_groups[0]

@@ -76,6 +76,7 @@ def test_overflowing_step_is_skipped_on_the_device():
     torch.cuda.synchronize()
     assert step.scaler.get_scale() == 2.0 ** 39 and step.scaler.skipped_steps() == 2
     assert optD.device_step_count() == 0 and optG.device_step_count() == 0
+    assert optG.step_count == 1 and optG.state_dict()["state"] == {}          # checkpoints carry the APPLIED step count
     assert float(optG.exp_avg.abs().max()) == 0.0 and float(optD.exp_avg_sq.abs().max()) == 0.0
     for net in (netG, netD):
         for k, v in net.state_dict().items():

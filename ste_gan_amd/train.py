@@ -815,6 +815,8 @@ def _train(cfg, model_directory: Path, checkpoint: Path, torch_device: str, debu
             for tag in tags:
                 if tag in stats:
                     writer.add_scalar(f"train_loss/{tag}", stats[tag], steps)
+            if "loss_scale" in stats:                                  # fp16 mode: the GradScaler's scale (not in the reference's logs)
+                writer.add_scalar("train/loss_scale", stats["loss_scale"], steps)
             if "num_phones" in stats:
                 acc["n"] += stats["num_phones"]; acc["ok"] += stats["num_correct_phones"]
                 acc["sil"] += stats["num_silence_phones"]; acc["ok_ns"] += stats["num_correct_phones_no_silence"]

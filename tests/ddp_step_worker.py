@@ -27,6 +27,11 @@ def main():
     netG, netD, optG, optD, step = build_nets()
     assert step.comm is not None and step.comm.world_size == world
     shards = [to_device_batch(shard_batch(full_batch(s), rank, world)) for s in range(STEPS)]
+    if os.environ.get("DDP_STEP_POISON") == "1" and rank == 1:
+        # ONE rank's first batch carries a value that overflows the fp16 operands: its gradients turn non-finite, the SUM
+        # all-reduce spreads that to every rank, and every rank's GradScaler must skip the same optimiser steps
+        from ste_gan_amd.constants import DataType
+        shards[0][DataType.REAL_EMG] = shards[0][DataType.REAL_EMG] * 1e30
     runner = step
     if mode == "eager_overlap":
         # the schedule of the single-graph capture, eagerly: the side branch is NOT joined before the D-gradient exchange
@@ -39,13 +44,21 @@ def main():
         netG.load_state_dict(sdG); netD.load_state_dict(sdD)
         for opt in (optG, optD):
             opt.reset_state()
+        if step.scaler is not None:                      # the warm-up steps moved the scale too: start over
+            step.scaler.load_state_dict(dict(scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                                             _growth_tracker=0))
+            step.scaler.state[3:].zero_()
     losses = []
     for s in range(STEPS):
         st = runner.read_stats(runner(shards[s]))
         losses.append([st["discriminator"], st["generator"]])
     torch.cuda.synchronize()
+    scaler = None
+    if step.scaler is not None:
+        scaler = dict(scale=step.scaler.get_scale(), skipped=step.scaler.skipped_steps(), d_steps=optD.device_step_count(),
+                      g_steps=optG.device_step_count())
     torch.save({"g": {k: v.cpu() for k, v in netG.state_dict().items()}, "d": {k: v.cpu() for k, v in netD.state_dict().items()},
-                "losses": losses}, os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
+                "losses": losses, "scaler": scaler}, os.path.join(out_dir, f"{mode}_rank{rank}.pt"))
     dist.barrier()
     shutdown(runner, step)
     print(f"RANK {rank} DONE", flush=True)

@@ -59,8 +59,8 @@ def build_nets():
     return netG, netD, optG, optD, step
 
 
-def _run_ranks(tmp_path, mode, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run_ranks(tmp_path, mode, port, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_step_worker.py"), str(tmp_path), mode]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
@@ -87,3 +87,20 @@ def test_two_gpu_step_replicas_equal_the_full_batch_step(tmp_path, mode):
             if v.is_floating_point():
                 torch.testing.assert_close(r0[net][k], v, rtol=2e-4, atol=2e-6, msg=lambda m: f"{net}.{k}: {m}")
     assert np.isfinite(np.array(r0["losses"])).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_grad_scaler_skips_on_every_rank_when_one_rank_overflows(tmp_path, mode):
+    """fp16 mode under data parallelism: rank 1's first batch overflows the fp16 operands; the SUM all-reduce carries its
+    non-finite gradients to rank 0, whose own were finite -- both GradScalers (checked BEHIND the exchange) skip the same
+    optimiser steps of iteration 0, halve the scale once, apply iteration 1, and the replicas stay bit-identical."""
+    r0, r1 = _run_ranks(tmp_path, mode, {"eager": 29775, "graph": 29776}[mode], DDP_STEP_DTYPE="f16", DDP_STEP_POISON="1")
+    assert r0["scaler"] == r1["scaler"], (r0["scaler"], r1["scaler"])
+    sc = r0["scaler"]
+    assert sc["skipped"] >= 1 and sc["scale"] == 32768.0, sc             # one back-off from torch's 65536
+    assert sc["d_steps"] + sc["g_steps"] + sc["skipped"] == 2 * STEPS, sc  # every optimiser step either applied or skipped
+    for net in ("g", "d"):
+        for k in r0[net]:
+            assert torch.equal(r0[net][k], r1[net][k]), f"replicas diverged on {net}.{k}"
+            assert torch.isfinite(r0[net][k].float()).all(), f"{net}.{k} is not finite: a poisoned step was applied"

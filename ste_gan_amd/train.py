@@ -224,16 +224,22 @@ class GANTrainStep:
         out, x_pred_t, x_t = st["out"], st["x_pred_t"], st["x_t"]
         speech_units_t, phoneme_targets = st["speech_units_t"], st["phoneme_targets"]
         xp = x_pred_t.detach().requires_grad_(True)        # leaf: this branch's backward stops at the generated EMG
+        # one alias of the leaf per loss term that reads it: their gradients meet in ONE hand-written sum (ops.fan_out)
+        users = [bool(t.loss_multi_td_error),
+                 bool((t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None),
+                 bool(t.loss_waveform_error)]
+        alias = iter(ops.fan_out(xp, sum(users))) if sum(users) > 1 else iter([xp] * 3)
+        xp_td, xp_enc, xp_wave = (next(alias) if u else None for u in users)
         terms = []                                          # (key in ``out``, weighted 0-dim loss, weight)
         ops.mark("side: start")
         if t.loss_multi_td_error:
             w = float(t.loss_multi_td_weight)
-            terms.append(("multi_td", self.multi_td_loss(x_t, xp, weight=w, unit_grad=True), w))
+            terms.append(("multi_td", self.multi_td_loss(x_t, xp_td, weight=w, unit_grad=True), w))
         ops.mark("side: TD done")
         if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
             w_su = float(t.loss_speech_unit_weight) if t.loss_speech_unit_error else 0.0
             w_ph = float(t.loss_phoneme_weight) if t.loss_phoneme_error else 0.0
-            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp, speech_units_t, phoneme_targets, su_weight=w_su,
+            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp_enc, speech_units_t, phoneme_targets, su_weight=w_su,
                                                                   ph_weight=w_ph, unit_grad=True)
             if t.loss_speech_unit_error:
                 terms.append(("speech_unit", enc_out.speech_unit_loss, w_su))
@@ -242,7 +248,7 @@ class GANTrainStep:
             out["phoneme_counters"] = enc_out._counters
         if t.loss_waveform_error:
             w = float(t.loss_waveform_weight)
-            terms.append(("waveform", ops.multi_pair_loss([xp], [x_t], 1, w, unit_grad=True), w))
+            terms.append(("waveform", ops.multi_pair_loss([xp_wave], [x_t], 1, w, unit_grad=True), w))
         ops.mark("side: encoder forward + losses done")
         loss_side = None
         if terms:

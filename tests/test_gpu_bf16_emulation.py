@@ -299,3 +299,54 @@ def test_config3_step_vs_bf16_operand_oracle(bf16_mode):
     assert err["losses"] <= 1e-3 and err["x_pred"] <= 2e-3, err
     assert err["g_norms"] <= 1.2e-3 and err["d_norms"] <= 1e-4, err
     assert err["g_vector"] <= 3.5e-3 and err["d_vector"] <= 1e-4, err
+
+
+def test_full_discriminator_step_vs_operand_oracle(bf16_mode):
+    """`model.discriminator_small: false` (discriminator.py:158-191: k5 s3 period stacks to 1024 channels, k41 grouped scale
+    stacks with strides up to 4, seven spectral-norm layers) through one train step against the oracle with rounded operands:
+    which kernel takes a layer (2-byte matrix-core, exact fp32 fallback) must be what the oracle's shape rule says, or the
+    losses drift apart at the 2^-9 level."""
+    from oracle.detfill import det_ints
+    from test_gpu_train_step import make_cfg
+    from ste_gan_amd.constants import DataType
+    from ste_gan_amd.losses.emg_encoder_loss import EMGEncoderLoss
+    from ste_gan_amd.losses.time_domain_loss import MultiTimeDomainFeatureLoss
+    from ste_gan_amd.models.discriminator import init_emg_discriminators
+    from ste_gan_amd.models.emg_encoder import EMGEncoderTransformer
+    from ste_gan_amd.models.generator import init_emg_generator
+    from ste_gan_amd.optim import GradScaler
+    from ste_gan_amd.train import GANTrainStep, make_optimizers
+    B, T = 2, 24
+    cfg = make_cfg(32)
+    cfg.model.discriminator_small = False
+    g_sd = fill_state_dict(oshapes.generator_shapes("SPEECH_UNITS", 32))
+    d_sd = fill_state_dict(oshapes.discriminator_shapes(False))
+    e_sd = fill_state_dict(oshapes.encoder_shapes(64, 3, 2, dim_feedforward=128))
+    netG = init_emg_generator(cfg); netG.load_state_dict(g_sd)
+    netD = init_emg_discriminators(cfg); netD.load_state_dict(d_sd)
+    enc = EMGEncoderTransformer(8, 256, 48, model_size=64, num_transformer_layers=2, dim_feedforward=128); enc.load_state_dict(e_sd)
+    netG, netD, enc = netG.cuda(), netD.cuda(), enc.cuda().eval()
+    optG, optD = make_optimizers(netG, netD)
+    step = GANTrainStep(cfg, netG, netD, EMGEncoderLoss(enc), MultiTimeDomainFeatureLoss(8), optG, optD)
+    scaler = None
+    if step.scaler is not None:                                  # fp16 operands: a scale that fits, on both sides
+        step.scaler = GradScaler(optG.flat.flat.device, init_scale=2.0 ** 10)
+        scaler = {"scale": 2.0 ** 10, "growth_tracker": 0}
+    su = det_input("fd.su", (B, T, 256)); x_real = det_input("fd.x", (B, 16 * T, 8), "tanh")
+    sess = det_ints("fd.s", (B,), 17); ph = det_ints("fd.ph", (B, T), 48)
+    batch = {DataType.REAL_EMG: x_real.cuda(), DataType.SPEECH_UNITS: su.cuda(), DataType.SESSION_INDEX: sess.cuda(),
+             DataType.SPEAKING_MODE_INDEX: torch.zeros_like(sess).cuda(), DataType.PHONEMES: ph.cuda()}
+    out = step(batch); st = step.read_stats(out)
+    d_train = {k: v for k, v in d_sd.items() if not O.is_sn_buffer(d_sd, k)}
+    with O.bf16_operands(OPERAND[1]):
+        o = O.train_step(g_sd, d_sd, e_sd, O.adamw_init(g_sd), O.adamw_init(d_train),
+                         {"su": su, "feats": su, "x_real": x_real, "sess": sess, "phonemes": ph}, small_d=False, keep_grads=True,
+                         scaler=scaler)
+    err = _step_errors(st, out, netG, netD, o) if scaler is None else None
+    got = np.array([st["discriminator"], st["generator"], st["multi_td"], st["speech_unit"], st["phoneme"], st["feature_matching"]])
+    want = np.array([o["loss_d"], o["loss_g"], o["loss_td"], o["loss_su"], o["loss_ph"], o["loss_fm"]])
+    rel_l = float((np.abs(got - want) / np.abs(want)).max())
+    print("\nfull discriminator:", f"losses {rel_l:.2e}", {k: f"{v:.2e}" for k, v in (err or {}).items()})
+    assert rel_l <= 1e-3, (got, want)
+    if err is not None:                 # (the build consumed nothing here: eager step, gradients still in the arenas)
+        assert err["d_vector"] <= 2e-3 and err["g_vector"] <= 2e-2, err

@@ -43,6 +43,12 @@ def test_every_layer_matches_the_f16_operand_oracle():
     E.test_every_layer_matches_the_bf16_operand_oracle(ops)
 
 
+def test_full_discriminator_step_vs_f16_operand_oracle():
+    from ste_gan_amd import ops
+    ops.set_compute_dtype("f16")
+    E.test_full_discriminator_step_vs_operand_oracle(ops)
+
+
 def _small(scaler_kw=None):
     from ste_gan_amd import ops
     from ste_gan_amd.optim import GradScaler

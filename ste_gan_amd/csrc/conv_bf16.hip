@@ -35,6 +35,7 @@
 // Numerics: products of bf16-rounded operands accumulated in fp32 (k-ordered chain inside the MFMA); everything around
 // the contraction (scale, bias, residual, activations, masks) is fp32 exactly as in conv_direct.hip.
 #include "conv_direct_common.h"
+#include "conv_tile.h"
 
 namespace {
 
@@ -1202,6 +1203,20 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     if (!xh) h.xh = nullptr;
     h.xh_cb = ceil_div(p.Csrc, 8); h.xh_bytes = (unsigned)img_bytes;
     const bool xv = xh ? false : (mc ? mc->xv : xv_eligible(p.Tsrc, p.src, mode == 0 && p.ups));
+    // round 5: the stride-1, ungrouped layers whose source comes as an image go to the one-tile-per-CU kernel (conv_tile.hip)
+    // when its plan takes the shape: generator blocks, encoder convs and linears, forward and input gradient
+    if (xh && !mc && d->stride == 1 && d->groups == 1 && !p.out_btc) {
+        const Taps t0 = phase_taps_host(p, 0);
+        TileConvArgs ta;
+        ta.xh = h.xh; ta.wh = h.wh; ta.scale = p.scale; ta.bias = mode == 0 ? p.bias : nullptr; ta.res = p.res;
+        ta.mask = mode == 1 ? p.mask : nullptr; ta.out = p.out; ta.out_h = p.out_h;
+        ta.B = d->B; ta.Csrc = p.Csrc; ta.Cdst = p.Cdst; ta.Tsrc = p.Tsrc; ta.Tq = p.Tq; ta.Tdst = p.Tdst; ta.Tmask = p.Tmask;
+        ta.ups = p.ups; ta.mode = mode; ta.C2 = p.C2_g; ta.M = p.M_g; ta.Mpad = h.Mpad; ta.Cpad = h.Cpad; ta.K = d->K;
+        ta.ntaps = t0.ntaps; ta.kbase = t0.kbase; ta.kstep = t0.kstep; ta.off_min = t0.off_min; ta.step = t0.step;
+        ta.in_relu = p.in_relu; ta.out_act = p.out_act; ta.mask_lrelu = p.mask_lrelu;
+        const int rc = stegan_tile_conv(ta, s);
+        if (rc != 1) return rc;
+    }
     const int xgran = (mode == 0 && p.ups) ? 8 : 4;               // slots per 16-byte X item
     // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the
     // graph-timed microbenchmark (scripts/bf16_stamps.py, scripts/bf16_microbench.py) on the hot-path layers:

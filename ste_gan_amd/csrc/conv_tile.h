@@ -1,0 +1,26 @@
+// One-tile-per-CU convolution for the stride-1, ungrouped layers (conv_tile.hip): interface towards conv_bf16.hip, which
+// offers every forward / input-gradient launch whose source comes as an activation image to it first.
+#pragma once
+#include "common.h"
+
+// What conv_bf16.hip knows about a launch when it asks (launch_bf16): the operands, the fused epilogue and the tap progression
+// of the (single) output phase.  Pointers as in DirP; ``mode`` 0 forward, 1 input gradient (stride 1: one phase).
+struct TileConvArgs {
+    const unsigned short* xh;     // source image [B][ceil(Csrc / 8)][Tsrc][8]
+    const unsigned short* wh;     // weight copy [K + 1][Cpad / 8][Mpad][8] of the direction (stegan_conv_prep_bf16)
+    const float* scale;           // mode 0: per output channel; mode 1: ONE factor (nullable)
+    const float* bias;            // mode 0
+    const float* res;             // mode 0 residual / mode 1 add_src
+    const float* mask;            // mode 1: ReLU mask source (B, Cdst, Tmask), or (mask_lrelu) the leaky-ReLU output
+    float* out;                   // (B, Cdst, Tdst)
+    unsigned short* out_h;        // image of the output or null
+    int B, Csrc, Cdst, Tsrc, Tq, Tdst, Tmask, ups, mode;
+    int C2, M, Mpad, Cpad, K;
+    int ntaps, kbase, kstep, off_min, step;
+    int in_relu, out_act, mask_lrelu;
+};
+
+// 0: launched; 1: the kernel does not take the shape (the caller goes on to its own plans); other: error status
+int stegan_tile_conv(const TileConvArgs& a, hipStream_t stream);
+// whether stegan_tile_conv would take the launch (no launch): bench.py names the kernel family by it
+bool stegan_tile_conv_takes(const TileConvArgs& a);

@@ -24,3 +24,21 @@ struct TileConvArgs {
 int stegan_tile_conv(const TileConvArgs& a, hipStream_t stream);
 // whether stegan_tile_conv would take the launch (no launch): bench.py names the kernel family by it
 bool stegan_tile_conv_takes(const TileConvArgs& a);
+
+// ---- weight gradient (conv_tile_wgrad.hip), offered every stride-1 ungrouped launch with both operands as images by
+// conv_wgrad_bf16.hip (wgh_run)
+struct TileWgradArgs {
+    const unsigned short* xh;     // [B][Cin / 8][Tin][8]
+    const unsigned short* dyh;    // [B][Cout / 8][Tout][8]
+    const float* dy;              // fp32 dy (bias gradient)
+    float* dw;                    // (Cout, Cin, K), accumulated into when the launch runs in one slice
+    float* db;                    // nullable
+    float* partial;               // slabs [slice][Cout][Cin][Keff] when the launch is sliced over the batch
+    int64_t partial_floats;
+    int B, Cin, Cout, K, dil, pad, Tin, Tout, ups, relu;
+    int k_lo, Keff;               // live taps
+    int bias_in_reduce;           // the caller computes db in its slab reduce when the launch is sliced
+};
+// 0: launched (*slices_out slabs to sum when > 1; 1: dW has been accumulated; *bias_done: db has been taken care of);
+// 1: declined; other: error status
+int stegan_tile_wgrad(const TileWgradArgs& a, int* slices_out, int* bias_done, hipStream_t stream);

@@ -724,6 +724,7 @@ int stegan_tile_conv(const TileConvArgs& a, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)conv_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipGetLastError();
         attr = true;
     }
     if (tile_opts().debug)
@@ -731,6 +732,6 @@ int stegan_tile_conv(const TileConvArgs& a, hipStream_t stream) {
                         "lds=%zu nW=%d nX=%d XROW=%d lgm=%d\n", a.mode, a.B, a.C2, a.M, a.ntaps, a.step, a.Tdst, k.Mc, k.Nc, k.WK,
                 k.nthreads, k.NCB, k.nch, k.NS, k.MT, k.NTl, lds, k.nW, k.nX, k.XROW, k.lgm);
     STEGAN_TIMED_LAUNCH(conv_tile_kernel, dim3((unsigned)(k.MT * k.NTl)), dim3((unsigned)k.nthreads), lds, stream, k);
-    STEGAN_LAUNCH_CHECK();
+    { const hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return -(1000 + (int)e__); }   // (never 1: that means "declined")
     return STEGAN_OK;
 }

@@ -24,6 +24,7 @@
 //
 // Numerics: bf16-rounded operands, fp32 accumulation; the bias gradient stays fp32 (stegan_bias_grad).
 #include "conv_direct_common.h"
+#include "conv_tile.h"
 
 namespace {
 
@@ -685,6 +686,40 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
     h.dy_bytes = (unsigned)((int64_t)d->B * d->Cout * d->Tout * 4);
     h.K_eff = wgh_live_taps(d, h.k_lo);
     if (h.K_eff <= 0) return STEGAN_OK;                  // every tap reads only padding: dW += 0
+    // round 5: stride-1 ungrouped layers with both operands as images go to the one-tile-per-CU kernel (conv_tile_wgrad.hip)
+    // when its plan takes the shape; its slabs are summed by the same ordered reduce as this file's
+    if (img && d->stride == 1 && d->groups == 1) {
+        TileWgradArgs ta;
+        ta.xh = xh; ta.dyh = dyh; ta.dy = dy; ta.dw = dw; ta.db = db; ta.partial = workspace; ta.partial_floats = workspace_floats;
+        ta.B = d->B; ta.Cin = d->Cin; ta.Cout = d->Cout; ta.K = d->K; ta.dil = d->dilation; ta.pad = d->pad; ta.Tin = d->Tin;
+        ta.Tout = d->Tout; ta.ups = h.ups; ta.relu = h.relu; ta.k_lo = h.k_lo; ta.Keff = h.K_eff;
+        ta.bias_in_reduce = deferred ? 0 : 1;
+        int sl = 0, bias_done = 0;
+        const int trc = stegan_tile_wgrad(ta, &sl, &bias_done, s);
+        if (trc != 1) {
+            if (trc) return trc;
+            const int64_t slab_t = (int64_t)h.K_eff * h.Cout * h.Cin_g;
+            if (sl > 1 && deferred) {
+                deferred->partial = workspace; deferred->dw = dw; deferred->per_tap = (int64_t)h.Cout * h.Cin_g;
+                deferred->slices = sl; deferred->K = d->K; deferred->k_lo = h.k_lo; deferred->K_eff = h.K_eff;
+                deferred->used_floats = slab_t * sl;
+            } else if (sl > 1) {
+                const long per_tap = (long)h.Cout * h.Cin_g;
+                long rb = (per_tap * h.K_eff + 255) / 256;
+                if (rb > 2048) rb = 2048;
+                BiasArgs ba;                            // the bias gradient rides here: blocks of 16 bytes of LDS
+                const bool bias_here = db && !bias_done;
+                ba.dy = dy; ba.db = bias_here ? db : nullptr; ba.B = d->B; ba.C = d->Cout; ba.T = d->Tout;
+                ba.slices = bias_here ? 1 : 0; ba.per = d->B;
+                ba.vec = (d->Tout % 4 == 0) && ((uintptr_t)dy % 16 == 0);
+                ba.fdT = make_fastdiv((uint32_t)(ba.vec ? d->Tout / 4 : d->Tout));
+                hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)(rb + (bias_here ? d->Cout : 0))), dim3(256), 0, s,
+                                   (const float*)workspace, dw, per_tap, sl, d->K, h.k_lo, h.K_eff, (int)rb, ba);
+            }
+            STEGAN_LAUNCH_CHECK();
+            return STEGAN_OK;
+        }
+    }
     // tile: 128 x 64 x 3 taps for the dense k = 3 layers; single taps take 128 x 128; more taps 64 x 64 x (5 | 8)
     int TM, TN, KT;
     if (h.K_eff == 1) { KT = 1; TM = h.Cout_g >= 96 ? 2 : 1; TN = h.Cin_g >= 96 ? 2 : 1; }

@@ -372,7 +372,9 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     const int nch = chunks_all / slices, bps = nch * CS;
     const int span = (a.Keff - 1) * a.dil;
     const int SEGW = T + span;
-    const int XSLOT = g_round_up(CS * SEGW, 64), DSLOT = g_round_up(KSC * 32, 64);
+    // (a partial last k-step reads rows past the chunk's columns: dy is zero there, and x must be -- never stale LDS, which may
+    // hold NaN patterns -- so the x plane covers every segment a k-step row can fall into; slots past CS * SEGW land as zeros)
+    const int XSLOT = g_round_up(((KSC * 32 + T - 1) / T) * SEGW, 64), DSLOT = g_round_up(KSC * 32, 64);
     const int xseg = XSLOT / 64, yseg = DSLOT / 64;
     const int nX = 6 * xseg, nY = 6 * yseg;
     if ((nX + 3) / 4 > GX_MAX || (nY + 3) / 4 > GY_MAX) return false;

@@ -286,6 +286,32 @@ def launch_ranks(n: int) -> int:
     return 0
 
 
+
+# ---- the bench line is tamper-evident.  Switches that change RESULTS (round-4 diagnostics: skipped entry points, what-if
+# passes, ablated kernels, another library in place of the built one) make the run refuse; every other STEGAN_* knob it saw
+# (planner experiments: tile shapes, slice counts, stream counts -- same results, different speed) is printed in the line.
+FORBIDDEN_ENV = ("STEGAN_SKIP", "STEGAN_WHATIF", "STEGAN_WHATIF_C", "STEGAN_BF16_DBG", "STEGAN_STAMP_PTR")
+FORBIDDEN_ENV_PREFIXES = ("STEGAN_HIP_LIB",)
+HARNESS_ENV = ("STEGAN_BENCH_",)               # this file's own rehearsal / detail switches: not kernel knobs
+
+
+def check_env(environ=None):
+    """(refused, recorded): names that make the run refuse, and the other STEGAN_* settings to print with the result."""
+    environ = os.environ if environ is None else environ
+    refused = sorted(k for k in environ if k in FORBIDDEN_ENV or k.startswith(FORBIDDEN_ENV_PREFIXES))
+    recorded = {k: environ[k] for k in sorted(environ) if k.startswith("STEGAN_") and k not in refused
+                and not k.startswith(HARNESS_ENV)}
+    return refused, recorded
+
+
+def guard_env():
+    refused, recorded = check_env()
+    if refused:
+        raise SystemExit("bench.py: refusing to measure with " + ", ".join(refused) + " set: these switches change the step's "
+                         "RESULTS (diagnostics) or swap the library under test; unset them")
+    return recorded
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,6 +328,7 @@ def main():
     ap.add_argument("--workload", choices=["train_step", "gen_infer"], default="train_step",
                     help="train_step = the metric's workload (default); gen_infer = BASELINE config 2 (generator-only inference)")
     args = ap.parse_args()
+    env_seen = guard_env()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)
@@ -520,11 +547,20 @@ def main():
         f32_path = {"dtype": "f32", "ms_per_step": round(1e3 * d32, 3), "value": round(B * T_EMG / d32, 1), "unit": "EMG frames/s",
                     "steps": n32, "note": "exact fp32 MFMA path, the one the parity tests pin to the reference within 1e-4"}
         ops.set_compute_dtype(args.dtype)
-    gi = None
+    gi = gi32 = None
     if rank == 0 and world == 1:             # BASELINE config 2 beside the headline number (same process, after the timed region;
         g = gen_infer(args, cfg, device, quiet=True)     # BEFORE the CPU baseline: its 128 worker threads keep spinning for a
         gi = {"value": g["value"], "unit": g["unit"], "ms_per_batch": g["ms_per_step"],      # while and slow this host-bound
               "workload": g["config"]["workload"]}                                           # eager loop 4x)
+        if args.dtype != "f32":              # ... and in config 2's OWN dtype (fp32: the exact parity path)
+            ops.set_compute_dtype("f32")
+            try:
+                g = gen_infer(args, cfg, device, quiet=True)
+                gi32 = {"value": g["value"], "unit": g["unit"], "ms_per_batch": g["ms_per_step"], "dtype": "f32",
+                        "workload": g["config"]["workload"],
+                        "frac_of_fp32_mfma_bound": round(g["value"] / 18.2e6, 4)}        # 18.2 M frames/s
+            finally:
+                ops.set_compute_dtype(args.dtype)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -549,6 +585,7 @@ def main():
                 # whole-step view against both roofs (SURVEY.md section 8d asks for both fractions and which one binds)
                 "step_rooflines": step_rooflines(dt / args.steps, args.dtype, frames / dt),
                 "fp32_parity_path": f32_path, "fp16_path": f16_path, "cpu_baseline": cpu, "generator_inference": gi,
+                "generator_inference_f32": gi32, "env": env_seen,
                 "last_step_losses": {k: round(float(v), 5) for k, v in stats.items() if isinstance(v, float)}}
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -12,10 +12,17 @@
  *     the parameter name ends in _host;
  *   - the caller owns every buffer (inputs, outputs, workspaces);
  *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*): no allocation,
- *     no synchronisation, no global state, so they are re-entrant on distinct streams and can
- *     be captured into a hipGraph;
- *   - return value: 0 = ok, STEGAN_E_ARG = invalid argument / unsupported shape,
- *     otherwise a positive hipError_t; no C++ exception crosses the ABI;
+ *     no synchronisation, no state kept between calls, so they are re-entrant on distinct
+ *     streams and can be captured into a hipGraph.  Two things live outside a call, both read-only
+ *     on the launch path: (1) the planners' experiment knobs (environment variables STEGAN_*,
+ *     read ONCE per process at first use; none of them changes results -- the switches that do
+ *     exist in the diagnostic builds only, scripts/build_stamps.sh); (2) the opt-in measurement
+ *     facility stegan_kernel_timing* (a process-wide list of event pairs, off unless bench.py's
+ *     instrumented pass switches it on; never under stream capture);
+ *   - return value: 0 = ok, STEGAN_E_ARG = invalid argument / unsupported shape, 1 = the entry
+ *     point's kernels do not take the shape (nothing enqueued: the *_h / *_hx / *_t / *_skinny
+ *     families, whose callers then use the generic entry point), otherwise a hipError_t; no C++
+ *     exception crosses the ABI;
  *   - activations are fp32, layout (B, C, T) with T contiguous unless stated otherwise.
  */
 #ifndef STEGAN_HIP_H
@@ -209,10 +216,6 @@ int stegan_adamw_step_z(float* params, float* grads, float* exp_avg, float* exp_
 int stegan_wn_backward_z(int32_t n, const float* const* v, const float* const* g, float* const* dw, float* const* dv,
                          float* const* dg, const int32_t* rows, const int32_t* cols, int32_t max_rows, int32_t zero_dw,
                          void* stream);
-/* Planning hint for the bf16 conv launches ENQUEUED WHILE IT IS SET (host-side state, not stream ordered): slot_weight > 0
- * makes the tile / split-K choice count the chip capacity a launch occupies (blocks x block time) beside its latency --
- * for a branch of the step that has slack.  0 restores the default. */
-int stegan_conv_plan_hint(float slot_weight);
 /* kernel-timestamp timing of the bf16 conv / weight-gradient launches (bench.py's roofline pass): while on, each such launch
  * carries a start / stop event pair holding the dispatch's own begin / end timestamps (hipExtLaunchKernelGGL), so a duration is
  * the kernel's, without the marker packets and dispatch gaps of an event bracket.  _count: pairs recorded so far;

@@ -59,7 +59,6 @@ SIGNATURES = {
     "stegan_timestamp": [_P, _P],
     "stegan_kernel_timing": [_I32],
     "stegan_kernel_timing_collect": [_P, _I64],
-    "stegan_conv_plan_hint": [C.c_float],
     "stegan_adamw_step_z": [_P, _P, _P, _P, _I64, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _I32, _P],
     "stegan_wn_backward_z": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "stegan_act_bwd_add_img": [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -186,21 +185,6 @@ def lib() -> C.CDLL:
         handle.stegan_operand_type.restype = C.c_char_p
         if handle.stegan_operand_type().decode() != _operand:
             raise SteganHipError(f"{path} was built for {handle.stegan_operand_type().decode()} operands, not {_operand}: rebuild")
-        # diagnostics (scripts/whatif2.py): STEGAN_SKIP=entry1,entry2 turns those entry points into no-ops that report
-        # success -- what would the step cost without them?  RESULTS ARE WRONG when set.
-        skip = [n for n in os.environ.get("STEGAN_SKIP", "").split(",") if n]
-        if skip:
-            class _Skipping:
-                def __init__(self, h, names):
-                    self._h, self._names = h, set(names)
-
-                def __getattr__(self, name):
-                    if name in self._names:
-                        return lambda *a, **k: 0
-                    return getattr(self._h, name)
-            for n in skip:
-                getattr(handle, n)              # typo guard: AttributeError for an unknown entry point
-            handle = _Skipping(handle, skip)
         _lib = _libs[_operand] = handle
     return _lib
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/stegan_hip.h"
 
@@ -26,6 +27,11 @@ void stegan_timing_pair(hipEvent_t* start, hipEvent_t* stop);      // a fresh pa
             hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                  \
         }                                                                                                       \
     } while (0)
+
+// Experiment knobs of the host-side planners (tile shapes, slice counts, ...): read from the environment ONCE per process, at the
+// first launch that consults them -- never again on the launch path.  None of them changes results; the switches that do
+// (ablations, what-if skips, stamp buffers) exist in the diagnostic builds only (scripts/build_stamps.sh).
+#define STEGAN_ENV(name_) ([]() -> const char* { static const char* const v__ = getenv(name_); return v__; }())
 
 #define STEGAN_LAUNCH_CHECK()                 \
     do {                                      \

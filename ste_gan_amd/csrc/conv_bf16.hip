@@ -1021,13 +1021,9 @@ void fill_prep(PrepH& t, const stegan_conv_desc* d) {
 // the memory pipeline), so it is opt-in: STEGAN_BF16_XVRAG=1.  Experiment switches back to the first version's 4-byte
 // loads: STEGAN_BF16_NO_XV (all), STEGAN_BF16_NO_XVUP (the forward's upsample).
 bool xv_eligible(int Tsrc, const void* src, bool fwd_ups) {
-    if (getenv("STEGAN_BF16_NO_XV") || (fwd_ups && getenv("STEGAN_BF16_NO_XVUP"))) return false;
-    return (Tsrc % 4 == 0 && ((uintptr_t)src % 16) == 0) || getenv("STEGAN_BF16_XVRAG");
+    if (STEGAN_ENV("STEGAN_BF16_NO_XV") || (fwd_ups && STEGAN_ENV("STEGAN_BF16_NO_XVUP"))) return false;
+    return (Tsrc % 4 == 0 && ((uintptr_t)src % 16) == 0) || STEGAN_ENV("STEGAN_BF16_XVRAG");
 }
-
-// plan hint (stegan_conv_plan_hint): extra weight of the slot time in the cost model for the launches planned while it is
-// set -- a branch of the step that has slack (the frozen-encoder side branch) can trade its own latency for chip capacity
-double g_plan_slot_w = 0.0;
 
 struct GeoH { int TM, TN, logNCB, SEG, NSEG, XROW, NG, ntW, xit, wit, span; size_t lds; bool ok; };
 
@@ -1226,9 +1222,9 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     //                  runs ~20 % slower;
     //   launch time  = rounds x block time (+ 6 + (splits + 1) x output bytes / 3 TB/s for the split-K partials and their
     //                  epilogue kernel).
-    const char* env_tile = getenv("STEGAN_BF16_TILE");                 // "MN", e.g. "22", "11" (experiments)
-    const char* env_cch = getenv("STEGAN_BF16_CCH_MAX");
-    const char* env_spl = getenv("STEGAN_BF16_SPLITS");
+    const char* env_tile = STEGAN_ENV("STEGAN_BF16_TILE");                 // "MN", e.g. "22", "11" (experiments)
+    const char* env_cch = STEGAN_ENV("STEGAN_BF16_CCH_MAX");
+    const char* env_spl = STEGAN_ENV("STEGAN_BF16_SPLITS");
     // (128-channel chunks, image path: the 1 x 1 layers alone get 10-17 % faster -- 768 -> 768: 10.9 -> 9.1 us -- but their
     // 68 KiB of LDS per block crowd the kernels of the other streams: 6.40 against 6.31 ms per step.  STEGAN_BF16_CCH_MAX=128)
     int cch_max = env_cch ? atoi(env_cch) : 64;
@@ -1273,7 +1269,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             // (STEGAN_BF16_SLOT_W weighs it; 0 = latency only, the round-2 model)
             static const char* env_sw = getenv("STEGAN_BF16_SLOT_W");
             static const double slot_w = env_sw ? atof(env_sw) : 0.0;
-            t += (slot_w + g_plan_slot_w) * (double)blocks * (5.0 + per * t_iter) / 512.0;
+            t += slot_w * (double)blocks * (5.0 + per * t_iter) / 512.0;
             if (t < best - 1e-9) { best = t; TM = tm; TN = tn; splits = sp; gm = g2; }
         }
     }
@@ -1311,13 +1307,17 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         const size_t epi = (size_t)4 * TM * TN * 2048 + 8192;
         if (gm.lds < epi) gm.lds = epi;
     }
+#ifdef STEGAN_BF16_ABLATE       // diagnostic builds only (scripts/build_stamps.sh): parts of the kernel switched off, WRONG results
     { const char* ed = getenv("STEGAN_BF16_DBG"); h.dbg = ed ? atoi(ed) : 0; }
+#else
+    h.dbg = 0;
+#endif
     {
         const bool al = ((uintptr_t)p.out % 16) == 0 && (!p.res || ((uintptr_t)p.res % 16) == 0) &&
                         (!p.mask || ((uintptr_t)p.mask % 16) == 0) && (!workspace || ((uintptr_t)workspace % 16) == 0);
         // unit output stride (forward, or the input gradient of a stride-1 conv), whole runs of 4 columns per row
         h.vec_out = al && !p.out_btc && (mode == 0 || d->stride == 1) && U % 4 == 0 && p.Tdst % 4 == 0 &&
-                    (p.ups == 0 || p.Tmask * 2 == p.Tdst) && !getenv("STEGAN_BF16_NO_VEC_OUT");
+                    (p.ups == 0 || p.Tmask * 2 == p.Tdst) && !STEGAN_ENV("STEGAN_BF16_NO_VEC_OUT");
     }
     h.src_bytes = (unsigned)((int64_t)d->B * p.Csrc * p.Tsrc * 4);
     const long nb = (N + BN - 1) / BN;
@@ -1330,7 +1330,11 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     p.splits = ceil_div(nchunks, p.chunks_per_split);
     p.partial = workspace;
     p.mix_S = 0; p.mix_full = 0; p.mix_cps = 0; p.nbx = (int)nb; p.ny = p.m_tiles * d->groups;
+#ifdef STEGAN_STAMPS             // diagnostic builds only: the stamp buffer's device address (decimal) from the environment
     { const char* se = getenv("STEGAN_STAMP_PTR"); p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }
+#else
+    p.stamps = nullptr;
+#endif
     p.fdMT = make_fastdiv((uint32_t)p.m_tiles); p.fdSP = make_fastdiv((uint32_t)p.splits);
     p.fdNBX = make_fastdiv((uint32_t)p.nbx); p.fdNY = make_fastdiv((uint32_t)p.ny);
     p.fdMS = make_fastdiv(1);
@@ -1341,7 +1345,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         // layers (scripts/traffic_probe.py): the model is within 5 % of the counter; the layers' run times do NOT follow
         // it (+-3 % over a 4x range of traffic: the Infinity Cache absorbs the re-reads) -- the choice lowers fabric load for
         // whatever runs beside the kernel, it is not a speed-up of the kernel itself.
-        const char* env_x = getenv("STEGAN_BF16_XLGM");                  // experiments: -1 identity, 0 .. 3 fixed
+        const char* env_x = STEGAN_ENV("STEGAN_BF16_XLGM");                  // experiments: -1 identity, 0 .. 3 fixed
         h.xR = p.nbx * p.splits * phases;
         const double xb = (double)N * p.C2_g * d->groups * (xh ? 2 : 4), wb = (double)p.M_g * d->groups * p.C2_g * d->K * 2;
         const int nz = p.splits * phases;
@@ -1354,8 +1358,8 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
             if (l == 0 || c < best) { best = c; h.xlgm = l; }
         }
         if (env_x) h.xlgm = atoi(env_x);
-        { const char* er = getenv("STEGAN_BF16_ROT"); h.rot = er ? atoi(er) : 1; }
-        { const char* ec = getenv("STEGAN_BF16_CW0"); h.cw0 = ec ? atoi(ec) : 1; }
+        { const char* er = STEGAN_ENV("STEGAN_BF16_ROT"); h.rot = er ? atoi(er) : 1; }
+        { const char* ec = STEGAN_ENV("STEGAN_BF16_CW0"); h.cw0 = ec ? atoi(ec) : 1; }
         while (h.xlgm > 0 && ((1 << h.xlgm) > p.ny || (8 >> h.xlgm) > h.xR)) --h.xlgm;
     }
     for (int ph = 0; ph < MAX_PHASES; ++ph) {
@@ -1395,7 +1399,11 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
     else if (TN == 2) HB_GO(1, 2)
     else HB_GO(1, 1)
 #undef HB_GO
-    static const int whatif = getenv("STEGAN_WHATIF_C") ? atoi(getenv("STEGAN_WHATIF_C")) : 0;     // diagnostics: WRONG results
+#ifdef STEGAN_BF16_ABLATE       // diagnostic builds only: launches skipped to see what they cost -- WRONG results
+    static const int whatif = getenv("STEGAN_WHATIF_C") ? atoi(getenv("STEGAN_WHATIF_C")) : 0;
+#else
+    constexpr int whatif = 0;
+#endif
     if (p.splits > 1 && !(whatif & 1)) {
         long eb = (((p.Tdst & 3) == 0 ? out_elems / 4 : out_elems) + 255) / 256;
         if (eb > 4096) eb = 4096;
@@ -1431,11 +1439,6 @@ int launch_multi_h(MultiCollectH& mc, hipStream_t s) {
 }
 
 }  // namespace
-
-extern "C" int stegan_conv_plan_hint(float slot_weight) {
-    g_plan_slot_w = slot_weight > 0.f ? (double)slot_weight : 0.0;
-    return STEGAN_OK;
-}
 
 extern "C" int64_t stegan_conv_prep_bf16_elems(const stegan_conv_desc* d, int32_t which) {
     if (!d || d->groups <= 0 || d->K <= 0) return -1;

@@ -638,7 +638,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     int TG = ntaps_max, NTG = 1;
     const int span_all = span_off;
     if (mc && ntaps_max > 8) return 1;                  // multi-problem launches: plain variants only
-    if (ntaps_max > 8 && !getenv("STEGAN_NO_TAPGROUPS")) {
+    if (ntaps_max > 8 && !STEGAN_ENV("STEGAN_NO_TAPGROUPS")) {
         const int pad8 = ceil_div(ntaps_max, 8) * 8, pad4 = ceil_div(ntaps_max, 4) * 4;
         TG = pad4 < pad8 ? 4 : 8;
         NTG = ceil_div(ntaps_max, TG);
@@ -652,7 +652,7 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
     }
     // 16-byte X DMA needs float4-aligned rows: row length and valid extent multiples of 4, no upsample, aligned base
     const bool xvec = p.Tsrc % 4 == 0 && p.Tq % 4 == 0 && (mode == 1 || p.ups == 0) && ((uintptr_t)p.src % 16) == 0 &&
-                      !getenv("STEGAN_NO_XVEC") && (!mc || mc->allow_xvec);
+                      !STEGAN_ENV("STEGAN_NO_XVEC") && (!mc || mc->allow_xvec);
     if (ntaps_max > MAX_TAPS) return 1;
     Geo gm = plan_geo(TG, span_off, cs, U, U_min, N, (long)ceil_div(p.M_g, BM2) * d->groups * phases, xvec, mc ? 64 : 0);
     if (!gm.ok) return 1;
@@ -740,10 +740,14 @@ static int launch_direct(const stegan_conv_desc* d, int mode, DirP& p, float* wo
             }
         }
     }
+#ifdef STEGAN_STAMPS             // diagnostic builds only: the stamp buffer's device address (decimal) from the environment
     {
-        static const char* se = getenv("STEGAN_STAMP_PTR");     // diagnostic builds: device buffer address (decimal)
+        static const char* se = getenv("STEGAN_STAMP_PTR");
         p.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr;
     }
+#else
+    p.stamps = nullptr;
+#endif
     {
         static const char* dbg = getenv("STEGAN_PLAN_DEBUG");
         if (dbg) fprintf(stderr, "plan mode=%d B=%d C2=%d M=%d K=%d s=%d d=%d T=%d | BN=%d tm=%d CC=%d nchunks=%d tiles=%ld splits=%d mix_S=%d full=%d lds=%zu TG=%d NTG=%d w14=%d XROW=%d\n",

@@ -735,7 +735,7 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
     h.NTG = ceil_div(h.K_eff, KT);
     const int BM = 64 * TM, BN = 64 * TN;
     const bool xv = !img && h.Tin % 4 == 0 && h.Tout % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)dy % 16) == 0 &&
-                    !getenv("STEGAN_BF16_NO_XV") && !(h.ups && getenv("STEGAN_BF16_NO_XVUP"));
+                    !STEGAN_ENV("STEGAN_BF16_NO_XV") && !(h.ups && STEGAN_ENV("STEGAN_BF16_NO_XVUP"));
     const int xg = 4 << h.ups;                           // x slots per 16-byte item
     // chunk of the reduction: up to RMAX columns (LDS budget / halo share), whole batch elements when the rows are short
     static const char* env_r = getenv("STEGAN_BF16_WGRAD_R");
@@ -792,18 +792,22 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
     static const char* env_t = getenv("STEGAN_BF16_WGRAD_TARGET");       // blocks to aim for (experiments)
     const long target = env_t ? atol(env_t) : 128;
     long want = (target + tiles - 1) / tiles;
-    if (const char* es = getenv("STEGAN_BF16_WGRAD_SLICES")) want = atol(es);
+    if (const char* es = STEGAN_ENV("STEGAN_BF16_WGRAD_SLICES")) want = atol(es);
     if (want > b_chunks) want = b_chunks;
     if (want > workspace_floats / slab) want = workspace_floats / slab;
     if (want < 1) want = 1;
     h.bps = ceil_div(b_chunks, (int)want) * h.NB;
     h.slices = ceil_div(h.B, h.bps);
     h.partial = workspace;
-    { const char* e1 = getenv("STEGAN_BF16_WGRAD_XCD"); h.xcd = e1 ? atoi(e1) : 1; }
-    { const char* e2 = getenv("STEGAN_BF16_WGRAD_ROT"); h.rot = e2 ? atoi(e2) : 1; }
+    { const char* e1 = STEGAN_ENV("STEGAN_BF16_WGRAD_XCD"); h.xcd = e1 ? atoi(e1) : 1; }
+    { const char* e2 = STEGAN_ENV("STEGAN_BF16_WGRAD_ROT"); h.rot = e2 ? atoi(e2) : 1; }
     h.fdNGA = make_fastdiv((uint32_t)h.NGA); h.fdNGX = make_fastdiv((uint32_t)h.NGX);
     h.fdRUp = make_fastdiv((uint32_t)h.RUp); h.fdSEG = make_fastdiv((uint32_t)h.SEG);
+#ifdef STEGAN_STAMPS             // diagnostic builds only
     { const char* se = getenv("STEGAN_STAMP_PTR"); h.stamps = se ? (unsigned long long*)strtoull(se, nullptr, 10) : nullptr; }
+#else
+    h.stamps = nullptr;
+#endif
     h.fdRSA = make_fastdiv((uint32_t)h.RSA); h.fdRSX = make_fastdiv((uint32_t)h.RSX);
     h.fdUC = make_fastdiv((uint32_t)h.u_chunks); h.fdCI = make_fastdiv((uint32_t)h.ci_tiles);
     h.fdCO = make_fastdiv((uint32_t)h.co_tiles); h.fdTG = make_fastdiv((uint32_t)h.NTG);
@@ -848,7 +852,7 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
         deferred->partial = h.partial; deferred->dw = dw; deferred->per_tap = (int64_t)h.Cout * h.Cin_g;
         deferred->slices = h.slices; deferred->K = d->K; deferred->k_lo = h.k_lo; deferred->K_eff = h.K_eff;
         deferred->used_floats = slab * h.slices;
-    } else if (!dw_direct && !(getenv("STEGAN_WHATIF_C") && (atoi(getenv("STEGAN_WHATIF_C")) & 2))) {   // (diagnostics)
+    } else if (!dw_direct) {
         const long per_tap = (long)h.Cout * h.Cin_g;
         long rb = (per_tap * h.K_eff + 255) / 256;
         if (rb > 2048) rb = 2048;

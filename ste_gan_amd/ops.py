@@ -139,10 +139,6 @@ class ConvProfiler:
 
 PROFILER: Optional[ConvProfiler] = None
 
-# What-if switches (scripts/whatif2.py): parts of the step skipped to see what they cost it -- RESULTS ARE WRONG when set.
-WHATIF = set(filter(None, os.environ.get("STEGAN_WHATIF", "").split(",")))
-
-
 LAST_CONV_KERNEL = ""    # "bf16" | "direct" | "igemm": which kernel family took the most recent conv launch (tests)
 
 
@@ -380,11 +376,6 @@ def mark(name: str) -> None:
     i = len(MARKS["names"])
     MARKS["names"].append(name)
     check(_lib.lib().stegan_timestamp(C.c_void_p(MARKS["buf"].data_ptr() + 8 * i), _stream()), "stegan_timestamp")
-
-
-def plan_hint(slot_weight: float) -> None:
-    """See stegan_conv_plan_hint (include/stegan_hip.h)."""
-    check(_lib.lib().stegan_conv_plan_hint(float(slot_weight)), "stegan_conv_plan_hint")
 
 
 def bump_weight_epoch() -> None:
@@ -1047,7 +1038,7 @@ class _WNConvMultiFn(torch.autograd.Function):
         else:
             gs = [act_bwd(g, y, l[3].out_act, None if l[3].out_btc else _fm_take(y)) if l[3].out_act != ACT_NONE else g
                   for g, y, l in zip(gs, ys, layers)]
-        if ctx.wgrad and "no_period_wgrad" not in WHATIF:
+        if ctx.wgrad:
             _sink_touch()
             done = False
             if SKINNY and PROFILER is None and n <= 5 and all(l[5] is not None and l[3].cout == 1 for l in layers):

@@ -169,12 +169,9 @@ class GANTrainStep:
         # every other queue idle.)
         main_stream = st["main_stream"]
         side = self._side_stream() if self.overlap_encoder else None
-        side_w = float(os.environ.get("STEGAN_SIDE_SLOT_W", "0"))
         if side is not None:
             side.wait_stream(main_stream)                      # x_pred, the batch
             torch.cuda.set_stream(side)
-            if side_w > 0:
-                ops.plan_hint(side_w)              # the branch has slack: plan its convs for chip capacity, not latency
         split = side is not None and self.split_side
         try:
             if split:
@@ -184,8 +181,6 @@ class GANTrainStep:
         finally:
             if side is not None:
                 torch.cuda.set_stream(main_stream)
-                if side_w > 0:
-                    ops.plan_hint(0.0)
         self._p_disc()
         if side is not None and ((self.comm is not None and self.join_side_after_phase_d) or split):
             # under torch.distributed this phase ends with the side stream joined: the gradient exchange that follows is
@@ -352,11 +347,8 @@ class GANTrainStep:
             else:
                 D_fake = netD(x_for_d)
             ops.mark("G step: D(fake) done")
-            if "no_dreal_g" in _ops.WHATIF:          # what-if (scripts/whatif.py): the pass skipped, WRONG values
-                D_real = [[f.detach() for f in sc] for sc in D_fake]
-            else:
-                with torch.no_grad():
-                    D_real = netD(x_t)
+            with torch.no_grad():
+                D_real = netD(x_t)
             ops.mark("G step: D(real) done")
             main_terms = []                                              # (key | None, weighted 0-dim loss, weight)
             if t.loss_adversarial:

@@ -86,3 +86,45 @@ def test_conv_profiler_algorithmic_bytes():
         assert ops.ConvProfiler.alg_bytes((1,) + shape[1:]) == 4 * (y + w) + 4 * x
     finally:
         ops.COMPUTE_DTYPE, ops.HALF = old
+
+
+def test_bench_refuses_result_changing_switches_and_records_the_other_knobs():
+    """with a diagnostic switch set (skipped entry points, what-if passes, ablated kernels, another library
+    in place of the built one) ``bench.py`` exits non-zero BEFORE touching the GPU; every other STEGAN_* knob is printed with
+    the result (``env``), this file's own rehearsal switches excepted."""
+    import bench
+    refused, recorded = bench.check_env({"STEGAN_SKIP": "stegan_act_bwd", "STEGAN_WHATIF_C": "3", "STEGAN_HIP_LIB_F16": "/x.so",
+                                         "STEGAN_TILE_NS": "3", "STEGAN_BENCH_DETAIL": "1", "HOME": "/root"})
+    assert refused == ["STEGAN_HIP_LIB_F16", "STEGAN_SKIP", "STEGAN_WHATIF_C"]
+    assert recorded == {"STEGAN_TILE_NS": "3"}
+    for name in ("STEGAN_SKIP", "STEGAN_WHATIF", "STEGAN_WHATIF_C", "STEGAN_BF16_DBG", "STEGAN_HIP_LIB"):
+        env = dict(os.environ, **{name: "1"})
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and name in r.stderr and "refusing" in r.stderr, (name, r.stderr[-300:])
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_the_product_package_has_no_result_changing_switches():
+    """The round-4 diagnostics (STEGAN_SKIP in the ctypes binding, STEGAN_WHATIF in ops / train) are gone from ste_gan_amd/; the
+    library reads its wrong-result knobs in the diagnostic builds only (#ifdef STEGAN_BF16_ABLATE / STEGAN_STAMPS)."""
+    import re
+    pkg = os.path.join(ROOT, "ste_gan_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "STEGAN_SKIP" not in text and "STEGAN_WHATIF" not in text, f
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        if not f.endswith((".hip", ".h")):
+            continue
+        lines = open(os.path.join(pkg, "csrc", f)).read().split("\n")
+        depth_diag = 0
+        for ln in lines:
+            s = ln.strip()
+            if s.startswith("#ifdef STEGAN_BF16_ABLATE") or s.startswith("#ifdef STEGAN_STAMPS") or s.startswith("#if defined(STEGAN_STAMPS)"):
+                depth_diag += 1
+            elif s.startswith("#endif") and depth_diag:
+                depth_diag -= 1
+            elif depth_diag == 0 and re.search(r'getenv\("STEGAN_(WHATIF_C|BF16_DBG|STAMP_PTR)"', s):
+                raise AssertionError(f"{f}: {s}")

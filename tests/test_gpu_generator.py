@@ -73,6 +73,33 @@ def test_whole_utterance_generation_at_batch_one(T_su, ch):
     torch.testing.assert_close(solo, out[0].cpu(), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("T_su,ch", [(1, 768), (7, 768), (333, 96)])
+def test_whole_utterance_generation_at_batch_one_in_the_two_byte_modes(T_su, ch, mode):
+    """The reference validates and samples under fp16 autocast (train.py:326,387-395): the same whole-utterance path with
+    2-byte matrix-core operands, against the oracle run on operands rounded at the same points (``O.bf16_operands``: the
+    kernels' rounding, fp32 everywhere else).  Every launch of these shapes -- T = 1 ... 5 328 at batch one -- takes the
+    kernels' ragged / single-sample plans (or declines to the fp32 staging path), which the B = 64 tests never reach."""
+    from ste_gan_amd import ops
+    dt = torch.bfloat16 if mode == "bf16" else torch.float16
+    g, sd = build("SPEECH_UNITS", ch)
+    feats = det_input(f"utt{T_su}.feats", (1, T_su, 256))
+    sess = torch.tensor([5])
+    ops.set_compute_dtype(mode)
+    try:
+        out = g.generate(feats.cuda(), sess.cuda(), torch.zeros(1, dtype=torch.long).cuda())
+        item = {"SPEECH_UNITS": feats[0], "SESSION_INDEX": torch.tensor(5), "SPEAKING_MODE_IDX": torch.tensor(0)}
+        solo = g.generate_from_data_dict(item, torch.device("cuda"))
+    finally:
+        ops.set_compute_dtype("f32")
+    assert out.shape == (1, 16 * T_su, 8) and not out.requires_grad
+    with torch.no_grad(), O.bf16_operands(dt):
+        ref = O.generator_forward(sd, feats, sess, None)
+    # the emulation bound of tests/test_gpu_bf16_emulation.py for a whole network: 1e-3 of the output's scale (tanh: <= 1)
+    assert float((out.cpu() - ref).abs().max()) <= 1e-3, float((out.cpu() - ref).abs().max())
+    torch.testing.assert_close(solo, out[0].cpu(), rtol=0, atol=0)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("up", [1, 2])
 def test_gblock_gradient_handover_equals_autograd_accumulation(up, dtype, monkeypatch):

@@ -79,16 +79,26 @@ def test_train_step_vs_golden(name, golden):
         assert [st["num_phones"], st["num_silence_phones"], st["num_correct_phones"],
                 st["num_correct_phones_no_silence"]] == g[t + "counters"].tolist()
         torch.testing.assert_close(out["x_pred"].cpu(), torch.from_numpy(g[t + "x_pred"]), rtol=1e-4, atol=1e-5)
+        # Bounds from the measured distances (scripts/step_margins.py, round 5: G gradient norms 1.6e-6, D 1.0e-6 at step 0 and
+        # 1.3e-4 at step 1 -- one leaky-ReLU unit of the fixture's 84 near-zero D pre-activations on the other side of zero after
+        # D's first update, make_golden.py records the kink margins --, parameter norms 1.8e-7): an order of magnitude of head
+        # room for G and the parameters, the fixture's own kink for D (round 4 held all of them to 2e-3)
         gG = norms([p.grad for p in netG.parameters()])
-        np.testing.assert_allclose(gG, g[t + "g_grad_norm"], rtol=2e-3, atol=2e-5 * g[t + "g_grad_norm"].max())
+        np.testing.assert_allclose(gG, g[t + "g_grad_norm"], rtol=2e-5, atol=2e-6 * g[t + "g_grad_norm"].max())
         # after the G step, netD's .grad still holds the gradients of loss_D (this path never adds loss_G's D grads)
         gD = norms([p.grad for p in netD.parameters()])
-        np.testing.assert_allclose(gD, g[t + "d_grad_norm"], rtol=2e-3, atol=2e-5 * g[t + "d_grad_norm"].max())
-        close(norms(netG.state_dict().values()), g[t + "g_param_norm"], 2e-5, t + "g_param_norm")
-        close(norms(netD.state_dict().values()), g[t + "d_param_norm"], 2e-5, t + "d_param_norm")
-        heads = np.stack([np.pad(v.flatten()[:4].double().cpu().numpy(), (0, max(0, 4 - v.numel())))
-                          for v in netG.state_dict().values()])
-        close(heads, g[t + "g_param_head"], 2e-4, t + "g_param_head")
+        np.testing.assert_allclose(gD, g[t + "d_grad_norm"], rtol=2e-4, atol=2e-6 * g[t + "d_grad_norm"].max())
+        close(norms(netG.state_dict().values()), g[t + "g_param_norm"], 2e-6, t + "g_param_norm")
+        close(norms(netD.state_dict().values()), g[t + "d_param_norm"], 2e-6, t + "d_param_norm")
+
+        def heads_of(tensors):
+            return np.stack([np.pad(v.flatten()[:4].double().cpu().numpy(), (0, max(0, 4 - v.numel()))) for v in tensors])
+
+        # element values, not only norms: the first four entries of every parameter of BOTH networks after the update, and of
+        # the generator's gradients (absolute bounds relative to the largest entry: 5.7e-6 / 5.7e-7 measured)
+        close(heads_of(netG.state_dict().values()), g[t + "g_param_head"], 2e-6, t + "g_param_head")
+        close(heads_of(netD.state_dict().values()), g[t + "d_param_head"], 2e-6, t + "d_param_head")
+        close(heads_of([p.grad for p in netG.parameters()]), g[t + "g_grad_head"], 2e-5, t + "g_grad_head")
 
 
 def test_optimizer_state_dict_roundtrip():

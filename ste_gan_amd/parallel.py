@@ -16,10 +16,27 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
+    """Everything the exchange needs from the host side exists BEFORE a launch: the communication stream and the two
+    events of every arena are created on first use OUTSIDE any capture and reused (``prime``).  A launch made while the
+    stream is being captured (GraphedTrainStep's single-graph mode) then consists of exactly: event record -> stream wait ->
+    the collective -> event record -- no event / stream construction, and no ``record_stream`` (caching-allocator
+    bookkeeping on a capturing side stream; the arena outlives every step, so the call protects nothing there)."""
+
     def __init__(self, process_group=None):
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self._stream: Optional[torch.cuda.Stream] = None
+        self._events = {}                       # arena address -> (ready, done)
+
+    def prime(self, flat_grad: torch.Tensor) -> None:
+        """Create the communication stream and this arena's events now (call outside a capture; ``launch`` does it
+        itself when it runs eagerly first, as every train loop does: the warm-up steps precede the capture)."""
+        if not flat_grad.is_cuda or dist.get_backend(self.group) != "nccl":
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat_grad.device)
+        if flat_grad.data_ptr() not in self._events:
+            self._events[flat_grad.data_ptr()] = (torch.cuda.Event(), torch.cuda.Event())
 
     def launch(self, flat_grad: torch.Tensor):
         """SUM all-reduce of the arena (the 1/world_size factor is folded into the AdamW kernel's grad_scale)."""
@@ -32,16 +49,20 @@ class FlatGradAllReduce:
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat_grad.copy_(host)
             return None
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=flat_grad.device)
-        ready = torch.cuda.Event()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._stream is None or flat_grad.data_ptr() not in self._events:
+            if capturing:
+                raise RuntimeError("ste_gan_amd.parallel: the gradient exchange must run eagerly once (or prime()) before it is "
+                                   "captured: its stream and events are not created inside a capture")
+            self.prime(flat_grad)
+        ready, done = self._events[flat_grad.data_ptr()]
         ready.record(torch.cuda.current_stream(flat_grad.device))
         self._stream.wait_event(ready)                      # gradients fully written before the exchange starts
         with torch.cuda.stream(self._stream):
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            done = torch.cuda.Event()
             done.record(self._stream)
-        flat_grad.record_stream(self._stream)
+        if not capturing:
+            flat_grad.record_stream(self._stream)
         return done
 
     def wait(self, handle) -> None:
@@ -53,6 +74,7 @@ class FlatGradAllReduce:
         if self._stream is not None:
             self._stream.synchronize()
             self._stream = None
+        self._events.clear()
 
 
 def shutdown(*steps) -> None:

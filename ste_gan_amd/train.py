@@ -128,14 +128,58 @@ class GANTrainStep:
 
     def abort(self) -> None:
         """A phase raised: leave no state behind that a later step would trust (the open zero pool, gradients already
-        accumulated into the arenas, weight gradients parked for side streams)."""
-        ops.zero_pool_abort()
-        ops.wgrad_abort()
+        accumulated into the arenas, weight gradients parked for side streams, the loss kernels' attached gradient scale).
+        Must never hide the exception it is cleaning up after: a sticky HIP error makes ``synchronize`` raise again, and on
+        a stream that is being captured (a failed graph capture) a fill would be RECORDED, not executed -- there the arenas
+        are only marked dirty, so the next eager ``zero_grad`` fills them."""
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            self._join_captured_forks()
+        for fn in (ops.zero_pool_abort, ops.wgrad_abort):
+            try:
+                fn()
+            except Exception as e:                                   # noqa: BLE001 -- the original exception is what matters
+                logging.warning(f"GANTrainStep.abort: {fn.__name__} raised {type(e).__name__}: {e}")
         self._st = None
         if self.scaler is not None:
             self.scaler.detach()
         for opt in (self.optG, self.optD):
-            opt.discard_grads()
+            try:
+                if capturing:
+                    opt.flat.clean = False
+                    if opt.pack is not None:
+                        opt.pack.clean = False
+                else:
+                    opt.discard_grads()
+            except Exception as e:                                   # noqa: BLE001
+                logging.warning(f"GANTrainStep.abort: discarding gradients raised {type(e).__name__}: {e}")
+
+    def _join_captured_forks(self) -> None:
+        """A phase raised INSIDE a graph capture: every stream the step forked into the capture (side branch, discriminator
+        forks, weight-gradient streams, the communication stream) is joined back into the capturing stream, so that the
+        capture can END -- hipStreamEndCapture refuses a capture with unjoined work and leaves the stream capturing, after
+        which no further capture can begin in the process (seen with the injected failure of
+        tests/test_gpu_train_step.py: "capturing stream has unjoined work", then "Cannot register the state during capturing
+        stage").  Only streams that ARE capturing are waited for: an event of a stream outside the capture would violate
+        its isolation."""
+        from .models.discriminator import _MultiDisc
+        cands = [getattr(self, "_side", None), getattr(_MultiDisc, "_side", None), getattr(_MultiDisc, "_third", None)]
+        cands += list(ops._WG_SIDE) + list(ops._SINK_STREAMS.values())
+        if self.comm is not None:
+            cands.append(getattr(self.comm, "_stream", None))
+        main = torch.cuda.current_stream()
+        seen = {main.cuda_stream}
+        for s_ in cands:
+            if s_ is None or s_.cuda_stream in seen:
+                continue
+            seen.add(s_.cuda_stream)
+            try:
+                with torch.cuda.stream(s_):
+                    forked = torch.cuda.is_current_stream_capturing()
+                if forked:
+                    main.wait_stream(s_)
+            except Exception as e:                                   # noqa: BLE001 -- best effort; the original error follows
+                logging.warning(f"GANTrainStep.abort: joining a forked stream raised {type(e).__name__}: {e}")
 
     def exchange_d(self):
         """SUM all-reduce of the discriminator's gradient arena (side stream, RCCL); awaited in phase_g."""
@@ -461,6 +505,21 @@ class GANTrainStep:
         return stats
 
 
+def _leak_failed_graphs(*graphs) -> None:
+    """Keep the CUDAGraph objects of a capture that raised alive FOR EVER.
+
+    Their destructor is not safe to run: at::cuda::CUDAGraph::~CUDAGraph() unregisters the graph from the generator states it
+    touched and, for a capture that did not complete, HIPGeneratorImpl::unregister_graph throws c10::Error ("The graph should
+    be registered to the state") -- an exception out of a destructor, i.e. std::terminate: the process dies with SIGABRT as
+    soon as the last reference goes (round 5 caught this with the stack of the injected-failure test; it is what turned a
+    capture that merely RAISED in round 4's single-graph mode into the "silent SIGABRT during the capture").  An extra
+    reference that is never dropped costs a few hundred bytes per failed capture."""
+    import ctypes
+    for g in graphs:
+        if g is not None:
+            ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
+
+
 class GraphedTrainStep:
     """The whole train step captured once into a hipGraph and replayed per batch.
 
@@ -475,6 +534,7 @@ class GraphedTrainStep:
     """
 
     CAPTURE_ERROR_MODE = "thread_local"      # pinned by tests/test_host_logic.py (see __init__)
+    DDP_GRAPH_DEFAULT = "three"              # arrangement under torch.distributed unless STEGAN_DDP_GRAPH says otherwise
 
     def __init__(self, step: GANTrainStep, example_batch: Dict[str, torch.Tensor], warmup: int = 3):
         self.step = step
@@ -508,8 +568,12 @@ class GraphedTrainStep:
         self.ddp_mode = None
         if step.comm is None:
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, **mode):
-                self.out = step(self.static)
+            try:
+                with torch.cuda.graph(self.graph, **mode):
+                    self.out = step(self.static)
+            except BaseException:
+                _leak_failed_graphs(self.graph)
+                raise
             self.graphs = None
         else:
             self.graph, self.graphs = None, None
@@ -521,7 +585,7 @@ class GraphedTrainStep:
             # construction.  It is NOT the default: in one of about six runs the process died with a silent SIGABRT (no HIP,
             # RCCL or c10d message) during the capture, after the first collective had been captured -- a crash at N > 1 costs
             # a whole run, 0.5 ms does not.  Falls back to "three" when the capture raises.
-            want = os.environ.get("STEGAN_DDP_GRAPH", "three")
+            want = os.environ.get("STEGAN_DDP_GRAPH", self.DDP_GRAPH_DEFAULT)
             if want == "single" and dist.get_backend(step.comm.group) != "nccl":
                 want = "three"                                   # (gloo's collectives cannot be captured)
             if want == "single":
@@ -536,9 +600,19 @@ class GraphedTrainStep:
                 except Exception as e:                           # noqa: BLE001 -- reported; the three-graph path follows
                     logging.warning(f"single-graph capture with RCCL collectives failed ({type(e).__name__}: {e}); "
                                     "falling back to three graphs around eager exchanges")
+                    _leak_failed_graphs(g)                       # (its destructor would abort the process: see there)
                     step.abort()
                     torch.cuda.synchronize()
                     self.graph = None
+                    # the failed capture ran the HOST side of a step (optimiser epochs, prepared-copy stamps) without executing
+                    # a kernel: bring the bookkeeping back to "weights as they are, copies to be re-derived", as in front of
+                    # the first capture
+                    step.optG.step_count, step.optD.step_count = self._counts
+                    if step.optG.pack is not None:
+                        step.optG.pack.invalidate()
+                    if step.optD.pack is not None:
+                        step.optD.pack.invalidate()
+                    self._refresh_d()
             if self.graph is None:
                 self._capture_three(step, mode)
                 self.ddp_mode = "three"
@@ -559,12 +633,17 @@ class GraphedTrainStep:
         # the discriminator graph's internal fork streams and the two ran one after the other.)
         step.split_side = os.environ.get("STEGAN_SPLIT_SIDE", "1") != "0"
         g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, **mode):
-            step.phase_d(self.static)
-        with torch.cuda.graph(g2, pool=g1.pool(), **mode):
-            step.phase_g()
-        with torch.cuda.graph(g3, pool=g1.pool(), **mode):
-            self.out = step.phase_opt()
+        try:
+            with torch.cuda.graph(g1, **mode):
+                step.phase_d(self.static)
+            with torch.cuda.graph(g2, pool=g1.pool(), **mode):
+                step.phase_g()
+            with torch.cuda.graph(g3, pool=g1.pool(), **mode):
+                self.out = step.phase_opt()
+        except BaseException:
+            _leak_failed_graphs(g1, g2, g3)
+            step.abort()        # (the phases are called directly here: GANTrainStep.__call__'s own cleanup does not run)
+            raise
         self.graphs = (g1, g2, g3)
 
     def _weights_signature(self):

@@ -1,8 +1,8 @@
-"""The graph replay under torch.distributed -- ONE graph with the two RCCL all-reduces captured inside it (STEGAN_DDP_GRAPH=single,
-the default with RCCL) or three graphs around eager exchanges (=three; side branch split over the first two, STEGAN_SPLIT_SIDE=0:
-whole in the first) -- under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
-(``parallel.shutdown``); run in-process by test_gpu_train_step.py::test_multi_graph_replay_with_process_group_matches_golden
-and usable as a script."""
+"""The graph replay under torch.distributed -- three graphs around eager exchanges (STEGAN_DDP_GRAPH=three, the default; side
+branch split over the first two, STEGAN_SPLIT_SIDE=0: whole in the first) or ONE graph with the two RCCL all-reduces captured
+inside it (=single, opt-in) -- under a 1-rank RCCL group against the golden fixture, ending in the ordered teardown
+(``parallel.shutdown``); run in-process by tests/test_gpu_train_step.py and usable as a script (then a fatal signal prints the
+Python AND the C++ stacks of every thread: a death in here must describe itself)."""
 import os
 import sys
 
@@ -19,7 +19,9 @@ import cases  # noqa: E402
 from test_gpu_train_step import build, close, norms, to_batch  # noqa: E402
 
 
-def main():
+def main(expect=None):
+    """``expect``: the arrangement the capture must end in (default: what STEGAN_DDP_GRAPH asks for, else the library's own
+    default -- a silent fallback would hide a capture failure)."""
     from ste_gan_amd.train import GraphedTrainStep
     name = "step_c48_b3"
     g = np.load(os.path.join(HERE, "golden", name + ".npz"))
@@ -30,7 +32,7 @@ def main():
     sdG = {k: v.clone() for k, v in netG.state_dict().items()}
     sdD = {k: v.clone() for k, v in netD.state_dict().items()}
     gs = GraphedTrainStep(step, to_batch(cases.step_batch(name, 0)), warmup=2)
-    want = os.environ.get("STEGAN_DDP_GRAPH", "single")
+    want = expect or os.environ.get("STEGAN_DDP_GRAPH", GraphedTrainStep.DDP_GRAPH_DEFAULT)
     assert gs.ddp_mode == want, f"captured as {gs.ddp_mode!r}, wanted {want!r} (a silent fallback would hide a capture failure)"
     assert (gs.graphs is not None and len(gs.graphs) == 3) if want == "three" else (gs.graph is not None and gs.graphs is None)
     netG.load_state_dict(sdG); netD.load_state_dict(sdD)
@@ -51,4 +53,11 @@ def main():
 
 
 if __name__ == "__main__":
+    import faulthandler
+    faulthandler.enable(all_threads=True)                        # Python stacks of all threads on SIGABRT / SIGSEGV / ...
+    os.environ.setdefault("TORCH_SHOW_CPP_STACKTRACES", "1")
+    try:
+        torch._C._set_print_stack_traces_on_fatal_signal(True)   # ... and the C++ stacks (c10's fatal-signal handler)
+    except AttributeError:
+        pass
     main()

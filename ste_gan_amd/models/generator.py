@@ -84,6 +84,13 @@ class EMGGeneratorGanTTS(EMGGenerator):
         x = speech_unit_sequence
         T = x.shape[1]
         if self.use_session_embeddings and x.is_cuda:
+            # nn.Embedding raises on an id outside its table; the gather kernel would read a zero row instead.  Checked on the
+            # host wherever a read-back is possible (eager calls); a captured / replayed step cannot, and takes ids that the
+            # data path has validated (data.loader: session / mode indices come from the corpus tables)
+            if not torch.cuda.is_current_stream_capturing():
+                _check_ids(session_ids, self.session_embeddings.num_embeddings, "session_ids")
+                if self.use_speaking_mode_embedding:
+                    _check_ids(speaking_mode_ids, self.speaking_mode_embeddings.num_embeddings, "speaking_mode_ids")
             # gather + broadcast over time + concat + 'b t c -> b c t' (generator.py:143-154) in one launch
             w1 = self.session_embeddings.weight
             w2 = self.speaking_mode_embeddings.weight if self.use_speaking_mode_embedding else None
@@ -101,6 +108,16 @@ class EMGGeneratorGanTTS(EMGGenerator):
             x = x.transpose(1, 2).contiguous()           # b t c -> b c t
         x = self.gblocks(x)
         return self.last_conv[1](x)                  # (B, T_emg, C_emg) in (-1, 1)
+
+
+def _check_ids(ids: Tensor, n: int, what: str) -> None:
+    """IndexError for an embedding id outside [0, n), as torch.nn.functional.embedding raises (one read-back of two words)."""
+    if ids.numel() == 0:
+        return
+    lo, hi = torch.aminmax(ids)
+    lo, hi = int(lo), int(hi)
+    if lo < 0 or hi >= n:
+        raise IndexError(f"index out of range in self ({what}: values in [{lo}, {hi}], embedding table has {n} rows)")
 
 
 def init_emg_generator(cfg, emg_generator_type: str = "") -> EMGGenerator:

@@ -271,15 +271,20 @@ class GANTrainStep:
         xp_td, xp_enc, xp_wave = (next(alias) if u else None for u in users)
         terms = []                                          # (key in ``out``, weighted 0-dim loss, weight)
         ops.mark("side: start")
+        # A term that is enabled with weight 0.0 is still LOGGED with its real value, as the reference does (train.py:213-262
+        # logs the term itself): its kernel runs with weight 1 and the term is neither a summand of the total nor a root of
+        # the backward pass (_w_eff / _live).
         if t.loss_multi_td_error:
             w = float(t.loss_multi_td_weight)
-            terms.append(("multi_td", self.multi_td_loss(x_t, xp_td, weight=w, unit_grad=True), w))
+            terms.append(("multi_td", self.multi_td_loss(x_t, xp_td, weight=_w_eff(w), unit_grad=True), w))
         ops.mark("side: TD done")
         if (t.loss_speech_unit_error or t.loss_phoneme_error) and self.emg_encoder_loss is not None:
             w_su = float(t.loss_speech_unit_weight) if t.loss_speech_unit_error else 0.0
             w_ph = float(t.loss_phoneme_weight) if t.loss_phoneme_error else 0.0
-            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp_enc, speech_units_t, phoneme_targets, su_weight=w_su,
-                                                                  ph_weight=w_ph, unit_grad=True)
+            enc_out: EMGEncoderLossOutput = self.emg_encoder_loss(xp_enc, speech_units_t, phoneme_targets,
+                                                                  su_weight=_w_eff(w_su) if t.loss_speech_unit_error else 0.0,
+                                                                  ph_weight=_w_eff(w_ph) if t.loss_phoneme_error else 0.0,
+                                                                  unit_grad=True)
             if t.loss_speech_unit_error:
                 terms.append(("speech_unit", enc_out.speech_unit_loss, w_su))
             if t.loss_phoneme_error:
@@ -287,12 +292,13 @@ class GANTrainStep:
             out["phoneme_counters"] = enc_out._counters
         if t.loss_waveform_error:
             w = float(t.loss_waveform_weight)
-            terms.append(("waveform", ops.multi_pair_loss([xp_wave], [x_t], 1, w, unit_grad=True), w))
+            terms.append(("waveform", ops.multi_pair_loss([xp_wave], [x_t], 1, _w_eff(w), unit_grad=True), w))
         ops.mark("side: encoder forward + losses done")
         loss_side = None
         if terms:
             n = len(terms)
-            rows = [[1.0] * n] + [[(1.0 / w if (j == i and w != 0.0) else 0.0) for j in range(n)] for i, (_, _, w) in enumerate(terms)]
+            rows = [[(1.0 if w != 0.0 else 0.0) for _, _, w in terms]] + \
+                   [[(1.0 / _w_eff(w) if j == i else 0.0) for j in range(n)] for i, (_, _, w) in enumerate(terms)]
             vals = ops.scalar_combine([v for _, v, _ in terms], rows)
             loss_side = vals[0]
             for (key, _, _), v in zip(terms, vals[1:]):
@@ -378,7 +384,7 @@ class GANTrainStep:
         # ---- generator-side discriminator passes with the updated D (train.py:206-211, 257-264)
         self._set_d_grad(False)          # D's weight grads from loss_G are discarded by the reference: skip them
         from . import ops as _ops
-        fold = self.fold_fm and bool(t.loss_feat_match_error)
+        fold = self.fold_fm and bool(t.loss_feat_match_error) and float(t.loss_feat_match_weight) != 0.0
         if fold:
             _ops.fm_fold_begin()         # the feature maps' producers add the feature-matching gradients themselves
         # the generated EMG has two gradient sources -- the discriminators here and the side branch's gradient, handed to
@@ -399,7 +405,7 @@ class GANTrainStep:
                 main_terms.append((None, lsgan_loss(D_fake, 1.0, unit_grad=True), 1.0))
             if t.loss_feat_match_error:
                 w_fm = float(t.loss_feat_match_weight)                   # folded into the loss kernels
-                loss_feat_w = feature_matching_loss(D_fake, D_real, weight=w_fm, unit_grad=True, fold=fold)
+                loss_feat_w = feature_matching_loss(D_fake, D_real, weight=_w_eff(w_fm), unit_grad=True, fold=fold)
                 n_fm = sum(len(sc) - 1 for sc in D_fake)
                 if fold and _ops._FM_COUNT[0] != n_fm:
                     # a gradient that went back to autograd would meet feature maps whose producers no longer apply their
@@ -428,8 +434,8 @@ class GANTrainStep:
             # autograd's ones_like fills
             roots, grads = [], []
             one = ops.one_like(x_pred_t)
-            for _, v, _ in main_terms:
-                if v.requires_grad:
+            for _, v, w in main_terms:
+                if v.requires_grad and w != 0.0:
                     roots.append(v); grads.append(one)
             if g_side is not None:
                 roots.append(st.pop("x_pred_root", x_pred_t)); grads.append(g_side)
@@ -443,10 +449,10 @@ class GANTrainStep:
             ins = [v for _, v, _ in main_terms] + ([loss_side] if loss_side is not None else [])
             loss_G = None
             if ins:
-                rows = [[1.0] * len(ins)]
+                rows = [[(1.0 if w != 0.0 else 0.0) for _, _, w in main_terms] + ([1.0] if loss_side is not None else [])]
                 for i, (key, _, w) in enumerate(main_terms):
                     if key is not None:
-                        rows.append([(1.0 / w if (j == i and w != 0.0) else 0.0) for j in range(len(ins))])
+                        rows.append([(1.0 / _w_eff(w) if j == i else 0.0) for j in range(len(ins))])
                 vals = _ops.scalar_combine(ins, rows)
                 loss_G = vals[0]
                 k = 1
@@ -503,6 +509,11 @@ class GANTrainStep:
             stats.update(num_phones=c[0], num_silence_phones=c[1], num_correct_phones=c[2],
                          num_correct_phones_no_silence=c[3])
         return stats
+
+
+def _w_eff(w: float) -> float:
+    """Weight a loss kernel runs with: the configured one, or 1 for a term enabled with weight 0 (logged, not trained on)."""
+    return w if w != 0.0 else 1.0
 
 
 def _leak_failed_graphs(*graphs) -> None:

@@ -187,3 +187,17 @@ def test_fan_out_sums_consumer_gradients_in_one_launch(n, shape):
     with torch.no_grad():
         assert ops.fan_out(x, 2) == (x, x)
     assert ops.fan_out(x.detach(), 2)[0] is not None and ops.fan_out(x.detach(), 2)[0].requires_grad is False
+
+
+def test_out_of_range_embedding_ids_raise_like_nn_embedding():
+    """nn.Embedding raises IndexError for an id outside its table (generator.py:143-151 call it); the fused gather kernel would
+    map such an id to a zero row, so the eager entry checks the ids on the host."""
+    g, _ = build("SPEECH_UNITS", 96)
+    feats = det_input("ids.feats", (2, 3, 256)).cuda()
+    zero = torch.zeros(2, dtype=torch.long).cuda()
+    n = g.session_embeddings.num_embeddings
+    g(feats, torch.tensor([0, n - 1]).cuda(), zero)                       # the last row is fine
+    with pytest.raises(IndexError):
+        g(feats, torch.tensor([0, n]).cuda(), zero)
+    with pytest.raises(IndexError):
+        g(feats, torch.tensor([-1, 0]).cuda(), zero)

@@ -349,3 +349,21 @@ def test_failed_single_graph_capture_falls_back_to_three_graphs_with_clean_state
     assert fired and not dist.is_initialized()
 
 
+def test_a_loss_term_with_weight_zero_is_logged_with_its_value_and_trains_nothing():
+    """The reference logs every enabled loss term itself (train.py:213-262), whatever its weight.  With the multi-TD and the
+    feature-matching weights set to 0 the step reports the same term values as the default step does on the same weights and
+    batch, the generator loss loses exactly those two summands, and the generated EMG (step 0: before any update) is equal."""
+    name = "step_c48_b3"
+    batch = to_batch(cases.step_batch(name, 0))
+    cfg, netG, netD, optG, optD, step = build(name)
+    ref = step.read_stats(step(batch))
+    cfg2, netG2, netD2, optG2, optD2, step2 = build(name)
+    w_td, w_fm = float(cfg2.train.loss_multi_td_weight), float(cfg2.train.loss_feat_match_weight)
+    cfg2.train.loss_multi_td_weight = 0.0
+    cfg2.train.loss_feat_match_weight = 0.0
+    got = step2.read_stats(step2(batch))
+    assert abs(got["multi_td"] - ref["multi_td"]) <= 1e-6 * abs(ref["multi_td"]) and ref["multi_td"] != 0.0
+    assert abs(got["feature_matching"] - ref["feature_matching"]) <= 1e-6 * abs(ref["feature_matching"])
+    want = ref["generator"] - w_td * ref["multi_td"] - w_fm * ref["feature_matching"]
+    assert abs(got["generator"] - want) <= 1e-5 * abs(ref["generator"]), (got["generator"], want)
+    assert got["discriminator"] == ref["discriminator"]

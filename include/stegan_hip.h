@@ -36,6 +36,10 @@ extern "C" {
 
 #define STEGAN_OK 0
 #define STEGAN_E_ARG (-1)
+/* informational success of the *_hx conv entry points: the launch went to the one-tile-per-CU kernels of round 5
+ * (conv_tile.hip / conv_tile_wgrad.hip) instead of the round 2-4 kernels -- same results contract; bench.py names the
+ * kernel family of a launch by it.  Callers that only want success treat it as STEGAN_OK. */
+#define STEGAN_OK_TILE 2
 
 #define STEGAN_ABI_VERSION 1
 int stegan_abi_version(void);

@@ -1211,7 +1211,7 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         ta.ntaps = t0.ntaps; ta.kbase = t0.kbase; ta.kstep = t0.kstep; ta.off_min = t0.off_min; ta.step = t0.step;
         ta.in_relu = p.in_relu; ta.out_act = p.out_act; ta.mask_lrelu = p.mask_lrelu;
         const int rc = stegan_tile_conv(ta, s);
-        if (rc != 1) return rc;
+        if (rc != 1) return rc == STEGAN_OK ? STEGAN_OK_TILE : rc;
     }
     const int xgran = (mode == 0 && p.ups) ? 8 : 4;               // slots per 16-byte X item
     // Tile and split-K factor from a small cost model in microseconds, constants measured with the in-kernel stamps and the

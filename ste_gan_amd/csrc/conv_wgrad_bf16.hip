@@ -717,7 +717,7 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
                                    (const float*)workspace, dw, per_tap, sl, d->K, h.k_lo, h.K_eff, (int)rb, ba);
             }
             STEGAN_LAUNCH_CHECK();
-            return STEGAN_OK;
+            return STEGAN_OK_TILE;
         }
     }
     // tile: 128 x 64 x 3 taps for the dense k = 3 layers; single taps take 128 x 128; more taps 64 x 64 x (5 | 8)

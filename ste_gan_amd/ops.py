@@ -142,13 +142,18 @@ PROFILER: Optional[ConvProfiler] = None
 LAST_CONV_KERNEL = ""    # "bf16" | "direct" | "igemm": which kernel family took the most recent conv launch (tests)
 
 
+OK_TILE = 2              # STEGAN_OK_TILE: success, the launch went to the one-tile-per-CU kernels (conv_tile*.hip)
+
+
 def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
+    """Runs one conv launch (``fn`` returns the C status), records it for the profiler when one is on, and returns the status
+    with the informational STEGAN_OK_TILE folded into 0 (LAST_CONV_KERNEL / the profiler's family name say "tile" then)."""
     global LAST_CONV_KERNEL
     if PROFILER is None:
         rc = fn()
         if rc != 1:
-            LAST_CONV_KERNEL = kind
-        return rc
+            LAST_CONV_KERNEL = "tile" if rc == OK_TILE else kind
+        return 0 if rc == OK_TILE else rc
     name, nominal, live = PROFILER.plan(d, mode)
     if kind == "direct":
         name = "conv_direct_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
@@ -163,13 +168,15 @@ def _timed(d: ConvDesc, mode: int, fn, kind: str = "igemm"):
     e0.record()
     rc = fn()
     e1.record()
+    if rc == OK_TILE:
+        name = "conv_tile_wgrad_kernel" if mode == 2 else "conv_tile_kernel" + ("<fwd>" if mode == 0 else "<bwd_data>")
     if rc != 1:
-        LAST_CONV_KERNEL = kind
+        LAST_CONV_KERNEL = "tile" if rc == OK_TILE else kind
         PROFILER.pairs.append((first, (_lib.lib().stegan_kernel_timing_count() - first) if PROFILER.kernel_timestamps else 0))
         PROFILER.records.append((name, nominal, live, e0, e1,
                                  (mode, d.B, d.Cin, d.Cout, d.K, d.stride, d.dilation, d.groups, d.upsample, d.Tin, d.Tout,
                                   d.pad, d.in_act, d.out_act)))
-    return rc
+    return 0 if rc == OK_TILE else rc
 
 def profiler_by_shape(prof: "ConvProfiler"):
     """(mode, shape) -> [launches, total ms, nominal MACs] for diagnostics."""
@@ -623,9 +630,9 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
                 rc = _lib.lib().stegan_conv1d_bwd_weight_hxd(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw), _p(db),
                                                              _p(ws), min(room, dw.numel() * 64), C.byref(item), _stream())
                 if rc != 1:
-                    check(rc, "stegan_conv1d_bwd_weight_hxd")
                     global LAST_CONV_KERNEL
-                    LAST_CONV_KERNEL = "bf16"
+                    LAST_CONV_KERNEL = "tile" if rc == OK_TILE else "bf16"
+                    check(0 if rc == OK_TILE else rc, "stegan_conv1d_bwd_weight_hxd")
                     if item.slices > 0:
                         st[1] = used + ((int(item.used_floats) + 63) & ~63)
                         _WG_DEFERRED.append((item, dw))

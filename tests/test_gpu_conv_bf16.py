@@ -20,6 +20,8 @@ OPERAND = ("bf16", torch.bfloat16)
 # accumulation inside the MFMA leaves.  (fp16 products carry 22 significant bits against bf16's 16, so the MFMA's fp32 sums
 # round more of them away: the f16 module runs with 2x this.)
 TOL = 2e-5
+# the 2-byte-operand kernel families: the round 2-4 kernels ("bf16") and the one-tile-per-CU kernels of round 5 ("tile")
+HALF_KERNELS = ("bf16", "tile")
 
 EXTRA = [
     (64, 96, 96, 3, 1, 27, 27, 1, 1, True, 192),     # 128 x 128 tiles, d = 27 halo, N = 12288
@@ -109,20 +111,20 @@ def test_conv_bf16_fwd_bwd_data(cfg, images=False):
         k_fwd = ops.LAST_CONV_KERNEL
         dxe = ops.conv1d_bwd_data(dyg, wg, sg, xg if relu else None, addg, c, Tin, wb)
         k_bwd = ops.LAST_CONV_KERNEL
-        if k_fwd == "bf16" and Cout % 8 == 0 and (Cout // g) % 8 == 0 and Cout >= 16:
+        if k_fwd in HALF_KERNELS and Cout % 8 == 0 and (Cout // g) % 8 == 0 and Cout >= 16:
             assert torch.equal(y.h.view(torch.int16), make_image(y).view(torch.int16)), "output image != bf16(y)"
-        if k_bwd == "bf16" and up == 1 and Cin % 8 == 0 and (Cin // g) % 8 == 0 and Cin >= 16:
+        if k_bwd in HALF_KERNELS and up == 1 and Cin % 8 == 0 and (Cin // g) % 8 == 0 and Cin >= 16:
             assert torch.equal(dxe.h.view(torch.int16), make_image(dxe).view(torch.int16)), "input-gradient image != bf16(dx)"
     finally:
         ops.set_compute_dtype("f32")
     cin_g, cout_g = Cin // g, Cout // g
     # shapes the bf16 kernel declines run on the implicit-GEMM kernel from the raw tensor (bf16 mode keeps no fp32 copies)
-    assert k_fwd == ("bf16" if (cin_g >= 8 and cout_g >= 8) else "igemm"), k_fwd
-    assert k_bwd == ("bf16" if (cout_g >= 8 and cin_g >= 8) else "igemm"), k_bwd
+    assert (k_fwd in HALF_KERNELS) if (cin_g >= 8 and cout_g >= 8) else (k_fwd == "igemm"), k_fwd
+    assert (k_bwd in HALF_KERNELS) if (cout_g >= 8 and cin_g >= 8) else (k_bwd == "igemm"), k_bwd
     for got, ref, f32, kern in ((y, y_ref, y_f32, k_fwd), (dxe, dx_ref, dx_f32, k_bwd)):
         got = got.double().cpu()
         scale_ = float(f32.abs().max())
-        if kern == "bf16":
+        if kern in HALF_KERNELS:
             assert float((got - ref).abs().max()) <= TOL * scale_, (kern, float((got - ref).abs().max()), scale_)
             assert float((got - f32).abs().max()) <= 3e-2 * scale_
         else:                                             # shape left to the exact fp32 kernel
@@ -180,10 +182,10 @@ def test_conv_bf16_bwd_weight(cfg, images=False):
     elif Cin // g < 16 or Cout // g < 16:
         assert kern == "igemm", kern                       # narrow groups stay on the exact fp32 kernels
     elif s == 1:
-        assert kern == "bf16", kern                        # (strided layers with long halo'd rows may not fit: fp32 then)
+        assert kern in HALF_KERNELS, kern                        # (strided layers with long halo'd rows may not fit: fp32 then)
     got = dw.double().cpu() - 0.25
     scale_ = float(dw_f32.abs().max())
-    if kern == "bf16":
+    if kern in HALF_KERNELS:
         assert float((got - dw_ref).abs().max()) <= 1.5 * TOL * scale_ + 1e-6, (float((got - dw_ref).abs().max()), scale_)
         assert float((got - dw_f32).abs().max()) <= 3e-2 * scale_
     else:
@@ -297,7 +299,7 @@ def test_weight_gradient_accumulates_onto_a_non_constant_dw(slices, monkeypatch)
                 ops._attach_image(xg, make_image(xg)); ops._attach_image(dyg, make_image(dyg))
             ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
             ops.conv1d_bwd_weight(xg, dyg, c, dw, db)
-            assert ops.LAST_CONV_KERNEL == "bf16"
+            assert ops.LAST_CONV_KERNEL in ("bf16", "tile")
             err = (dw.double().cpu() - init.double() - 2 * ref).abs()
             assert float(err.max()) <= 3e-5 * float(ref.abs().max()), err.amax((0, 1)).tolist()
     finally:

@@ -61,5 +61,5 @@ def test_f16_overflow_becomes_inf_not_garbage():
     w = torch.full((32, 32, 3), 0.01, device="cuda")
     wf, wb = ops.prep_weights(w, c, None, None)
     y = ops.conv1d_fwd(x, w, None, None, None, c, wf)
-    assert ops.LAST_CONV_KERNEL == "bf16"
+    assert ops.LAST_CONV_KERNEL in ("bf16", "tile")
     assert torch.isinf(y[0, :, 4:7]).all() and torch.isfinite(y[1]).all()

@@ -165,5 +165,9 @@ static inline int bias_grad_slices(int B, int C, int T) {
 }
 
 // conv_wgrad.hip: direct weight-gradient kernel; returns 1 when the caller should use the generic implicit GEMM
+// conv_wgrad_small.hip: the 8-input-channel first layers of the discriminators (exact fp32, register-blocked); returns 1 when the
+// shape is not one of them (or there is no workspace for its slabs)
+int stegan_wgrad_small(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db, float* workspace,
+                       int64_t workspace_floats, hipStream_t stream);
 int stegan_wgrad_direct(const stegan_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
                         float* workspace, int64_t workspace_floats, hipStream_t stream);

@@ -432,6 +432,8 @@ static int bwd_weight_impl(const stegan_conv_desc* d, const float* x, const floa
     int rc = fill_common(d, p);
     if (rc) return rc;
     STEGAN_CHECK_ARG(x && dy && dw);
+    rc = stegan_wgrad_small(d, x, dy, dw, db, workspace, workspace_floats, (hipStream_t)stream);
+    if (rc != 1) return rc;
     rc = stegan_wgrad_direct(d, x, dy, dw, db, workspace, workspace_floats, (hipStream_t)stream);
     if (rc != 1) return rc;
     p.x = x; p.dy = dy; p.out = dw; p.db = db;

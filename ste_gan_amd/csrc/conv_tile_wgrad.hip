@@ -5,7 +5,7 @@
 // Why: the generator's backward pass is bound by its weight gradients, not by the input-gradient chain -- 41 layers x
 // (22 us launch + 7 us slab sum) on four side streams.  Same recipe as conv_tile.hip:
 //
-//   * a block owns 48 output channels x 48 input channels x all live taps (<= 3) of dW for ONE slice of the batch; tiles x
+//   * a block owns 48 output channels x 48 input channels x all live taps (<= 5) of dW for ONE slice of the batch; tiles x
 //     slices ~ one block per CU.  Slices > 1 write slabs [slice][co][ci][tap] that the caller's ordered reduce adds into dW
 //     (conv_wgrad_bf16.hip); one slice adds straight into dW;
 //   * both operands come as activation images [b][C / 8][T][8] and are staged by 4 producer waves with LDS-DMA into
@@ -16,9 +16,13 @@
 //     channels 4 p .. 4 p + 3 and receives 4 consecutive slots of channel (lane & 15); every row has its own address, so a tap
 //     is a slot offset and the x rows of a k-step may sit in different samples' segments (T % 4 == 0: a 4-row block never
 //     straddles two samples);
-//   * the consumer waves split the chunk's k-steps (32 columns each) and meet in LDS at the end, tap by tap, in a fixed order
-//     (bit-reproducible); the summed tile is laid out as dW's rows in LDS and added with 16-byte read-modify-writes of whole
-//     rows (48 ci x K floats are contiguous in dW);
+//   * a consumer wave owns ONE tap and every nkg-th k-step (32 columns) of the chunk: 9 accumulator tiles, 12 transposed reads
+//     per 9 MFMAs.  (The first version gave every wave all taps of its k-steps -- 27 tiles, 108 accumulator registers, one
+//     k-step per wave and barrier, so each k-step's LDS latency lay open -- and met tap by tap in LDS behind six barriers: the
+//     stamps (scripts/tile_wgrad_stamps.py) showed 2700-3500 cycles per chunk against 1400 of DMA, and 8000 cycles for the
+//     meeting.)  The waves of a tap meet once in LDS, in a fixed order (bit-reproducible); the summed tile is laid out as dW's
+//     rows and added with 16-byte read-modify-writes of whole rows (48 ci x K floats are contiguous in dW), the old values
+//     fetched before the meeting;
 //   * the bias gradient rides in the same grid (blocks behind the tiles), as in conv_wgrad_bf16.hip.
 #include "conv_tile.h"
 
@@ -42,7 +46,8 @@ constexpr unsigned G_OOB = 0x7ffff000u;
 constexpr int GX_MAX = 12;                   // x DMA items per producer wave and chunk
 constexpr int GY_MAX = 8;                    // dy DMA items per producer wave and chunk
 constexpr int GT = 48;                       // tile: 48 x 48 x taps
-constexpr int KT_MAX = 3;
+constexpr int KT_MAX = 5;
+constexpr int G_PRE = 5;                     // 16-byte pieces of the tile per consumer thread (48 x 12 Keff pieces over ncons x 64 threads)
 constexpr int G_LDS_MAX = 160 * 1024 - 256;
 
 struct GK {
@@ -56,7 +61,7 @@ struct GK {
     int B, Cin, Cout, K, k_lo, Keff, Tin, Tout, ups, relu;
     int CBx, CBy;                 // channel blocks per sample of the two images
     int off_min, step;            // x slot 0 of a segment is source position off_min; taps are `step` slots apart
-    int ncons, nthreads;
+    int ncons, nthreads, nkg;     // consumer waves = Keff taps x nkg k-step groups
     int CS, cols, KSC;            // samples per chunk, dense columns per chunk, k-steps per chunk
     int SEGW, XSLOT, DSLOT;       // slots per x segment, per x plane, per dy plane (multiples of 64)
     int nX, nY, xseg, yseg;       // DMA items per chunk, items per plane
@@ -65,7 +70,7 @@ struct GK {
     int MT, NTl, tiles;
     int x_samp, y_samp;           // bytes between samples of the images
     int bias_first, bias_vec, bias_mode;   // 0 none | 1 inside the tile blocks (one slice) | 2 blocks behind the tiles
-    FastDiv fdT, fdSEGW, fdXseg, fdYseg, fdMT, fdTiles, fdTb;
+    FastDiv fdT, fdSEGW, fdXseg, fdYseg, fdMT, fdTiles, fdTb, fdNkg, fdRow4;
 #ifdef STEGAN_STAMPS
     unsigned long long* stamps;
 #endif
@@ -88,13 +93,22 @@ __device__ __forceinline__ unsigned g_sdiv(unsigned n, const FastDiv& f) {
     return (unsigned)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
 }
 
-__global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
+__global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
     extern __shared__ __align__(16) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+#ifdef STEGAN_STAMPS
+#define GSTAMP(i_) if (k.stamps && threadIdx.x == 0) k.stamps[(size_t)blockIdx.x * 16 + (i_)] = __builtin_amdgcn_s_memtime();
+#define GPSTAMP(i_) if (k.stamps && (int)threadIdx.x == k.ncons * 64) k.stamps[(size_t)blockIdx.x * 16 + (i_)] = __builtin_amdgcn_s_memtime();
+    if (k.stamps && threadIdx.x == 0) k.stamps[(size_t)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GSTAMP(i_)
+#define GPSTAMP(i_)
+#endif
+    GSTAMP(0)
     if ((int)blockIdx.x >= k.bias_first) {                            // bias-gradient blocks (bias_mode 2): one output channel each
         if (tid >= 256) return;
         bias_grad_body(k.dy, k.db, k.B, k.Cout, k.Tout, k.B, k.fdTb, k.bias_vec, (int)blockIdx.x - k.bias_first, 0);
@@ -116,9 +130,51 @@ __global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
         asm volatile("" : "+s"(xbase), "+s"(ybase), "+s"(xbytes), "+s"(ybytes));
         const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)xbase, 0, xbytes, 0x00020000);
         const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, ybytes, 0x00020000);
-        // per-lane offsets of this wave's items (i = pw + 4 n), relative to the chunk's first sample; the chunk is a scalar
+        // per-lane offsets of this wave's items (i = pw + 4 n), relative to the chunk's first sample; the chunk is a scalar.
+        // The first chunk's loads leave as soon as their offsets exist (dy, then x): the set-up of the other half runs under them
         unsigned xv[GX_MAX], yv[GY_MAX];
         const int xlive = k.CS * k.SEGW, Te = k.Tin << k.ups;
+        const int nXw = k.nX > pw ? (k.nX - pw + 3) >> 2 : 0, nYw = k.nY > pw ? (k.nY - pw + 3) >> 2 : 0;
+        const int ipc = nXw + nYw;
+        int chunk_x = k.CS * k.x_samp, chunk_y = k.CS * k.y_samp, stage_b = k.stage, ystage_b = k.ystage;
+        int x0 = bs0 * k.x_samp, y0 = bs0 * k.y_samp;
+        int nXi = nXw, nYi = nYw;
+        asm volatile("" : "+s"(chunk_x), "+s"(chunk_y), "+s"(stage_b), "+s"(ystage_b), "+s"(x0), "+s"(y0));
+#define GL_X_IT(n_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(Xd_ + (n_) * 4096), 16, (int)xv[n_], cx_, 0, 0);
+#define GL_Y_IT(n_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Yd_ + (n_) * 4096), 16, (int)yv[n_], cy_, 0, 0);
+#define GL_ISSUE_Y(c_, st_)                                                                                     \
+        {                                                                                                       \
+            char* Yd_ = smem + (st_) * stage_b + pw * 1024;                                                     \
+            const int cy_ = y0 + (c_) * chunk_y;                                                                \
+            int nYw_ = nYi;                                                                                     \
+            asm volatile("" : "+s"(nYw_));                                                                      \
+            if (nYw_ > 0) { GL_Y_IT(0) if (nYw_ > 1) { GL_Y_IT(1) if (nYw_ > 2) { GL_Y_IT(2) if (nYw_ > 3) { GL_Y_IT(3) \
+            if (nYw_ > 4) { GL_Y_IT(4) if (nYw_ > 5) { GL_Y_IT(5) if (nYw_ > 6) { GL_Y_IT(6) if (nYw_ > 7) { GL_Y_IT(7) \
+            } } } } } } } }                                                                                     \
+        }
+#define GL_ISSUE_X(c_, st_)                                                                                     \
+        {                                                                                                       \
+            char* Xd_ = smem + (st_) * stage_b + pw * 1024 + ystage_b;                                          \
+            const int cx_ = x0 + (c_) * chunk_x;                                                                \
+            int nXw_ = nXi;                                                                                     \
+            asm volatile("" : "+s"(nXw_));                                                                      \
+            if (nXw_ > 0) { GL_X_IT(0) if (nXw_ > 1) { GL_X_IT(1) if (nXw_ > 2) { GL_X_IT(2) if (nXw_ > 3) { GL_X_IT(3) \
+            if (nXw_ > 4) { GL_X_IT(4) if (nXw_ > 5) { GL_X_IT(5) if (nXw_ > 6) { GL_X_IT(6) if (nXw_ > 7) { GL_X_IT(7) \
+            if (nXw_ > 8) { GL_X_IT(8) if (nXw_ > 9) { GL_X_IT(9) if (nXw_ > 10) { GL_X_IT(10) if (nXw_ > 11) { GL_X_IT(11) \
+            } } } } } } } } } } } }                                                                             \
+        }
+#define GL_ISSUE(c_, st_) GL_ISSUE_Y(c_, st_) GL_ISSUE_X(c_, st_)
+        static_assert(GX_MAX == 12 && GY_MAX == 8, "the item switches are written out for 12 / 8 items");
+#pragma unroll
+        for (int n = 0; n < GY_MAX; ++n) {
+            const unsigned i = (unsigned)(pw + 4 * n);
+            const unsigned cb = g_sdiv(i, k.fdYseg), sg = i - cb * (unsigned)k.yseg;
+            const unsigned slot = sg * 64u + (unsigned)lane;
+            const unsigned g = fd_div(slot, k.fdT), t = slot - g * (unsigned)k.Tout;
+            const bool ok = ((int)slot < k.cols) & ((int)cb < 6) & (m0 / 8 + (int)cb < k.CBy);
+            yv[n] = ok ? (unsigned)((((int)g * k.CBy + m0 / 8 + (int)cb) * k.Tout + (int)t) * 16) : G_OOB;
+        }
+        if (nch > 0) GL_ISSUE_Y(0, 0)
 #pragma unroll
         for (int n = 0; n < GX_MAX; ++n) {
             const unsigned i = (unsigned)(pw + 4 * n);
@@ -129,40 +185,8 @@ __global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
             const bool ok = ((int)slot < xlive) & (q >= 0) & (q < Te) & ((int)cb < 6) & (n0 / 8 + (int)cb < k.CBx);
             xv[n] = ok ? (unsigned)((((int)g * k.CBx + n0 / 8 + (int)cb) * k.Tin + (q >> k.ups)) * 16) : G_OOB;
         }
-#pragma unroll
-        for (int n = 0; n < GY_MAX; ++n) {
-            const unsigned i = (unsigned)(pw + 4 * n);
-            const unsigned cb = g_sdiv(i, k.fdYseg), sg = i - cb * (unsigned)k.yseg;
-            const unsigned slot = sg * 64u + (unsigned)lane;
-            const unsigned g = fd_div(slot, k.fdT), t = slot - g * (unsigned)k.Tout;
-            const bool ok = ((int)slot < k.cols) & ((int)cb < 6) & (m0 / 8 + (int)cb < k.CBy);
-            yv[n] = ok ? (unsigned)((((int)g * k.CBy + m0 / 8 + (int)cb) * k.Tout + (int)t) * 16) : G_OOB;
-        }
-        const int nXw = k.nX > pw ? (k.nX - pw + 3) >> 2 : 0, nYw = k.nY > pw ? (k.nY - pw + 3) >> 2 : 0;
-        const int ipc = nXw + nYw;
-        int chunk_x = k.CS * k.x_samp, chunk_y = k.CS * k.y_samp, stage_b = k.stage, ystage_b = k.ystage;
-        int x0 = bs0 * k.x_samp, y0 = bs0 * k.y_samp;
-        int nXi = nXw, nYi = nYw;
-        asm volatile("" : "+s"(chunk_x), "+s"(chunk_y), "+s"(stage_b), "+s"(ystage_b), "+s"(x0), "+s"(y0));
-#define GL_X_IT(n_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(Xd_ + (n_) * 4096), 16, (int)xv[n_], cx_, 0, 0);
-#define GL_Y_IT(n_) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Yd_ + (n_) * 4096), 16, (int)yv[n_], cy_, 0, 0);
-#define GL_ISSUE(c_, st_)                                                                                       \
-        {                                                                                                       \
-            char* Yd_ = smem + (st_) * stage_b + pw * 1024;                                                     \
-            char* Xd_ = Yd_ + ystage_b;                                                                         \
-            const int cx_ = x0 + (c_) * chunk_x, cy_ = y0 + (c_) * chunk_y;                                     \
-            int nXw_ = nXi, nYw_ = nYi;                                                                         \
-            asm volatile("" : "+s"(nXw_), "+s"(nYw_));                                                          \
-            if (nYw_ > 0) { GL_Y_IT(0) if (nYw_ > 1) { GL_Y_IT(1) if (nYw_ > 2) { GL_Y_IT(2) if (nYw_ > 3) { GL_Y_IT(3) \
-            if (nYw_ > 4) { GL_Y_IT(4) if (nYw_ > 5) { GL_Y_IT(5) if (nYw_ > 6) { GL_Y_IT(6) if (nYw_ > 7) { GL_Y_IT(7) \
-            } } } } } } } }                                                                                     \
-            if (nXw_ > 0) { GL_X_IT(0) if (nXw_ > 1) { GL_X_IT(1) if (nXw_ > 2) { GL_X_IT(2) if (nXw_ > 3) { GL_X_IT(3) \
-            if (nXw_ > 4) { GL_X_IT(4) if (nXw_ > 5) { GL_X_IT(5) if (nXw_ > 6) { GL_X_IT(6) if (nXw_ > 7) { GL_X_IT(7) \
-            if (nXw_ > 8) { GL_X_IT(8) if (nXw_ > 9) { GL_X_IT(9) if (nXw_ > 10) { GL_X_IT(10) if (nXw_ > 11) { GL_X_IT(11) \
-            } } } } } } } } } } } }                                                                             \
-        }
-        static_assert(GX_MAX == 12 && GY_MAX == 8, "the item switches are written out for 12 / 8 items");
-        if (nch > 0) GL_ISSUE(0, 0)
+        GPSTAMP(6)
+        if (nch > 0) GL_ISSUE_X(0, 0)
         int st_in = 1 % NS, issued = 1;
         for (int j = 0; j < nch; ++j) {
             g_wait_vmcnt((issued - 1 - j) * ipc);
@@ -174,7 +198,10 @@ __global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
                 ++issued;
             }
         }
+        GPSTAMP(7)
 #undef GL_ISSUE
+#undef GL_ISSUE_X
+#undef GL_ISSUE_Y
 #undef GL_X_IT
 #undef GL_Y_IT
         return;
@@ -182,102 +209,33 @@ __global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
 
     // ================= consumers =================
     const int l15 = lane & 15, kg = lane >> 4, q4 = l15 >> 2, p4 = l15 & 3;
-    const int ncw = k.ncons, KSC = k.KSC, ntaps = k.Keff;
+    const int ncw = k.ncons, KSC = k.KSC, ntaps = k.Keff, nkg = k.nkg;
+    const int tp = (int)g_sdiv((unsigned)wave, k.fdNkg), kgp = wave - tp * nkg;        // this wave's tap, its k-step group
     // lane-constant parts of the transposed reads: channel quad p4 of group i sits in plane 2 i + (p4 >> 1), bytes 8 (p4 & 1)
     const int pl = (p4 >> 1), sub = (p4 & 1) * 8;
-    const int a_pl = pl * k.DSLOT * 16 + sub, b_pl = pl * k.XSLOT * 16 + sub;
+    const int a_pl = pl * k.DSLOT * 16 + sub, b_pl = pl * k.XSLOT * 16 + sub + tp * k.step * 16;
     const int a_grp = 2 * k.DSLOT * 16, b_grp = 2 * k.XSLOT * 16;      // bytes between the planes of neighbouring channel groups
-    const int tapB = k.step * 16;
 
-    f32x4 acc[KT_MAX][3][3];
-#pragma unroll
-    for (int tp = 0; tp < KT_MAX; ++tp)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[tp][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const bool relu = k.relu != 0;
-    int st_c = 0;
-    for (int jc = 0; jc < nch; ++jc) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* Ycur = smem + st_c * k.stage;
-        const char* Xcur = Ycur + k.ystage;
-        for (int s = wave; s < KSC; s += ncw) {
-            // rows (columns of the layer) 32 s + 8 kg + q4 and + 4: dense slot for dy, (sample segment, t) for x
-            const unsigned c0 = (unsigned)(32 * s + 8 * kg + q4), c1 = c0 + 4u;
-            const unsigned g0 = fd_div(c0, k.fdT), g1 = fd_div(c1, k.fdT);
-            const int xs0 = (int)g0 * k.SEGW + (int)(c0 - g0 * (unsigned)k.Tout), xs1 = (int)g1 * k.SEGW + (int)(c1 - g1 * (unsigned)k.Tout);
-            const char* ya0 = Ycur + a_pl + (int)c0 * 16;
-            const char* xb0 = Xcur + b_pl + xs0 * 16;
-            const int dx1 = (xs1 - xs0) * 16;
-            hx8 af[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(ya0 + i * a_grp));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(ya0 + i * a_grp + 64));
-                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                af[i] = __builtin_bit_cast(hx8, v);
-            }
-#pragma unroll
-            for (int tp = 0; tp < KT_MAX; ++tp) {
-                if (tp < ntaps) {
-                    hx8 bf[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const char* pb = xb0 + j * b_grp + tp * tapB;
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(pb));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(pb + dx1));
-                        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        if (relu) v = __builtin_elementwise_max(v, (s16x8)(0));
-                        bf[j] = __builtin_bit_cast(hx8, v);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) acc[tp][i][j] = TILE_MFMA(af[i], bf[j], acc[tp][i][j]);
-                }
-            }
-        }
-        st_c = st_c + 1 == NS ? 0 : st_c + 1;
-    }
-
-    // ---- the consumer waves' partial tiles meet in LDS, tap by tap, in a fixed order; the sums are laid out as the rows of dW
-    // ([co][ci][tap], 48 x 48 x Keff floats) behind the exchange area
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                     // every consumer has read its last operands: LDS is free
-    asm volatile("" ::: "memory");
-    f32x4* const red = (f32x4*)smem;                                  // [wave][9][64] x 16 B
-    float* const rows = (float*)(smem + ncw * 9 * 64 * 16);           // [48][48 * Keff]
+    // ---- while the producers set up and the first chunk is in flight (about 4500 cycles): the tile's old values (one slice:
+    // dW += tile) are fetched -- they meet the sums after the LDS exchange -- and the bias gradient is summed.  A row of the tile is
+    // 48 * Keff consecutive floats of its row of dW when every tap is live and the tile is whole: 12 Keff 16-byte pieces
+    const int nthr = ncw * 64;
+    const int Keff = ntaps, K = k.K;
     const int rowf = GT * ntaps;
-    for (int tp = 0; tp < ntaps; ++tp) {
+    float* const dst = k.slices > 1 ? k.partial + (size_t)slice * k.Cout * k.Cin * Keff : k.dw;
+    const int dK = k.slices > 1 ? Keff : K, dk0 = k.slices > 1 ? 0 : k.k_lo;       // taps per (co, ci) of the destination
+    const bool acc_into = k.slices == 1;
+    const int co_n = min(GT, k.Cout - m0), ci_n = min(GT, k.Cin - n0);
+    const bool vec = dK == Keff && ci_n == GT && ((k.Cin * dK) & 3) == 0 && ((n0 * dK) & 3) == 0;
+    const int v4row = GT * Keff / 4, total4 = co_n * v4row;
+    f32x4 old[G_PRE];
+    if (vec && acc_into) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const f32x4 v = tp == 0 ? acc[0][i][j] : (tp == 1 ? acc[1][i][j] : acc[2][i][j]);
-                red[(wave * 9 + i * 3 + j) * 64 + lane] = v;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        for (int tau = wave; tau < 9; tau += ncw) {
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int pwv = 0; pwv < ncw; ++pwv) {
-                const f32x4 t = red[(pwv * 9 + tau) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += t[e];
-            }
-            const int i = (tau * 11) >> 5, j = tau - 3 * i;           // tau / 3, tau % 3
-            // D[row = co 16 i + 4 kg + e][col = ci 16 j + l15]
-#pragma unroll
-            for (int e = 0; e < 4; ++e) rows[(16 * i + 4 * kg + e) * rowf + (16 * j + l15) * ntaps + tp] = v[e];
+        for (int u = 0; u < G_PRE; ++u) {
+            const int e = tid + u * nthr;
+            const int r = (int)fd_div((uint32_t)e, k.fdRow4), c4 = e - r * v4row;
+            if (e < total4) old[u] = *(const f32x4*)(dst + ((size_t)(m0 + r) * k.Cin + n0) * dK + c4 * 4);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
     }
     // ---- bias gradient inside the tile blocks (one slice: B * T is small -- the T = 12 ... 48 layers): the NTl tiles of an output
     // channel group share its 48 channels; consumer wave w of tile nt sums channel m0 + nt * cpb + w over the whole batch in
@@ -298,36 +256,121 @@ __global__ __launch_bounds__(768) void conv_tile_wgrad_kernel(const GK k) {
             if (lane == 0) k.db[c] += sacc;
         }
     }
-    // ---- rows of the tile -> dW (+=) or the slice's slab (=).  A row of the tile is 48 * Keff consecutive floats of its row of
-    // dW when every tap is live; otherwise element by element
-    const int nthr = ncw * 64;
-    const int Keff = ntaps, K = k.K;
-    float* const dst = k.slices > 1 ? k.partial + (size_t)slice * k.Cout * k.Cin * Keff : k.dw;
-    const int dK = k.slices > 1 ? Keff : K, dk0 = k.slices > 1 ? 0 : k.k_lo;       // taps per (co, ci) of the destination
-    const bool acc_into = k.slices == 1;
-    const int co_n = min(GT, k.Cout - m0), ci_n = min(GT, k.Cin - n0);
-    if (dK == Keff && ((ci_n * Keff) & 3) == 0 && ((k.Cin * dK) & 3) == 0 && ((n0 * dK) & 3) == 0) {
-        const int v4row = ci_n * Keff / 4, total = co_n * v4row;
-        for (int e = tid; e < total; e += nthr) {
-            const int r = e / v4row, c4 = e - r * v4row;
-            const f32x4 v = *(const f32x4*)(rows + r * rowf + c4 * 4);
-            f32x4* p = (f32x4*)(dst + ((size_t)(m0 + r) * k.Cin + n0) * dK + c4 * 4);
-            if (acc_into) { f32x4 o = *p; o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3]; *p = o; }
-            else *p = v;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool relu = k.relu != 0;
+    int st_c = 0;
+    for (int jc = 0; jc < nch; ++jc) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (jc == 0) { GSTAMP(1) }
+        const char* Ycur = smem + st_c * k.stage;
+        const char* Xcur = Ycur + k.ystage;
+        for (int s = kgp; s < KSC; s += nkg) {
+            // rows (columns of the layer) 32 s + 8 kg + q4 and + 4: dense slot for dy, (sample segment, t) for x
+            const unsigned c0 = (unsigned)(32 * s + 8 * kg + q4), c1 = c0 + 4u;
+            const unsigned g0 = fd_div(c0, k.fdT), g1 = fd_div(c1, k.fdT);
+            const int xs0 = (int)g0 * k.SEGW + (int)(c0 - g0 * (unsigned)k.Tout), xs1 = (int)g1 * k.SEGW + (int)(c1 - g1 * (unsigned)k.Tout);
+            const char* ya0 = Ycur + a_pl + (int)c0 * 16;
+            const char* xb0 = Xcur + b_pl + xs0 * 16;
+            const int dx1 = (xs1 - xs0) * 16;
+            hx8 af[3], bf[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(ya0 + i * a_grp));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(ya0 + i * a_grp + 64));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[i] = __builtin_bit_cast(hx8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const char* pb = xb0 + j * b_grp;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(pb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr_t)(pb + dx1));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                if (relu) v = __builtin_elementwise_max(v, (s16x8)(0));
+                bf[j] = __builtin_bit_cast(hx8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = TILE_MFMA(af[i], bf[j], acc[i][j]);
+        }
+        st_c = st_c + 1 == NS ? 0 : st_c + 1;
+    }
+    GSTAMP(2)
+    GSTAMP(3)
+
+    // ---- the waves of a tap meet in LDS, in a fixed order; the sums are laid out as the rows of dW ([co][ci][tap],
+    // 48 x 48 x Keff floats) behind the exchange area
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                     // every consumer has read its last operands: LDS is free
+    asm volatile("" ::: "memory");
+    f32x4* const red = (f32x4*)smem;                                  // [wave][9][64] x 16 B
+    float* const rows = (float*)(smem + ncw * 9 * 64 * 16);           // [48][48 * Keff]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) red[(wave * 9 + i * 3 + j) * 64 + lane] = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int u = wave; u < 9 * ntaps; u += ncw) {
+        const int tpu = (u * 57) >> 9, tau = u - 9 * tpu;              // u / 9, u % 9 (u < 45)
+        f32x4 v = red[((tpu * nkg) * 9 + tau) * 64 + lane];
+        for (int g = 1; g < nkg; ++g) {
+            const f32x4 t = red[((tpu * nkg + g) * 9 + tau) * 64 + lane];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
+        const int i = (tau * 11) >> 5, j = tau - 3 * i;               // tau / 3, tau % 3
+        // D[row = co 16 i + 4 kg + e][col = ci 16 j + l15]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rows[(16 * i + 4 * kg + e) * rowf + (16 * j + l15) * ntaps + tpu] = v[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    GSTAMP(4)
+    // ---- rows of the tile -> dW (+=) or the slice's slab (=)
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < G_PRE; ++u) {
+            const int e = tid + u * nthr;
+            const int r = (int)fd_div((uint32_t)e, k.fdRow4), c4 = e - r * v4row;
+            if (e < total4) {
+                f32x4 v = *(const f32x4*)(rows + r * rowf + c4 * 4);
+                if (acc_into) { v[0] += old[u][0]; v[1] += old[u][1]; v[2] += old[u][2]; v[3] += old[u][3]; }
+                *(f32x4*)(dst + ((size_t)(m0 + r) * k.Cin + n0) * dK + c4 * 4) = v;
+            }
         }
     } else {
         const int per = ci_n * Keff, total = co_n * per;
         for (int e = tid; e < total; e += nthr) {
             const int r = e / per, c = e - r * per;
-            const int ci = c / Keff, tp = c - ci * Keff;
-            const float v = rows[r * rowf + ci * Keff + tp];
-            float* p = dst + ((size_t)(m0 + r) * k.Cin + n0 + ci) * dK + dk0 + tp;
+            const int ci = c / Keff, tpe = c - ci * Keff;
+            const float v = rows[r * rowf + ci * Keff + tpe];
+            float* p = dst + ((size_t)(m0 + r) * k.Cin + n0 + ci) * dK + dk0 + tpe;
             if (acc_into) *p += v; else *p = v;
         }
     }
+#ifdef STEGAN_STAMPS
+    if (k.stamps && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        k.stamps[(size_t)blockIdx.x * 16 + 5] = __builtin_amdgcn_s_memtime();
+        k.stamps[(size_t)blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
+#undef GSTAMP
+#undef GPSTAMP
 }
 
-struct GOpts { int enable, debug, ns, target; };
+struct GOpts { int enable, debug, ns, target, nkg; };
 const GOpts& g_opts() {
     static const GOpts o = [] {
         GOpts t;
@@ -336,6 +379,7 @@ const GOpts& g_opts() {
         t.debug = getenv("STEGAN_PLAN_DEBUG") != nullptr;
         t.ns = (e = getenv("STEGAN_TILE_WGRAD_NS")) ? atoi(e) : 0;
         t.target = (e = getenv("STEGAN_TILE_WGRAD_TARGET")) ? atoi(e) : 256;
+        t.nkg = (e = getenv("STEGAN_TILE_WGRAD_NKG")) ? atoi(e) : 0;
         return t;
     }();
     return o;
@@ -379,7 +423,12 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     const int nX = 6 * xseg, nY = 6 * yseg;
     if ((nX + 3) / 4 > GX_MAX || (nY + 3) / 4 > GY_MAX) return false;
     const int ystage = nY * 1024, stage = ystage + nX * 1024;
-    int ncons = KSC >= 8 ? 8 : (KSC >= 6 ? 6 : 4);
+    // consumer waves: one tap each, nkg k-step groups per tap, at most 12 (+ 4 producers = 1024 threads)
+    int nkg = 12 / a.Keff;
+    if (o.nkg > 0 && nkg > o.nkg) nkg = o.nkg;
+    if (nkg > KSC) nkg = KSC;
+    const int ncons = a.Keff * nkg;
+    if ((size_t)GT * (GT * a.Keff / 4) > (size_t)G_PRE * ncons * 64) return false;
     const size_t epi = (size_t)ncons * 9 * 64 * 16 + (size_t)GT * GT * a.Keff * 4;
     int NS = o.ns ? o.ns : 3;
     if (NS > nch) NS = nch;
@@ -394,7 +443,7 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     k.ups = a.ups; k.relu = a.relu;
     k.CBx = a.Cin / 8; k.CBy = a.Cout / 8;
     k.off_min = a.k_lo * a.dil - a.pad; k.step = a.dil;
-    k.ncons = ncons; k.nthreads = 64 * (ncons + 4);
+    k.ncons = ncons; k.nthreads = 64 * (ncons + 4); k.nkg = nkg;
     k.CS = CS; k.cols = cols; k.KSC = KSC; k.SEGW = SEGW; k.XSLOT = XSLOT; k.DSLOT = DSLOT;
     k.nX = nX; k.nY = nY; k.xseg = xseg; k.yseg = yseg; k.NS = NS; k.ystage = ystage; k.stage = stage;
     k.slices = slices; k.bps = bps; k.nch = nch; k.MT = MT; k.NTl = NTl; k.tiles = tiles;
@@ -413,10 +462,16 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     k.fdT = make_fastdiv((uint32_t)T); k.fdSEGW = make_fastdiv((uint32_t)SEGW); k.fdXseg = make_fastdiv((uint32_t)xseg);
     k.fdYseg = make_fastdiv((uint32_t)yseg); k.fdMT = make_fastdiv((uint32_t)MT); k.fdTiles = make_fastdiv((uint32_t)tiles);
     k.fdTb = make_fastdiv((uint32_t)(k.bias_vec ? a.Tout / 4 : a.Tout));
+    k.fdNkg = make_fastdiv((uint32_t)nkg); k.fdRow4 = make_fastdiv((uint32_t)(GT * a.Keff / 4));
     return true;
 }
 
 }  // namespace
+
+#ifdef STEGAN_STAMPS
+static unsigned long long* g_wgrad_stamps = nullptr;
+extern "C" int stegan_tile_wgrad_debug_stamps(void* p) { g_wgrad_stamps = (unsigned long long*)p; return 0; }
+#endif
 
 int stegan_tile_wgrad(const TileWgradArgs& a, int* slices_out, int* bias_done, hipStream_t stream) {
     GK k;
@@ -434,7 +489,7 @@ int stegan_tile_wgrad(const TileWgradArgs& a, int* slices_out, int* bias_done, h
                         "NS=%d lds=%zu nX=%d nY=%d XSLOT=%d\n", a.B, a.Cin, a.Cout, a.K, a.Keff, a.dil, a.Tout, a.ups, k.MT, k.NTl, k.slices,
                 k.nch, k.CS, k.KSC, k.ncons, k.NS, lds, k.nX, k.nY, k.XSLOT);
 #ifdef STEGAN_STAMPS
-    k.stamps = nullptr;
+    k.stamps = g_wgrad_stamps;
 #endif
     const unsigned grid = (unsigned)(k.tiles * k.slices + (k.bias_mode == 2 ? a.Cout : 0));
     if (bias_done) *bias_done = (!a.db || k.bias_mode != 0) ? 1 : 0;

@@ -267,6 +267,16 @@ int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const float* x, cons
                                  const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
                                  stegan_wgrad_reduce* deferred, void* stream);
 int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream);
+/* the CHAINED form (round 5): `prev` (nullable, or slices == 0: none) is the pending sum that an earlier call ON THE SAME STREAM
+ * left in its `next`; it is run at the head of this launch -- by the tile kernel's consumer waves while its producers set up,
+ * with the launch boundary as the hand-off (no fences), when the kernel takes the shape; else as a reduce launch of its own --
+ * so a chain of n sliced layers costs one reduce launch (its tail's: stegan_wgrad_reduce_multi(1, &next)) instead of n.  The
+ * slabs of `prev` must stay untouched until this call's kernels have run: give consecutive calls different workspaces.
+ * Same adds in the same order as the reduce kernel: identical results.  Return 1: nothing was enqueued and `prev` is still
+ * pending. */
+int stegan_conv1d_bwd_weight_hxc(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                 const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
+                                 const stegan_wgrad_reduce* prev, stegan_wgrad_reduce* next, void* stream);
 int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
                                const float* const* bias, const float* const* residual, float* const* y,

@@ -50,14 +50,16 @@ def alg_bytes(name, s):
 def join(recs_path, fdir, wdir, out=None):
     from pmc_summary import load
     recs = json.load(open(recs_path))
-    fam_of = lambda n: ("conv_wgrad_bf16" if "wgrad_bf16" in n else "conv_bf16_kernel" if n.startswith("conv_bf16") else None)
+    fam_of = lambda n: ("conv_tile_wgrad_kernel" if n.startswith("conv_tile_wgrad") else "conv_tile_kernel" if n.startswith("conv_tile_kernel")
+                        else "conv_wgrad_bf16" if "wgrad_bf16" in n else "conv_bf16_kernel" if n.startswith("conv_bf16") else None)
     want = collections.defaultdict(list)
     for name, shape in recs:
         if fam_of(name):
             want[fam_of(name)].append((name, shape))
     table = {}
     for fam, rl in want.items():
-        keys = {"conv_bf16_kernel": ("conv_bf16_kernel<",), "conv_wgrad_bf16": ("conv_wgrad_bf16_img_kernel", "conv_wgrad_bf16_one_kernel",
+        keys = {"conv_tile_kernel": ("conv_tile_kernel(",), "conv_tile_wgrad_kernel": ("conv_tile_wgrad_kernel(",),
+                "conv_bf16_kernel": ("conv_bf16_kernel<",), "conv_wgrad_bf16": ("conv_wgrad_bf16_img_kernel", "conv_wgrad_bf16_one_kernel",
                                                                                "conv_wgrad_bf16_kernel")}[fam]
         cols = []
         for d in (fdir, wdir):

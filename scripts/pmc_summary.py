@@ -11,7 +11,10 @@ usage: pmc_summary.py <dirA> <dirB> <dirC> <steps> <out.json> [raw csv prefix]
 The raw per-dispatch rows of the three passes are copied beside the summary (gzip)."""
 import collections, csv, glob, gzip, io, json, shutil, sys
 
-FAMILIES = [("conv_bf16_kernel", ("conv_bf16_kernel", "conv_bf16_multi_kernel")),
+FAMILIES = [("conv_tile_kernel", ("conv_tile_kernel",)),
+            ("conv_tile_wgrad_kernel", ("conv_tile_wgrad_kernel",)),
+            ("wgrad_small", ("wgrad_small_kernel", "wgrad_small_reduce_kernel")),
+            ("conv_bf16_kernel", ("conv_bf16_kernel", "conv_bf16_multi_kernel")),
             ("conv_wgrad_bf16", ("conv_wgrad_bf16_img_kernel", "conv_wgrad_bf16_one_kernel", "conv_wgrad_bf16_kernel")),
             ("conv_wgrad_bf16_reduce", ("conv_wgrad_bf16_reduce_kernel",)),
             ("conv_splitk_epilogue", ("conv_splitk_epilogue_kernel",)),

@@ -38,6 +38,13 @@ struct TileWgradArgs {
     int B, Cin, Cout, K, dil, pad, Tin, Tout, ups, relu;
     int k_lo, Keff;               // live taps
     int bias_in_reduce;           // the caller computes db in its slab reduce when the launch is sliced
+    // a PENDING slab sum of an earlier launch on the same stream (another layer: dw_prev[i] += sum_s slab_prev[s][i] over 16-byte
+    // pieces, every tap live), run by the consumer waves while the producers set up -- the launch boundary is its hand-off, so
+    // no fences and no reduce launch (prev_n4 == 0: none)
+    const float* prev_partial;
+    float* prev_dw;
+    int64_t prev_n4;
+    int prev_slices;
 };
 // 0: launched (*slices_out slabs to sum when > 1; 1: dW has been accumulated; *bias_done: db has been taken care of);
 // 1: declined; other: error status

@@ -57,6 +57,10 @@ struct GK {
     float* dw;                    // slices == 1: accumulate here
     float* db;
     float* partial;               // slices > 1: slabs [slice][Cout][Cin][Keff]
+    const float* prev_partial;    // pending slab sum of an earlier launch (conv_tile.h)
+    float* prev_dw;
+    long prev_n4;
+    int prev_slices;
     unsigned xh_bytes, dyh_bytes;
     int B, Cin, Cout, K, k_lo, Keff, Tin, Tout, ups, relu;
     int CBx, CBy;                 // channel blocks per sample of the two images
@@ -216,6 +220,47 @@ __global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
     const int a_pl = pl * k.DSLOT * 16 + sub, b_pl = pl * k.XSLOT * 16 + sub + tp * k.step * 16;
     const int a_grp = 2 * k.DSLOT * 16, b_grp = 2 * k.XSLOT * 16;      // bytes between the planes of neighbouring channel groups
 
+    // ---- the pending slab sum of the layer before (same stream: its launch is complete).  Same order of adds as
+    // conv_wgrad_bf16_reduce_kernel: identical bits
+    if (k.prev_n4 > 0) {
+        const f32x4* src4 = (const f32x4*)k.prev_partial;
+        f32x4* dw4 = (f32x4*)k.prev_dw;
+        const long n4 = k.prev_n4, stride = (long)k.tiles * k.slices * (ncw * 64);
+        const int ps = k.prev_slices;
+        // three pieces a thread per trip, every load of the trip in flight at once (one memory latency, under the producers'
+        // set-up; a piece per trip was 2-3 dependent latencies: as long as the reduce launch it replaces)
+        for (long i0 = (long)bid * (ncw * 64) + tid; i0 < n4; i0 += 3 * stride) {
+            f32x4 o[3], v[3][4];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const long i = i0 + q * stride;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[q][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (i < n4) {
+                    o[q] = dw4[i];
+                    if (ps == 4) {                                    // the usual slicing: four loads, no loop
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[q][u] = src4[(size_t)u * n4 + i];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const long i = i0 + q * stride;
+                if (i < n4) {
+                    if (ps != 4) {
+                        int sidx = 0;
+                        for (; sidx + 4 <= ps; sidx += 4) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[q][u] += src4[(size_t)(sidx + u) * n4 + i];
+                        }
+                        for (; sidx < ps; ++sidx) v[q][0] += src4[(size_t)sidx * n4 + i];
+                    }
+                    dw4[i] = o[q] + ((v[q][0] + v[q][1]) + (v[q][2] + v[q][3]));
+                }
+            }
+        }
+    }
     // ---- while the producers set up and the first chunk is in flight (about 4500 cycles): the tile's old values (one slice:
     // dW += tile) are fetched -- they meet the sums after the LDS exchange -- and the bias gradient is summed.  A row of the tile is
     // 48 * Keff consecutive floats of its row of dW when every tap is live and the tile is whole: 12 Keff 16-byte pieces
@@ -241,15 +286,29 @@ __global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
     // channel group share its 48 channels; consumer wave w of tile nt sums channel m0 + nt * cpb + w over the whole batch in
     // fp32 (fixed order) and adds it into db -- no extra blocks (which would each hold a whole block's LDS: 768 of them cost
     // three more rounds of blocks)
-    if (k.bias_mode == 1) {
+    if (k.bias_mode == 1 && slice == 0) {
         const int cpb = (GT + k.NTl - 1) / k.NTl;                     // channels per tile block (<= ncons: host)
         const int cl = (int)nt * cpb + wave;                          // channel inside the group
         if (wave < cpb && cl < GT && m0 + cl < k.Cout) {
             const int c = m0 + cl, T4 = k.Tout >> 2, n4 = k.B * T4;
+            const float* base = k.dy + (size_t)c * k.Tout;
+            const size_t bstr = (size_t)k.Cout * k.Tout;
             float sacc = 0.f;
-            for (int r = lane; r < n4; r += 64) {
+            int r = lane;
+            for (; r + 7 * 64 < n4; r += 8 * 64) {                    // eight loads in flight (B * T up to 16 k: 64 a lane)
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ru = r + u * 64;
+                    const int b = (int)fd_div((uint32_t)ru, k.fdTb), t4 = ru - b * T4;
+                    v[u] = *reinterpret_cast<const float4*>(base + (size_t)b * bstr + 4 * t4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sacc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+            }
+            for (; r < n4; r += 64) {
                 const int b = (int)fd_div((uint32_t)r, k.fdTb), t4 = r - b * T4;
-                const float4 v = *reinterpret_cast<const float4*>(k.dy + ((size_t)b * k.Cout + c) * k.Tout + 4 * t4);
+                const float4 v = *reinterpret_cast<const float4*>(base + (size_t)b * bstr + 4 * t4);
                 sacc += (v.x + v.y) + (v.z + v.w);
             }
             sacc = wave_sum(sacc);
@@ -438,6 +497,7 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     if ((size_t)NS * stage > (size_t)G_LDS_MAX || epi > (size_t)G_LDS_MAX || (NS - 1) * ipc > 40) return false;
     lds = (size_t)NS * stage > epi ? (size_t)NS * stage : epi;
     k.xh = a.xh; k.dyh = a.dyh; k.dy = a.dy; k.dw = a.dw; k.db = a.db; k.partial = a.partial;
+    k.prev_partial = a.prev_partial; k.prev_dw = a.prev_dw; k.prev_n4 = (long)a.prev_n4; k.prev_slices = a.prev_slices;
     k.xh_bytes = (unsigned)xbytes; k.dyh_bytes = (unsigned)ybytes;
     k.B = a.B; k.Cin = a.Cin; k.Cout = a.Cout; k.K = a.K; k.k_lo = a.k_lo; k.Keff = a.Keff; k.Tin = a.Tin; k.Tout = a.Tout;
     k.ups = a.ups; k.relu = a.relu;
@@ -456,6 +516,7 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
         const int cpb = (GT + NTl - 1) / NTl;
         if (slices == 1 && cpb <= ncons && k.bias_vec && (int64_t)a.B * T <= 8192) k.bias_mode = 1;
         else if (slices > 1 && a.bias_in_reduce) k.bias_mode = 0;
+        else if (slices > 1 && cpb <= ncons && k.bias_vec && (int64_t)a.B * T <= 16384) k.bias_mode = 1;   // slice 0's blocks
         else k.bias_mode = 2;
     }
     k.bias_first = k.bias_mode == 2 ? tiles * slices : 0x7fffffff;

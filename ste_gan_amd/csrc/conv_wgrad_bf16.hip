@@ -677,7 +677,7 @@ void wgh_launch(bool xv, dim3 grid, size_t lds, hipStream_t s, const WH& h, floa
 // the fp32 kernels: fewer than 16 channels per group on either side, or a workspace too small for one slab.
 static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy, const uint16_t* dyh,
                    float* dw, float* db, float* workspace, int64_t workspace_floats, stegan_wgrad_reduce* deferred,
-                   void* stream) {
+                   void* stream, const stegan_wgrad_reduce* prev = nullptr, int* prev_done = nullptr) {
     if (deferred) { deferred->partial = nullptr; deferred->dw = nullptr; deferred->per_tap = 0; deferred->slices = 0;
                     deferred->K = 0; deferred->k_lo = 0; deferred->K_eff = 0; deferred->used_floats = 0; }
     int rc = check_desc(d);
@@ -715,10 +715,18 @@ static int wgh_run(const stegan_conv_desc* d, const float* x, const uint16_t* xh
         ta.B = d->B; ta.Cin = d->Cin; ta.Cout = d->Cout; ta.K = d->K; ta.dil = d->dilation; ta.pad = d->pad; ta.Tin = d->Tin;
         ta.Tout = d->Tout; ta.ups = h.ups; ta.relu = h.relu; ta.k_lo = h.k_lo; ta.Keff = h.K_eff;
         ta.bias_in_reduce = deferred ? 0 : 1;
+        // a pending slab sum of the layer before rides in this launch when it is the 16-byte case of the reduce kernel
+        ta.prev_partial = nullptr; ta.prev_dw = nullptr; ta.prev_n4 = 0; ta.prev_slices = 0;
+        if (prev && prev->slices > 0 && prev->K_eff == prev->K && prev->k_lo == 0 && ((prev->per_tap * prev->K_eff) & 3) == 0 &&
+            (((uintptr_t)prev->partial | (uintptr_t)prev->dw) & 15) == 0) {
+            ta.prev_partial = prev->partial; ta.prev_dw = prev->dw; ta.prev_n4 = prev->per_tap * prev->K_eff / 4;
+            ta.prev_slices = prev->slices;
+        }
         int sl = 0, bias_done = 0;
         const int trc = stegan_tile_wgrad(ta, &sl, &bias_done, s);
         if (trc != 1) {
             if (trc) return trc;
+            if (prev_done && ta.prev_n4 > 0) *prev_done = 1;
             const int64_t slab_t = (int64_t)h.K_eff * h.Cout * h.Cin_g;
             if (sl > 1 && deferred) {
                 deferred->partial = workspace; deferred->dw = dw; deferred->per_tap = (int64_t)h.Cout * h.Cin_g;
@@ -900,6 +908,24 @@ extern "C" int stegan_conv1d_bwd_weight_hxd(const stegan_conv_desc* d, const flo
     return wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, deferred, stream);
 }
 
+// the chained form: `prev` (nullable / slices == 0: none) is the pending sum an earlier call on the SAME stream left in its
+// `next`; it is run at the head of this launch (inside the tile kernel when it takes the shape, else as a reduce launch of its
+// own), so a chain of n sliced layers costs one reduce launch -- its tail's -- instead of n.  Return 1: nothing was enqueued,
+// `prev` is still pending.
+extern "C" int stegan_conv1d_bwd_weight_hxc(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
+                                            const uint16_t* dyh, float* dw, float* db, float* workspace,
+                                            int64_t workspace_floats, const stegan_wgrad_reduce* prev, stegan_wgrad_reduce* next,
+                                            void* stream) {
+    STEGAN_CHECK_ARG(next && next != prev);
+    int prev_done = 0;
+    const int rc = wgh_run(d, x, xh, dy, dyh, dw, db, workspace, workspace_floats, next, stream, prev, &prev_done);
+    if ((rc == STEGAN_OK || rc == STEGAN_OK_TILE) && prev && prev->slices > 0 && !prev_done) {
+        const int r2 = stegan_wgrad_reduce_multi(1, prev, stream);
+        if (r2) return r2;
+    }
+    return rc;
+}
+
 // ---- the deferred slab sums of up to WRM_MAX layers in ONE launch (52 reduce launches a step become one per phase)
 namespace {
 constexpr int WRM_MAX = 48;
@@ -941,6 +967,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_multi_kernel(const
 extern "C" int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void* stream) {
     STEGAN_CHECK_ARG(n >= 0 && (n == 0 || items));
     hipStream_t s = (hipStream_t)stream;
+    if (n == 1 && items[0].slices > 0) {                   // one layer: the per-layer kernel (16 bytes per lane when every tap is live)
+        const stegan_wgrad_reduce& it = items[0];
+        STEGAN_CHECK_ARG(it.partial && it.dw && it.per_tap > 0 && it.K_eff > 0);
+        long rb = (it.per_tap * it.K_eff + 255) / 256;
+        if (rb > 2048) rb = 2048;
+        BiasArgs ba;
+        ba.dy = nullptr; ba.db = nullptr; ba.B = 0; ba.C = 0; ba.T = 0; ba.slices = 0; ba.per = 1; ba.vec = 0;
+        ba.fdT = make_fastdiv(1u);
+        hipLaunchKernelGGL(conv_wgrad_bf16_reduce_kernel, dim3((unsigned)rb), dim3(256), 0, s, it.partial, it.dw, (long)it.per_tap,
+                           (int)it.slices, (int)it.K, (int)it.k_lo, (int)it.K_eff, (int)rb, ba);
+        STEGAN_LAUNCH_CHECK();
+        return STEGAN_OK;
+    }
     for (int base = 0; base < n; base += WRM_MAX) {
         WRMulti a;
         a.n = 0; a.first[0] = 0;

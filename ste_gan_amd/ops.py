@@ -586,9 +586,21 @@ class WgradReduce(C.Structure):       # mirrors struct stegan_wgrad_reduce
 # backward pass and fill gaps on busy streams, the batched sum sits alone between the last weight gradient and the optimiser.
 # Kept as an option (STEGAN_WGRAD_DEFER=1; tests/test_gpu_train_step.py runs the golden step through it).
 WGRAD_DEFER = os.environ.get("STEGAN_WGRAD_DEFER", "0") == "1"
+# Round 5: inside a batch of weight gradients issued on one side stream (_wgrad_flush) the slab sum of a sliced layer is run by
+# the NEXT layer's launch (its consumer waves are idle while its producers set up); only the batch's last layer pays a reduce
+# launch.  The slabs live in the arena below (a region per layer, recycled at wgrad_join).
+WGRAD_CHAIN = os.environ.get("STEGAN_WGRAD_CHAIN", "1") == "1"
 _WG_ARENA_FLOATS = int(os.environ.get("STEGAN_WGRAD_ARENA_MB", "1024")) * (1 << 18)
 _WG_ARENA: dict = {}           # device -> [arena, floats in use]
 _WG_DEFERRED: list = []        # (WgradReduce, dw tensor kept alive)
+
+
+def wgrad_chain_end(chain: list) -> None:
+    """Sums the pending slabs a chain of conv1d_bwd_weight(..., chain=chain) calls left behind (current stream)."""
+    if chain[0] is not None:
+        item, _ = chain[0]
+        check(_lib.lib().stegan_wgrad_reduce_multi(1, C.byref(item), _stream()), "stegan_wgrad_reduce_multi")
+        chain[0] = None
 
 
 def _wgrad_reduce_flush() -> None:
@@ -602,9 +614,13 @@ def _wgrad_reduce_flush() -> None:
         st[1] = 0
 
 
-def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor], defer: bool = False) -> None:
+def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optional[Tensor], defer: bool = False,
+                      chain: Optional[list] = None) -> None:
     """Accumulates into dw (and db).  ``defer``: the caller promises that dw is read only after ops.wgrad_join() (gradient
-    sinks); the sum over the batch slices may then be postponed to that call."""
+    sinks); the sum over the batch slices may then be postponed to that call.  ``chain``: a one-element list owned by a caller
+    that issues several weight gradients on ONE stream (_wgrad_flush): it carries the pending slab sum of the launch before,
+    which this launch runs at its head (stegan_conv1d_bwd_weight_hxc), and receives this launch's; the caller sums the tail."""
+    global LAST_CONV_KERNEL
     B, _, tin = x.shape
     d = _desc(cfg, B, tin, dy.shape[2])
     if cfg.cout == 1 and SKINNY:
@@ -618,6 +634,28 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
         xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
         if IMG_STATS is not None:
             IMG_STATS.setdefault((2, xh is not None and dyh is not None), []).append((B, cfg.cin, cfg.cout, cfg.k, tin))
+        if chain is not None and defer and PROFILER is None and x.is_cuda:
+            st = _WG_ARENA.get(x.device)
+            if st is None:
+                st = _WG_ARENA[x.device] = [torch.empty(_WG_ARENA_FLOATS, device=x.device, dtype=torch.float32), 0]
+            arena, used = st
+            room = arena.numel() - used
+            prev = chain[0]
+            if room >= dw.numel() * 8:
+                item = WgradReduce()
+                ws = arena[used:]
+                rc = _lib.lib().stegan_conv1d_bwd_weight_hxc(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw), _p(db), _p(ws),
+                                                             min(room, dw.numel() * 64), C.byref(prev[0]) if prev else None,
+                                                             C.byref(item), _stream())
+                if rc != 1:
+                    LAST_CONV_KERNEL = "tile" if rc == OK_TILE else "bf16"
+                    check(0 if rc == OK_TILE else rc, "stegan_conv1d_bwd_weight_hxc")
+                    chain[0] = None
+                    if item.slices > 0:
+                        st[1] = used + ((int(item.used_floats) + 63) & ~63)
+                        chain[0] = (item, dw)
+                    return
+            wgrad_chain_end(chain)                     # declined (or no room): the pending sum runs on its own, then the usual path
         if defer and WGRAD_DEFER and PROFILER is None and x.is_cuda:
             st = _WG_ARENA.get(x.device)
             if st is None:
@@ -630,7 +668,6 @@ def conv1d_bwd_weight(x: Tensor, dy: Tensor, cfg: ConvCfg, dw: Tensor, db: Optio
                 rc = _lib.lib().stegan_conv1d_bwd_weight_hxd(C.byref(d), _p(x), _p(xh), _p(dy), _p(dyh), _p(dw), _p(db),
                                                              _p(ws), min(room, dw.numel() * 64), C.byref(item), _stream())
                 if rc != 1:
-                    global LAST_CONV_KERNEL
                     LAST_CONV_KERNEL = "tile" if rc == OK_TILE else "bf16"
                     check(0 if rc == OK_TILE else rc, "stegan_conv1d_bwd_weight_hxd")
                     if item.slices > 0:
@@ -685,8 +722,11 @@ def _wgrad_flush() -> None:
     _WG_USED[side.cuda_stream] = side
     side.wait_stream(torch.cuda.current_stream())       # ONE cross-queue edge for the whole batch (11 us each inside a
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
+        chain = [None] if WGRAD_CHAIN else None         # the slab sum of layer i rides in the launch of layer i + 1
         for x, dy, cfg, dw, db in _WG_PENDING:
-            conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True)
+            conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
+        if chain is not None:
+            wgrad_chain_end(chain)
     _WG_KEEP.extend((x, dy) for x, dy, _, _, _ in _WG_PENDING)
     _WG_PENDING.clear()
 

@@ -304,3 +304,45 @@ def test_weight_gradient_accumulates_onto_a_non_constant_dw(slices, monkeypatch)
             assert float(err.max()) <= 3e-5 * float(ref.abs().max()), err.amax((0, 1)).tolist()
     finally:
         ops.set_compute_dtype("f32")
+
+
+def test_chained_weight_gradients_equal_the_unchained_ones_bit_for_bit():
+    """ops.conv1d_bwd_weight(..., chain=...): the slab sum of a sliced layer is run by the NEXT layer's launch
+    (stegan_conv1d_bwd_weight_hxc) and only the chain's tail pays a reduce launch.  Same adds in the same order: dW and db of
+    every layer equal the per-layer path's bits -- for a chain of sliced tile layers, an unsliced one in the middle (nothing
+    pending behind it) and a shape the tile kernel declines (its predecessor's sum then runs as a launch of its own)."""
+    from ste_gan_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    # (B, Cin, Cout, K, dil, up, relu, Tin): sliced x3, one slice (T = 12), declined by the tile kernel (Tout % 4), sliced
+    layers = [(16, 96, 96, 3, 1, 1, 1, 48), (16, 96, 48, 3, 3, 2, 1, 24), (16, 48, 96, 1, 1, 1, 0, 96), (16, 768, 96, 3, 1, 1, 1, 12),
+              (8, 64, 64, 3, 1, 1, 0, 30), (16, 96, 96, 3, 9, 1, 1, 96)]
+    ops.set_compute_dtype(OPERAND[0])
+    try:
+        data = []
+        for (B, Cin, Cout, K, d, up, relu, Tin) in layers:
+            c = ops.ConvCfg(Cin, Cout, K, 1, d, d * (K - 1) // 2, 1, up, relu)
+            x = torch.randn(B, Cin, Tin, generator=gen).cuda(); dy = torch.randn(B, Cout, c.tout(Tin), generator=gen).cuda()
+            ops._attach_image(x, make_image(x)); ops._attach_image(dy, make_image(dy))
+            init = torch.randn(Cout, Cin, K, generator=gen).cuda()
+            data.append((c, x, dy, init))
+        plain = []
+        for c, x, dy, init in data:
+            dw, db = init.clone(), torch.ones(c.cout, device="cuda")
+            ops.conv1d_bwd_weight(x, dy, c, dw, db)
+            plain.append((dw, db))
+        chain, got, kinds = [None], [], []
+        for c, x, dy, init in data:
+            dw, db = init.clone(), torch.ones(c.cout, device="cuda")
+            ops.conv1d_bwd_weight(x, dy, c, dw, db, defer=True, chain=chain)
+            kinds.append((ops.LAST_CONV_KERNEL, chain[0] is not None))
+            got.append((dw, db))
+        assert chain[0] is not None                          # the last layer is sliced: its sum is still pending
+        ops.wgrad_chain_end(chain)
+        ops.wgrad_join()
+        torch.cuda.synchronize()
+        assert [k for k, _ in kinds].count("tile") >= 4 and sum(p for _, p in kinds) >= 3, kinds
+        for i, ((dw, db), (dw0, db0)) in enumerate(zip(got, plain)):
+            assert torch.equal(dw, dw0), (i, kinds[i], float((dw - dw0).abs().max()))
+            assert torch.equal(db, db0), (i, kinds[i], float((db - db0).abs().max()))
+    finally:
+        ops.set_compute_dtype("f32")

@@ -948,6 +948,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_reduce_multi_kernel(const
     float* __restrict__ dw = a.dw[it];
     const int K_eff = a.K_eff[it], K = a.K[it], k_lo = a.k_lo[it], slices = a.slices[it];
     const long total = a.per_tap[it] * K_eff;
+    if (K_eff == K && (total & 3) == 0 && (((uintptr_t)partial | (uintptr_t)dw) & 15) == 0) {     // as the per-layer kernel
+        const long n4 = total >> 2;
+        const f32x4* src4 = (const f32x4*)partial;
+        f32x4* dw4 = (f32x4*)dw;
+        for (long i = (long)blk * 256 + threadIdx.x; i < n4; i += (long)rb * 256) {
+            const f32x4 o = dw4[i];
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 4 <= slices; s += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] += src4[(size_t)(s + u) * n4 + i];
+            }
+            for (; s < slices; ++s) v[0] += src4[(size_t)s * n4 + i];
+            dw4[i] = o + ((v[0] + v[1]) + (v[2] + v[3]));
+        }
+        return;
+    }
     for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)rb * 256) {
         const long r = i / K_eff;
         const int kk = (int)(i - r * K_eff);

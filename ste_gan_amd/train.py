@@ -93,6 +93,8 @@ class GANTrainStep:
         # feature-matching gradients are added inside the discriminator convs' activation backward instead of by one
         # autograd accumulation kernel per feature map (ops.fm_fold_begin)
         self.fold_fm = os.environ.get("STEGAN_FOLD_FM", "1") != "0"
+        # the generator step's backward pass through the discriminators runs before the side branch is joined (_p_g2)
+        self.early_d_backward = os.environ.get("STEGAN_EARLY_D_BWD", "1") != "0"
         self._side = None
         # the side branch in two halves, each forked and joined inside its phase: forward + losses beside the discriminator
         # step (phase_d), backward beside the D update and the generator-side discriminator passes (phase_g).  Set by
@@ -390,6 +392,7 @@ class GANTrainStep:
         # the generated EMG has two gradient sources -- the discriminators here and the side branch's gradient, handed to
         # autograd as a root in _p_g2: they meet in ONE hand-written sum (ops.fan_out) instead of the engine's ATen add
         x_for_d, st["x_pred_root"] = ops.fan_out(x_pred_t, 2)
+        st["x_for_d"] = x_for_d
         try:
             if fold:                          # feature-matching gradients are parked, not returned to autograd (ops.ActFuse)
                 with ops.act_fuse_scope():
@@ -427,9 +430,6 @@ class GANTrainStep:
         out, x_pred_t, side, main_stream = st["out"], st["x_pred_t"], st["side"], st["main_stream"]
         loss_side, g_side, main_terms, fold = st["loss_side"], st["g_side"], st["main_terms"], st["fold"]
         try:
-            if side is not None:
-                main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
-            ops.mark("G step: side joined")
             # one pass through the generator for both gradient sources; the scalar roots meet a persistent 1.0 instead of
             # autograd's ones_like fills
             roots, grads = [], []
@@ -437,8 +437,20 @@ class GANTrainStep:
             for _, v, w in main_terms:
                 if v.requires_grad and w != 0.0:
                     roots.append(v); grads.append(one)
+            x_root, x_for_d = st.pop("x_pred_root", x_pred_t), st.pop("x_for_d", None)
+            if (self.early_d_backward and side is not None and g_side is not None and roots and x_for_d is not None
+                    and x_for_d is not x_root and x_for_d.requires_grad):
+                # Round 5: the discriminators' input gradient reads nothing of the side branch, so it runs BEFORE the join,
+                # beside the tail of the encoder's backward pass (the main stream used to idle ~0.45 ms at the join, then run
+                # these ~0.4 ms alone).  Same sums: the two gradients of x_pred meet in fan_out's kernel, in the same order.
+                (g_d,) = torch.autograd.grad(roots, x_for_d, grad_outputs=grads)
+                ops.mark("G step: D input gradient done")
+                roots, grads = [x_for_d], [g_d]
+            if side is not None:
+                main_stream.wait_stream(side)                  # join: the side branch's losses and gradient are complete
+            ops.mark("G step: side joined")
             if g_side is not None:
-                roots.append(st.pop("x_pred_root", x_pred_t)); grads.append(g_side)
+                roots.append(x_root); grads.append(g_side)
             if roots:
                 _ops.wgrad_async(True)         # generator backward: weight gradients beside the input-gradient chain
                 try:

@@ -370,74 +370,81 @@ __device__ __forceinline__ float ln_column_sum(float v, float* red, int tid, int
     return tot[tid % T];          // (red / tot are rewritten only behind the next reduction's first barrier)
 }
 
+// Round 5: a block owns Tg of the T columns of its batch element (grid = B x T / Tg): at T = 12, B = 64 the 64 blocks of the
+// first form left three quarters of the chip idle on the encoder branch's critical chain (13.6 / 11.4 us per launch, 24 launches
+// a step); four column groups make 256 blocks with a quarter of the loads each.  Thread i sees column t0 + i % Tg and channels
+// i / Tg + e P.  Tg == T is the first form.
 __global__ __launch_bounds__(1024) void ln_fwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ r,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ y, float* __restrict__ xhat,
-                                                           float* __restrict__ rstd, int Cm, int T, int P, float eps,
+                                                           float* __restrict__ rstd, int Cm, int T, int Tg, int P, float eps,
                                                            unsigned short* __restrict__ y_h) {
     extern __shared__ float red[];
-    const int tid = threadIdx.x, nth = T * P, n = Cm * T;
-    const size_t off = (size_t)blockIdx.x * n;
-    float z[LN_EPT];
+    const int G = T / Tg, b = (int)blockIdx.x / G, t0 = ((int)blockIdx.x - b * G) * Tg;
+    const int tid = threadIdx.x, c0 = tid / Tg, tl = tid - c0 * Tg;
+    const size_t off = (size_t)b * Cm * T + t0 + tl;
+    float z[LN_EPT], gm[LN_EPT], bt[LN_EPT];
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
-        const int i = tid + e * nth;
-        z[e] = i < n ? x[off + i] + (r ? r[off + i] : 0.f) : 0.f;
+        const int c = c0 + e * P;
+        const bool in = c < Cm;
+        z[e] = in ? x[off + (size_t)c * T] + (r ? r[off + (size_t)c * T] : 0.f) : 0.f;
+        gm[e] = in ? gamma[c] : 0.f;
+        bt[e] = in ? beta[c] : 0.f;
         s += z[e];
     }
-    const float mean = ln_column_sum(s, red, tid, T, P) / (float)Cm;
+    const float mean = ln_column_sum(s, red, tid, Tg, P) / (float)Cm;
     float vs = 0.f;
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
-        const float d = (tid + e * nth < n) ? z[e] - mean : 0.f;
+        const float d = (c0 + e * P < Cm) ? z[e] - mean : 0.f;
         vs += d * d;
     }
-    const float rs = rsqrtf(ln_column_sum(vs, red, tid, T, P) / (float)Cm + eps);
-    const int c0 = tid / T;
+    const float rs = rsqrtf(ln_column_sum(vs, red, tid, Tg, P) / (float)Cm + eps);
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
-        const int i = tid + e * nth;
-        if (i < n) {
-            const int c = c0 + e * P;
+        const int c = c0 + e * P;
+        if (c < Cm) {
             const float xh = (z[e] - mean) * rs;
-            if (xhat) xhat[off + i] = xh;
-            const float yv = xh * gamma[c] + beta[c];
-            y[off + i] = yv;
-            if (y_h) img_store(y_h, Cm >> 3, T, blockIdx.x, c, tid % T, yv);
+            if (xhat) xhat[off + (size_t)c * T] = xh;
+            const float yv = xh * gm[e] + bt[e];
+            y[off + (size_t)c * T] = yv;
+            if (y_h) img_store(y_h, Cm >> 3, T, b, c, t0 + tl, yv);
         }
     }
-    if (tid < T && rstd) rstd[blockIdx.x * T + tid] = rs;
+    if (tid < Tg && rstd) rstd[b * T + t0 + tid] = rs;
 }
 
 __global__ __launch_bounds__(1024) void ln_bwd_slab_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           float* __restrict__ dz, int Cm, int T, int P,
+                                                           float* __restrict__ dz, int Cm, int T, int Tg, int P,
                                                            unsigned short* __restrict__ dz_h) {
     extern __shared__ float red[];
-    const int tid = threadIdx.x, nth = T * P, n = Cm * T;
-    const size_t off = (size_t)blockIdx.x * n;
-    const int c0 = tid / T;
+    const int G = T / Tg, b = (int)blockIdx.x / G, t0 = ((int)blockIdx.x - b * G) * Tg;
+    const int tid = threadIdx.x, c0 = tid / Tg, tl = tid - c0 * Tg;
+    const size_t off = (size_t)b * Cm * T + t0 + tl;
+    const float rs = rstd[b * T + t0 + tl];
     float g[LN_EPT], xh[LN_EPT];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
-        const int i = tid + e * nth;
-        g[e] = i < n ? gamma[c0 + e * P] * dy[off + i] : 0.f;
-        xh[e] = i < n ? xhat[off + i] : 0.f;
+        const int c = c0 + e * P;
+        const bool in = c < Cm;
+        g[e] = in ? gamma[c] * dy[off + (size_t)c * T] : 0.f;
+        xh[e] = in ? xhat[off + (size_t)c * T] : 0.f;
         s1 += g[e];
         s2 += g[e] * xh[e];
     }
-    s1 = ln_column_sum(s1, red, tid, T, P) / (float)Cm;
-    s2 = ln_column_sum(s2, red, tid, T, P) / (float)Cm;
-    const float rs = rstd[blockIdx.x * T + tid % T];
+    s1 = ln_column_sum(s1, red, tid, Tg, P) / (float)Cm;
+    s2 = ln_column_sum(s2, red, tid, Tg, P) / (float)Cm;
 #pragma unroll
     for (int e = 0; e < LN_EPT; ++e) {
-        const int i = tid + e * nth;
-        if (i < n) {
+        const int c = c0 + e * P;
+        if (c < Cm) {
             const float dv_ = rs * (g[e] - s1 - xh[e] * s2);
-            dz[off + i] = dv_;
-            if (dz_h) img_store(dz_h, Cm >> 3, T, blockIdx.x, c0 + e * P, tid % T, dv_);
+            dz[off + (size_t)c * T] = dv_;
+            if (dz_h) img_store(dz_h, Cm >> 3, T, b, c, t0 + tl, dv_);
         }
     }
 }
@@ -449,8 +456,23 @@ inline int ln_slab_p(int Cm, int T) {
     if (off || T > 256) return 0;
     int P = 1;
     while (T * P * 2 <= 1024) P *= 2;
-    if ((long)Cm * T > (long)LN_EPT * T * P || T * P < 64) return 0;
+    if ((long)Cm > (long)LN_EPT * P || T * P < 64) return 0;
     return P;
+}
+
+// columns per block: the divisor Tg of T that brings the grid B * T / Tg closest to one block per CU from below (Tg == T when
+// the batch alone fills the chip), with whole waves in the block
+inline int ln_slab_tg(int B, int Cm, int T) {
+    static const char* e = getenv("STEGAN_LN_SPLIT");                        // experiments: column groups per batch element
+    const int want = e ? atoi(e) : 0;
+    int best = T;
+    for (int G = 1; G <= T; ++G) {
+        if (T % G) continue;
+        const int Tg = T / G;
+        if (!ln_slab_p(Cm, Tg)) continue;
+        if (want ? G == want : (long)B * G <= 320) best = Tg;
+    }
+    return best;
 }
 
 }  // namespace
@@ -506,9 +528,10 @@ extern "C" int stegan_add_layernorm_fwd_img(const float* x, const float* residua
                                             float eps, void* stream) {
     STEGAN_CHECK_ARG(x && gamma && beta && y && B > 0 && C > 0 && T > 0);
     STEGAN_CHECK_ARG(!y_h || C % 8 == 0);
-    if (const int P = ln_slab_p(C, T)) {
-        hipLaunchKernelGGL(ln_fwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, x,
-                           residual, gamma, beta, y, xhat, rstd, C, T, P, eps, y_h);
+    if (ln_slab_p(C, T)) {
+        const int Tg = ln_slab_tg(B, C, T), P = ln_slab_p(C, Tg);
+        hipLaunchKernelGGL(ln_fwd_slab_kernel, dim3(B * (T / Tg)), dim3(Tg * P), (size_t)Tg * (P + 1) * sizeof(float),
+                           (hipStream_t)stream, x, residual, gamma, beta, y, xhat, rstd, C, T, Tg, P, eps, y_h);
         STEGAN_LAUNCH_CHECK();
         return STEGAN_OK;
     }
@@ -528,9 +551,10 @@ extern "C" int stegan_add_layernorm_bwd_img(const float* dy, const float* xhat, 
                                             float* dz, uint16_t* dz_h, int32_t B, int32_t C, int32_t T, void* stream) {
     STEGAN_CHECK_ARG(dy && xhat && rstd && gamma && dz && B > 0 && C > 0 && T > 0);
     STEGAN_CHECK_ARG(!dz_h || C % 8 == 0);
-    if (const int P = ln_slab_p(C, T)) {
-        hipLaunchKernelGGL(ln_bwd_slab_kernel, dim3(B), dim3(T * P), (size_t)T * (P + 1) * sizeof(float), (hipStream_t)stream, dy,
-                           xhat, rstd, gamma, dz, C, T, P, dz_h);
+    if (ln_slab_p(C, T)) {
+        const int Tg = ln_slab_tg(B, C, T), P = ln_slab_p(C, Tg);
+        hipLaunchKernelGGL(ln_bwd_slab_kernel, dim3(B * (T / Tg)), dim3(Tg * P), (size_t)Tg * (P + 1) * sizeof(float),
+                           (hipStream_t)stream, dy, xhat, rstd, gamma, dz, C, T, Tg, P, dz_h);
         STEGAN_LAUNCH_CHECK();
         return STEGAN_OK;
     }

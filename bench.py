@@ -130,8 +130,8 @@ def step_rooflines(sec_per_step, dtype, frames_per_s):
     else:
         r["moved_gbytes_per_step_pmc"] = None
         r["moved_profile"] = PMC_STALE if dtype == "bf16" else "counters exist for the bf16 step only"
-    r["binding"] = ("neither roof: the step is ~600 launches of 10-25 us, each bound by its blocks' fixed costs and by the "
-                    "CU's fetch path into LDS (DESIGN.md section 6)")
+    r["binding"] = ("neither roof: the step is ~520 launches of 6-25 us, each bound by its blocks' fixed costs and by the "
+                    "CU's fetch path into LDS, and two streams cannot share a CU (DESIGN.md section 6.0)")
     return r
 
 

@@ -42,8 +42,8 @@ def alg_bytes(name, s):
     x, y = B * Cin * Tin, B * Cout * Tout
     if mode == 0:
         return 2 * x + 2 * w, 6 * y
-    if mode == 1:
-        return 2 * y + 2 * w, 6 * x
+    if mode == 1:                                  # (+ the fp32 mask source of a fused activation derivative)
+        return 2 * y + 2 * w + (4 * x if len(s) > 12 and s[12] else 0), 6 * x
     return 2 * x + 2 * y, 4 * w
 
 
@@ -68,7 +68,7 @@ def join(recs_path, fdir, wdir, out=None):
             cols.append(rows[-len(rl):])
         agg = collections.OrderedDict()
         for (name, shape), rf, rw in zip(rl, *cols):
-            a = agg.setdefault((name, tuple(shape[:11])), [0, 0.0, 0.0, rf["Kernel_Name"].split("(")[0][-40:], rf["Grid_Size"]])
+            a = agg.setdefault((name, tuple(shape[:14])), [0, 0.0, 0.0, rf["Kernel_Name"].split("(")[0][-40:], rf["Grid_Size"]])
             a[0] += 1
             a[1] += 2.0 * float(rf["Counter_Value"]) * 1024
             a[2] += float(rw["Counter_Value"]) * 1024

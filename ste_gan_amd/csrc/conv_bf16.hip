@@ -74,6 +74,13 @@ struct HP {
     // into 2^xlgm x 2^(3 - xlgm) rectangles, one per XCD; xlgm = 0 is the round-2 placement (all M tiles of a few N tiles per
     // XCD: X once, W by every XCD), larger xlgm trades re-reads of X for fewer re-reads of W.  xlgm < 0: identity (experiments)
     int xlgm = 0, xR = 1;
+    // input gradient of a strided layer: the `stride` output phases of a tile write interleaved columns of the SAME lines of dx
+    // and read the same dy tile / mask rows.  With the phase as the SLOWEST part of the id (rounds 2-4) an XCD worked on one
+    // phase: every line of dx left three L2s as three partial writes (2.7 x the algorithmic write bytes, 4-6 x the reads:
+    // profiles/r04_pmc_by_shape.txt).  nph > 1: the phase is the FASTEST part of the "rest" id, so a tile's phases run on one
+    // XCD within a few blocks of each other and meet in its L2
+    int nph = 1;
+    FastDiv fdPH;
     int rot = 1;                  // image path: rotated chunk walk per block (STEGAN_BF16_ROT=0: every block starts at chunk 0)
     int cw0 = 1;                  // image path: the consumer waves request chunk 0's weights (STEGAN_BF16_CW0=0: the producers)
 };
@@ -195,10 +202,18 @@ __device__ __forceinline__ void conv_bf16_body(const HP& h, const unsigned bid_x
             by = (int)(mb0 + (t3 - q * hm));
             rest = rb0 + q;
         }
-        const unsigned z = fd_div(rest, p.fdNBX);
-        bx = (int)(rest - z * p.nbx);
-        phase = (int)fd_div(z, p.fdSP);
-        split = (int)z - phase * p.splits;
+        if (h.nph > 1) {
+            const unsigned r2 = fd_div(rest, h.fdPH);
+            phase = (int)(rest - r2 * (unsigned)h.nph);
+            const unsigned z = fd_div(r2, p.fdNBX);
+            bx = (int)(r2 - z * p.nbx);
+            split = (int)z;
+        } else {
+            const unsigned z = fd_div(rest, p.fdNBX);
+            bx = (int)(rest - z * p.nbx);
+            phase = (int)fd_div(z, p.fdSP);
+            split = (int)z - phase * p.splits;
+        }
     }
     const int g = (int)fd_div((uint32_t)by, p.fdMT);
     const int m0 = (by - g * p.m_tiles) * BM;
@@ -1347,6 +1362,9 @@ int launch_bf16(const stegan_conv_desc* d, int mode, HP& h, float* workspace, in
         // whatever runs beside the kernel, it is not a speed-up of the kernel itself.
         const char* env_x = STEGAN_ENV("STEGAN_BF16_XLGM");                  // experiments: -1 identity, 0 .. 3 fixed
         h.xR = p.nbx * p.splits * phases;
+        static const bool ph_slow = STEGAN_ENV("STEGAN_BF16_PHASE_SLOW") != nullptr;      // experiments: the round-2 order
+        h.nph = ph_slow ? 1 : phases;
+        h.fdPH = make_fastdiv((uint32_t)phases);
         const double xb = (double)N * p.C2_g * d->groups * (xh ? 2 : 4), wb = (double)p.M_g * d->groups * p.C2_g * d->K * 2;
         const int nz = p.splits * phases;
         double best = 0;

@@ -125,15 +125,19 @@ class ConvProfiler:
     def alg_bytes(shape) -> int:
         """Bytes a launch must move if every operand is read once and every result written once, as this path stores them:
         activations and their gradients read as bf16 images (2 B; 4 B in fp32 mode), weights 2 B (4 B), results written as
-        fp32 plus -- in bf16 mode -- the bf16 image for the next layer (6 B); weight gradients fp32."""
+        fp32 plus -- in bf16 mode -- the bf16 image for the next layer (6 B); weight gradients fp32.  An input gradient with a
+        fused activation derivative (in_act != 0) also reads the fp32 tensor the mask is taken from (4 B per element; VERDICT
+        r04 item 6: that operand was missing here).  Parked feature-matching / hand-over gradients added in the epilogue are
+        not visible in the descriptor and stay uncounted."""
         mode, B, Cin, Cout, K, stride, dil, groups, up, Tin, Tout = shape[:11]
+        in_act = shape[12] if len(shape) > 12 else 0
         e = 2 if HALF else 4
         o = 6 if HALF else 4
         w, x, y = Cout * (Cin // groups) * K, B * Cin * Tin, B * Cout * Tout
         if mode == 0:
             return e * (x + w) + o * y
         if mode == 1:
-            return e * (y + w) + o * x
+            return e * (y + w) + o * x + (4 * x if in_act else 0)
         return e * (x + y) + 4 * w
 
 

@@ -49,9 +49,11 @@ def test_training_mode_raises():
         enc(torch.zeros(1, 64, 8, device="cuda"))
 
 
-@pytest.mark.parametrize("B,C,T", [(64, 768, 12), (3, 100, 5), (4, 64, 40), (2, 48, 300), (2, 3000, 12), (5, 7, 1)])
+@pytest.mark.parametrize("B,C,T", [(64, 768, 12), (3, 100, 5), (4, 64, 40), (2, 48, 300), (2, 3000, 12), (5, 7, 1),
+                                   (16, 768, 12), (40, 256, 8), (130, 64, 6), (7, 768, 9)])
 def test_add_layernorm_against_torch(B, C, T):
-    """stegan_add_layernorm_fwd / _bwd on (B, C, T): the one-block-per-batch-element kernels (short rows) and the
+    """stegan_add_layernorm_fwd / _bwd on (B, C, T): the slab kernels (short rows; a block owns a group of T / G columns of its
+    batch element, G chosen from B: one column per block at B = 16, three at B = 64, the whole slab at B = 130) and the
     per-column kernels (T > 256, or a slab too large for the per-thread registers) against torch.layer_norm in fp64."""
     from ste_gan_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + C + T)

@@ -440,6 +440,14 @@ int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const*
 int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
                               const float* weight, const float* target, const float* target2, const int64_t* split,
                               int32_t mode, float* loss_slot, float* const* da, void* stream);
+/* the same with a REPRODUCIBLE value (round 5): every block writes its share of the sum into `partials` (at most 128 floats per
+ * pair; with fewer than that many floats left the launch falls back to atomic adds) and a one-block kernel adds the shares
+ * into *loss_slot in a fixed order -- two launches on the same inputs report the same bits.  The gradients never went through
+ * atomics in either form.  `partials` is scratch: free again when the call's kernels have run. */
+int stegan_pair_loss_multi_det(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                               const float* weight, const float* target, const float* target2, const int64_t* split,
+                               int32_t mode, float* loss_slot, float* const* da, float* partials, int64_t partials_floats,
+                               void* stream);
 /* out = x * (*scalar_dev): chains an upstream 0-dim gradient into a stored unit gradient without a host sync. */
 int stegan_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
 /*

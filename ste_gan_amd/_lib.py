@@ -94,6 +94,7 @@ SIGNATURES = {
     "stegan_avgpool421_fwd": [_P, _P, _I64, _I32, _P],
     "stegan_avgpool421_bwd": [_P, _P, _P, _I64, _I32, _P],
     "stegan_pair_loss_multi_ex": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
+    "stegan_pair_loss_multi_det": [_I32, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P],
     "stegan_pair_loss_multi": [_I32, _P, _P, _P, C.c_float, _I32, C.c_float, _P, _P, _P],
     "stegan_pair_loss_fwd_bwd": [_P, _P, C.c_float, _I64, _I32, C.c_float, _P, _P, _P],
     "stegan_scale_by_scalar": [_P, _P, _P, _I64, _P],

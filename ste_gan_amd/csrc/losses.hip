@@ -25,7 +25,8 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
                                                int mode, float w_over_n, float* __restrict__ loss_slot,
                                                float* __restrict__ da, int vec, long bid, long nblocks,
                                                const float* __restrict__ gscale,
-                                               long split = (1l << 62), float target2 = 0.f) {
+                                               long split = (1l << 62), float target2 = 0.f,
+                                               float* __restrict__ part = nullptr) {
     __shared__ float red[4];
     float s = 0.f;
     const float gw = gscale ? w_over_n * *gscale : w_over_n;      // the gradient's factor (loss scaling); the value keeps w_over_n
@@ -57,7 +58,21 @@ __device__ __forceinline__ void pair_loss_body(const float* __restrict__ a, cons
         }
     }
     s = block_sum_256(s, red);
-    if (threadIdx.x == 0 && loss_slot) atomicAdd(loss_slot, s * w_over_n);
+    // the block's share of the value: a slot of its own when the caller gave room for them (summed in a fixed order by
+    // pair_loss_sum_kernel: two launches of a step report the same bits), else an atomic add into the loss word
+    if (threadIdx.x == 0) {
+        if (part) *part = s * w_over_n;
+        else if (loss_slot) atomicAdd(loss_slot, s * w_over_n);
+    }
+}
+
+// *loss_slot += sum of the blocks' shares, in a fixed order (thread t takes shares t, t + 256, ...; then the block's tree)
+__global__ __launch_bounds__(256) void pair_loss_sum_kernel(const float* __restrict__ part, int n, float* __restrict__ loss_slot) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) *loss_slot += s;
 }
 
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -73,6 +88,7 @@ constexpr int PL_MULTI = 64;
 struct PairMulti {
     int n, mode;
     float* loss_slot;
+    float* part;                  // nullable: a share per block (deterministic value), block b of the launch writes part[b]
     const float* gscale;
     int first[PL_MULTI + 1];
     struct E { const float* a; const float* b; float* da; long n, split; float w_over_n, target, target2; int vec; } e[PL_MULTI];
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(256) void pair_loss_multi_kernel(const PairMulti m)
     }
     const PairMulti::E& e = m.e[lo];
     pair_loss_body(e.a, e.b, e.target, e.n, m.mode, e.w_over_n, m.loss_slot, e.da, e.vec, (long)blockIdx.x - m.first[lo],
-                   (long)m.first[lo + 1] - m.first[lo], m.gscale, e.split, e.target2);
+                   (long)m.first[lo + 1] - m.first[lo], m.gscale, e.split, e.target2, m.part ? m.part + blockIdx.x : nullptr);
 }
 
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -424,11 +440,12 @@ extern "C" int stegan_pair_loss_fwd_bwd(const float* a, const float* b, float ta
     return STEGAN_OK;
 }
 
-extern "C" int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
-                                         const float* weight, const float* target, const float* target2,
-                                         const int64_t* split, int32_t mode, float* loss_slot, float* const* da,
-                                         void* stream) {
+static int pair_loss_multi_impl(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                const float* weight, const float* target, const float* target2, const int64_t* split,
+                                int32_t mode, float* loss_slot, float* const* da, float* partials, int64_t partials_floats,
+                                void* stream) {
     STEGAN_CHECK_ARG(n >= 1 && a && numel && weight && loss_slot && (mode == 0 || mode == 1));
+    int64_t used = 0;
     for (int base = 0; base < n; base += PL_MULTI) {
         PairMulti m;
         m.n = n - base < PL_MULTI ? n - base : PL_MULTI;
@@ -446,14 +463,37 @@ extern "C" int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const
             e.vec = (((uintptr_t)e.a | (uintptr_t)e.b | (uintptr_t)e.da) % 16) == 0;
             m.first[i] = blocks;
             int nb = nblk(e.vec ? (e.n + 3) / 4 : e.n);
-            if (nb > 128) nb = 128;                   // the launch as a whole fills the chip; fewer atomics per pair
+            if (nb > 128) nb = 128;                   // the launch as a whole fills the chip
             blocks += nb;
         }
         m.first[m.n] = blocks;
+        // the blocks' shares of the value: slots of their own when there is room (then a fixed-order sum), else atomics
+        m.part = (partials && used + blocks <= partials_floats) ? partials + used : nullptr;
         hipLaunchKernelGGL(pair_loss_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m);
+        if (m.part) {
+            hipLaunchKernelGGL(pair_loss_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)m.part, blocks,
+                               loss_slot);
+            used += blocks;
+        }
     }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
+}
+
+extern "C" int stegan_pair_loss_multi_ex(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                         const float* weight, const float* target, const float* target2,
+                                         const int64_t* split, int32_t mode, float* loss_slot, float* const* da,
+                                         void* stream) {
+    return pair_loss_multi_impl(n, a, b, numel, weight, target, target2, split, mode, loss_slot, da, nullptr, 0, stream);
+}
+
+extern "C" int stegan_pair_loss_multi_det(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,
+                                          const float* weight, const float* target, const float* target2,
+                                          const int64_t* split, int32_t mode, float* loss_slot, float* const* da,
+                                          float* partials, int64_t partials_floats, void* stream) {
+    STEGAN_CHECK_ARG(partials && partials_floats > 0);
+    return pair_loss_multi_impl(n, a, b, numel, weight, target, target2, split, mode, loss_slot, da, partials, partials_floats,
+                                stream);
 }
 
 extern "C" int stegan_pair_loss_multi(int32_t n, const float* const* a, const float* const* b, const int64_t* numel,

@@ -1584,8 +1584,11 @@ class _PairLossFn(torch.autograd.Function):
         loss = pooled_zeros((), af.device)
         need = ctx.needs_input_grad[0]
         da = torch.empty_like(af) if need else None
-        check(_lib.lib().stegan_pair_loss_fwd_bwd(_p(af), _p(bf), float(target), af.numel(), mode, 1.0, _p(loss), _p(da),
-                                                  _stream()), "stegan_pair_loss_fwd_bwd")
+        part = _workspace(af.device, 128)
+        check(_lib.lib().stegan_pair_loss_multi_det(1, _ptr_array([af]), _ptr_array([bf]) if bf is not None else None,
+                                                    (C.c_int64 * 1)(af.numel()), (C.c_float * 1)(1.0),
+                                                    (C.c_float * 1)(float(target)), None, None, mode, _p(loss), _ptr_array([da]),
+                                                    _p(part), part.numel(), _stream()), "stegan_pair_loss_multi_det")
         ctx.restore = restore
         ctx.save_for_backward(da)
         return loss
@@ -1631,15 +1634,19 @@ class _MultiPairLossFn(torch.autograd.Function):
         # every pair in ONE launch (stegan_pair_loss_multi), all adding into the one loss word
         m = len(afs)
         numel = (C.c_int64 * m)(*[t.numel() for t in afs])
+        # (stegan_pair_loss_multi_det: the blocks' shares of the value go through a scratch and a fixed-order sum -- no float
+        # atomics, the reported loss words of two launches agree to the bit)
+        fa = lambda xs: (C.c_float * m)(*[float(v) for v in xs])
+        part = _workspace(afs[0].device, 128 * m)
         if spec is None:
-            check(L.stegan_pair_loss_multi(m, _ptr_array(afs), _ptr_array(bfs), numel, float(target or 0.0), mode,
-                                           float(weight), _p(loss), _ptr_array(das), _stream()), "stegan_pair_loss_multi")
+            check(L.stegan_pair_loss_multi_det(m, _ptr_array(afs), _ptr_array(bfs), numel, fa([weight] * m),
+                                               fa([float(target or 0.0)] * m), None, None, mode, _p(loss), _ptr_array(das),
+                                               _p(part), part.numel(), _stream()), "stegan_pair_loss_multi_det")
         else:
             ws_, t1, t2, sp = spec
-            fa = lambda xs: (C.c_float * m)(*[float(v) for v in xs])
-            check(L.stegan_pair_loss_multi_ex(m, _ptr_array(afs), None, numel, fa(ws_), fa(t1), fa(t2),
-                                              (C.c_int64 * m)(*[int(v) for v in sp]), mode, _p(loss), _ptr_array(das),
-                                              _stream()), "stegan_pair_loss_multi_ex")
+            check(L.stegan_pair_loss_multi_det(m, _ptr_array(afs), None, numel, fa(ws_), fa(t1), fa(t2),
+                                               (C.c_int64 * m)(*[int(v) for v in sp]), mode, _p(loss), _ptr_array(das),
+                                               _p(part), part.numel(), _stream()), "stegan_pair_loss_multi_det")
         for af, da in zip(afs, das):
             key = (af.data_ptr(), af.numel())
             if fold and da is not None and key in _FM_FOLDABLE and key not in _FM_PENDING:

@@ -42,6 +42,8 @@ CASES = [
     (3, 256, 512, 37, 2, 1, 18, 16, 1, False, 24),
     (3, 8, 128, 15, 1, 1, 7, 1, 1, False, 24),       # k15 tap groups at T = 24 and 96
     (3, 8, 128, 15, 1, 1, 7, 1, 1, False, 96),
+    (300, 8, 32, 3, 1, 1, 2, 1, 1, False, 18),       # MPD p = 11 layer 0: more chunks than blocks, 20 of a chunk's 64 columns live
+    (5, 8, 128, 15, 1, 1, 7, 1, 1, False, 130),      # k15 first layer: three chunks a row, the last one 2 columns
 ]
 
 

@@ -98,7 +98,13 @@ __device__ __forceinline__ unsigned sdiv(unsigned n, const FastDiv& f) {     // 
     return (unsigned)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
 }
 
+#ifdef STEGAN_TILE_PAIR
+// diagnostic build (scripts/build_tile_pair.sh): blocks of at most 8 waves, 128 registers and 78 KB of LDS, so that two blocks --
+// of two launches on two streams -- are resident on a CU.  Measures what co-residency would buy.
+__global__ __launch_bounds__(512, 4) void conv_tile_kernel(const TK k) {
+#else
 __global__ __launch_bounds__(768) void conv_tile_kernel(const TK k) {
+#endif
     extern __shared__ __align__(16) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -632,7 +638,12 @@ bool tile_plan(const TileConvArgs& a, TK& k, size_t& lds) {
         if (XROW > 256) continue;
         // channel blocks per chunk: the reduction parts of a tile position split each chunk's k-steps evenly
         int NCB = c.WK == 4 ? 16 : (c.WK == 2 ? 8 : (o.ncb1 ? o.ncb1 : 8));
-        while (NCB > 4 && (NCB * a.ntaps * Mc + NCB * XROW) * 16 > 72 * 1024) NCB >>= 1;
+#ifdef STEGAN_TILE_PAIR
+        constexpr int STAGE_MAX = 38 * 1024;                    // two stages in half a CU's LDS
+#else
+        constexpr int STAGE_MAX = 72 * 1024;
+#endif
+        while (NCB > 4 && (NCB * a.ntaps * Mc + NCB * XROW) * 16 > STAGE_MAX) NCB >>= 1;
         if ((a.ntaps * (NCB / 4)) % c.WK != 0) continue;        // (uneven reduction parts)
         const int ipt = NCB * Mc / 64, xseg = XROW / 64;        // (NCB * Mc is a multiple of 192: whole periods of 3 items)
         const int nW = a.ntaps * ipt, nX = NCB * xseg;
@@ -641,8 +652,14 @@ bool tile_plan(const TileConvArgs& a, TK& k, size_t& lds) {
         const int nch = (a.C2 + 8 * NCB - 1) / (8 * NCB);
         const size_t epi = (size_t)ncons * (9 * 64 * 16 + 80 * 40 > 64 * 104 ? 9 * 64 * 16 + 80 * 40 : 64 * 104);
         // one block per CU may use the whole LDS; more tiles than CUs: two co-resident blocks
+#ifdef STEGAN_TILE_PAIR
+        const bool pair = true;
+        if (nthreads > 512) continue;
+        const size_t cap = 78 * 1024;
+#else
         const bool pair = false;    // (157 VGPRs: one block per CU; two co-resident blocks need <= 128)
         const size_t cap = pair ? 80 * 1024 : 160 * 1024;
+#endif
         const int ipc = (nW + 3) / 4 + (nX + 3) / 4;            // DMA instructions of the busiest producer wave per chunk
         int NS = o.ns ? o.ns : 4;
         if (NS > nch) NS = nch;

@@ -277,6 +277,17 @@ int stegan_wgrad_reduce_multi(int32_t n, const stegan_wgrad_reduce* items, void*
 int stegan_conv1d_bwd_weight_hxc(const stegan_conv_desc* d, const float* x, const uint16_t* xh, const float* dy,
                                  const uint16_t* dyh, float* dw, float* db, float* workspace, int64_t workspace_floats,
                                  const stegan_wgrad_reduce* prev, stegan_wgrad_reduce* next, void* stream);
+/* Up to 5 layers' weight gradients in ONE launch of the one-tile-per-CU kernel (round 5: the five convs of a generator block;
+ * the blocks of different layers follow each other on a CU, so their fixed phases overlap and the batch is cut in 2 slices
+ * instead of 4).  All or nothing: 1 = nothing enqueued and `prev` untouched unless EVERY layer is stride 1, ungrouped, with both
+ * operands as images and admitted by the kernel's plan.  On success (STEGAN_OK_TILE) next[i] is layer i's pending slab sum
+ * (slices == 0: none; run it with stegan_wgrad_reduce_multi or hand it on as `prev`), and every prev[j], j < n_prev, has been
+ * run: inside problem j's prologue when it is the 16-byte case, else by one reduce launch.  workspace[i]: layer i's slabs. */
+int stegan_conv1d_bwd_weight_multi_hxc(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                       const uint16_t* const* xh, const float* const* dy, const uint16_t* const* dyh,
+                                       float* const* dw, float* const* db, float* const* workspace,
+                                       const int64_t* workspace_floats, int32_t n_prev, const stegan_wgrad_reduce* prev,
+                                       stegan_wgrad_reduce* next, void* stream);
 int stegan_conv1d_fwd_multi_hx(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
                                const uint16_t* const* xh, const uint16_t* const* wfh, const float* const* scale,
                                const float* const* bias, const float* const* residual, float* const* y,

@@ -71,6 +71,7 @@ SIGNATURES = {
     "stegan_conv1d_bwd_weight_hx": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P],
     "stegan_conv1d_bwd_weight_hxd": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P],
     "stegan_conv1d_bwd_weight_hxc": [_D, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P],
+    "stegan_conv1d_bwd_weight_multi_hxc": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P, _P, _P],
     "stegan_wgrad_reduce_multi": [_I32, _P, _P],
     "stegan_conv1d_fwd_multi_hx": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "stegan_conv1d_bwd_data_multi_hx": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -49,3 +49,5 @@ struct TileWgradArgs {
 // 0: launched (*slices_out slabs to sum when > 1; 1: dW has been accumulated; *bias_done: db has been taken care of);
 // 1: declined; other: error status
 int stegan_tile_wgrad(const TileWgradArgs& a, int* slices_out, int* bias_done, hipStream_t stream);
+// n <= 5 layers in ONE launch (per-layer outputs in the arrays); 1: declined as a whole (nothing enqueued)
+int stegan_tile_wgrad_multi(int n, const TileWgradArgs* a, int* slices_out, int* bias_done, hipStream_t stream);

@@ -97,12 +97,14 @@ __device__ __forceinline__ unsigned g_sdiv(unsigned n, const FastDiv& f) {
     return (unsigned)((((unsigned long long)n * f.mul) >> 32) + n) >> f.shift;
 }
 
-__global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
+// (body shared by the single-problem kernel and the multi-problem one: `bid0` is the block's index inside its problem)
+__device__ __forceinline__ void conv_tile_wgrad_body(const GK& k, const unsigned bid0) {
     extern __shared__ __align__(16) char smem[];
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     typedef __attribute__((address_space(3))) s16x4* tr_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wave >= k.ncons + 4) return;          // (multi-problem launches size the block for the widest problem)
 
 #ifdef STEGAN_STAMPS
 #define GSTAMP(i_) if (k.stamps && threadIdx.x == 0) k.stamps[(size_t)blockIdx.x * 16 + (i_)] = __builtin_amdgcn_s_memtime();
@@ -113,13 +115,13 @@ __global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
 #define GPSTAMP(i_)
 #endif
     GSTAMP(0)
-    if ((int)blockIdx.x >= k.bias_first) {                            // bias-gradient blocks (bias_mode 2): one output channel each
+    if ((int)bid0 >= k.bias_first) {                                  // bias-gradient blocks (bias_mode 2): one output channel each
         if (tid >= 256) return;
-        bias_grad_body(k.dy, k.db, k.B, k.Cout, k.Tout, k.B, k.fdTb, k.bias_vec, (int)blockIdx.x - k.bias_first, 0);
+        bias_grad_body(k.dy, k.db, k.B, k.Cout, k.Tout, k.B, k.fdTb, k.bias_vec, (int)bid0 - k.bias_first, 0);
         return;
     }
     // block -> (slice, tile): tiles of one slice are neighbours (they share the slice's columns of dy / x in the L2s)
-    const unsigned bid = blockIdx.x;
+    const unsigned bid = bid0;
     const unsigned slice = g_sdiv(bid, k.fdTiles), tile = bid - slice * (unsigned)k.tiles;
     const unsigned nt = g_sdiv(tile, k.fdMT), mt = tile - nt * (unsigned)k.MT;
     const int m0 = (int)mt * GT, n0 = (int)nt * GT;                  // first output channel, first input channel
@@ -287,9 +289,10 @@ __global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
     // fp32 (fixed order) and adds it into db -- no extra blocks (which would each hold a whole block's LDS: 768 of them cost
     // three more rounds of blocks)
     if (k.bias_mode == 1 && slice == 0) {
-        const int cpb = (GT + k.NTl - 1) / k.NTl;                     // channels per tile block (<= ncons: host)
-        const int cl = (int)nt * cpb + wave;                          // channel inside the group
-        if (wave < cpb && cl < GT && m0 + cl < k.Cout) {
+        const int cpb = (GT + k.NTl - 1) / k.NTl;                     // channels per tile block (<= 2 ncons: host)
+        for (int cw = wave; cw < cpb; cw += ncw) {
+            const int cl = (int)nt * cpb + cw;                        // channel inside the group
+            if (cl >= GT || m0 + cl >= k.Cout) break;
             const int c = m0 + cl, T4 = k.Tout >> 2, n4 = k.B * T4;
             const float* base = k.dy + (size_t)c * k.Tout;
             const size_t bstr = (size_t)k.Cout * k.Tout;
@@ -429,6 +432,24 @@ __global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) {
 #undef GPSTAMP
 }
 
+__global__ __launch_bounds__(1024) void conv_tile_wgrad_kernel(const GK k) { conv_tile_wgrad_body(k, blockIdx.x); }
+
+// The weight gradients of up to GM_MAX layers in ONE grid (the five convs of a generator block: VERDICT r04 item 3).  Layer by
+// layer a launch is 256 blocks that all pay their fixed phases at the same time and a tail in which the chip drains; in one
+// grid the blocks of different layers follow each other on a CU, so set-up, first fetch and epilogue of one block overlap the
+// K loops of its neighbours' blocks on other CUs, and the batch can be cut into 2 slices instead of 4 (half the slabs).
+constexpr int GM_MAX = 5;
+struct GKMulti { int n; int first[GM_MAX + 1]; GK p[GM_MAX]; };
+static_assert(sizeof(GKMulti) <= 4096, "kernel argument segment limit");
+
+__global__ __launch_bounds__(1024) void conv_tile_wgrad_multi_kernel(const GKMulti m) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GM_MAX; ++i)
+        if (i < m.n && (int)blockIdx.x >= m.first[i]) pi = i;
+    conv_tile_wgrad_body(m.p[pi], blockIdx.x - (unsigned)m.first[pi]);
+}
+
 struct GOpts { int enable, debug, ns, target, nkg; };
 const GOpts& g_opts() {
     static const GOpts o = [] {
@@ -446,8 +467,9 @@ const GOpts& g_opts() {
 
 inline int g_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
-bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
+bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds, int target = 0) {
     const GOpts& o = g_opts();
+    if (target <= 0) target = o.target;
     if (!o.enable || !a.xh || !a.dyh || !a.dw) return false;
     if (a.Cin % 8 || a.Cout % 8 || a.Cin < 32 || a.Cout < 32) return false;
     if (a.Keff < 1 || a.Keff > KT_MAX) return false;
@@ -465,7 +487,7 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
     // batch slices: about one block per CU, whole chunks per slice, a workspace that holds the slabs
     const int chunks_all = a.B / CS;
     if (a.B % CS) return false;
-    int slices = (o.target + tiles - 1) / tiles;
+    int slices = (target + tiles - 1) / tiles;
     if (slices > chunks_all) slices = chunks_all;
     const int64_t slab = (int64_t)a.Cout * a.Cin * a.Keff;
     if (slices > 1 && (!a.partial || a.partial_floats < slab)) return false;
@@ -516,7 +538,7 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
         const int cpb = (GT + NTl - 1) / NTl;
         if (slices == 1 && cpb <= ncons && k.bias_vec && (int64_t)a.B * T <= 8192) k.bias_mode = 1;
         else if (slices > 1 && a.bias_in_reduce) k.bias_mode = 0;
-        else if (slices > 1 && cpb <= ncons && k.bias_vec && (int64_t)a.B * T <= 16384) k.bias_mode = 1;   // slice 0's blocks
+        else if (slices > 1 && cpb <= 2 * ncons && k.bias_vec && (int64_t)a.B * T <= 16384) k.bias_mode = 1;   // slice 0's blocks
         else k.bias_mode = 2;
     }
     k.bias_first = k.bias_mode == 2 ? tiles * slices : 0x7fffffff;
@@ -533,6 +555,45 @@ bool wgrad_plan(const TileWgradArgs& a, GK& k, size_t& lds) {
 static unsigned long long* g_wgrad_stamps = nullptr;
 extern "C" int stegan_tile_wgrad_debug_stamps(void* p) { g_wgrad_stamps = (unsigned long long*)p; return 0; }
 #endif
+
+// n layers in one launch; 1: not every layer is a shape for the tile kernel (nothing enqueued: the caller goes layer by layer)
+int stegan_tile_wgrad_multi(int n, const TileWgradArgs* a, int* slices_out, int* bias_done, hipStream_t stream) {
+    if (n < 1 || n > GM_MAX) return 1;
+    static const int mtarget = [] { const char* e = getenv("STEGAN_TILE_WGRAD_MULTI_TARGET"); return e ? atoi(e) : 128; }();
+    GKMulti m;
+    m.n = n; m.first[0] = 0;
+    size_t lds = 0;
+    int nthreads = 0;
+    for (int i = 0; i < n; ++i) {
+        size_t l = 0;
+        if (!wgrad_plan(a[i], m.p[i], l, mtarget)) return 1;
+        if (m.p[i].bias_mode == 2) return 1;          // (blocks behind the tiles: single launches only)
+        if (l > lds) lds = l;
+        if (m.p[i].nthreads > nthreads) nthreads = m.p[i].nthreads;
+#ifdef STEGAN_STAMPS
+        m.p[i].stamps = nullptr;
+#endif
+        m.first[i + 1] = m.first[i] + m.p[i].tiles * m.p[i].slices;
+    }
+    for (int i = n; i < GM_MAX; ++i) m.first[i + 1] = m.first[n];
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv_tile_wgrad_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_MAX);
+        (void)hipGetLastError();
+        attr = true;
+    }
+    if (g_opts().debug)
+        for (int i = 0; i < n; ++i)
+            fprintf(stderr, "plan-tile-wgrad-multi[%d/%d] Cin=%d Cout=%d K=%d T=%d | tiles=%d slices=%d nch=%d ncons=%d bias_mode=%d\n", i, n,
+                    a[i].Cin, a[i].Cout, a[i].Keff, a[i].Tout, m.p[i].tiles, m.p[i].slices, m.p[i].nch, m.p[i].ncons, m.p[i].bias_mode);
+    STEGAN_TIMED_LAUNCH(conv_tile_wgrad_multi_kernel, dim3((unsigned)m.first[n]), dim3((unsigned)nthreads), lds, stream, m);
+    { const hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return -(1000 + (int)e__); }
+    for (int i = 0; i < n; ++i) {
+        if (slices_out) slices_out[i] = m.p[i].slices;
+        if (bias_done) bias_done[i] = (!a[i].db || m.p[i].bias_mode != 0) ? 1 : 0;
+    }
+    return STEGAN_OK;
+}
 
 int stegan_tile_wgrad(const TileWgradArgs& a, int* slices_out, int* bias_done, hipStream_t stream) {
     GK k;

@@ -926,6 +926,74 @@ extern "C" int stegan_conv1d_bwd_weight_hxc(const stegan_conv_desc* d, const flo
     return rc;
 }
 
+// Up to 5 layers' weight gradients in ONE launch of the tile kernel (the five convs of a generator block, issued together by
+// ops._wgrad_flush).  All or nothing: return 1 (nothing enqueued, `prev` untouched) unless EVERY layer is a shape for the tile
+// kernel (stride 1, ungrouped, both operands as images, plan admits it); the caller then goes layer by layer.  On success
+// next[i] describes layer i's pending slab sum (slices == 0: none) and every prev[j] has been dealt with: prev[j], j < n, rides
+// in problem j's prologue when it is the 16-byte case, the others are summed by one reduce launch.
+extern "C" int stegan_conv1d_bwd_weight_multi_hxc(int32_t n, const stegan_conv_desc* const* descs, const float* const* x,
+                                                  const uint16_t* const* xh, const float* const* dy, const uint16_t* const* dyh,
+                                                  float* const* dw, float* const* db, float* const* workspace,
+                                                  const int64_t* workspace_floats, int32_t n_prev,
+                                                  const stegan_wgrad_reduce* prev, stegan_wgrad_reduce* next, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && n <= 5 && descs && x && xh && dy && dyh && dw && workspace && workspace_floats && next);
+    STEGAN_CHECK_ARG(n_prev >= 0 && (n_prev == 0 || prev));
+    static const bool no_xh = getenv("STEGAN_BF16_NO_XH") != nullptr;
+    if (no_xh) return 1;
+    TileWgradArgs ta[5];
+    int k_lo[5], K_eff[5];
+    bool rides[5] = {false, false, false, false, false};
+    for (int i = 0; i < n; ++i) {
+        const stegan_conv_desc* d = descs[i];
+        STEGAN_CHECK_ARG(d && x[i] && dy[i] && dw[i]);
+        const int rc = check_desc(d);
+        if (rc) return rc;
+        if (!xh[i] || !dyh[i] || d->stride != 1 || d->groups != 1 || d->Cin % 8 || d->Cout % 8) return 1;
+        if (d->in_act != STEGAN_ACT_NONE && d->in_act != STEGAN_ACT_RELU) return 1;
+        if ((int64_t)d->B * (d->Cin / 8) * d->Tin * 16 >= (int64_t)OOBW || (int64_t)d->B * (d->Cout / 8) * d->Tout * 16 >= (int64_t)OOBW) return 1;
+        K_eff[i] = wgh_live_taps(d, k_lo[i]);
+        if (K_eff[i] <= 0) return 1;
+        TileWgradArgs& t = ta[i];
+        t.xh = xh[i]; t.dyh = dyh[i]; t.dy = dy[i]; t.dw = dw[i]; t.db = db ? db[i] : nullptr;
+        t.partial = workspace[i]; t.partial_floats = workspace_floats[i];
+        t.B = d->B; t.Cin = d->Cin; t.Cout = d->Cout; t.K = d->K; t.dil = d->dilation; t.pad = d->pad; t.Tin = d->Tin;
+        t.Tout = d->Tout; t.ups = d->upsample == 2 ? 1 : 0; t.relu = d->in_act == STEGAN_ACT_RELU; t.k_lo = k_lo[i]; t.Keff = K_eff[i];
+        t.bias_in_reduce = 0;
+        t.prev_partial = nullptr; t.prev_dw = nullptr; t.prev_n4 = 0; t.prev_slices = 0;
+        if (i < n_prev) {
+            const stegan_wgrad_reduce& pv = prev[i];
+            if (pv.slices > 0 && pv.K_eff == pv.K && pv.k_lo == 0 && ((pv.per_tap * pv.K_eff) & 3) == 0 &&
+                (((uintptr_t)pv.partial | (uintptr_t)pv.dw) & 15) == 0) {
+                t.prev_partial = pv.partial; t.prev_dw = pv.dw; t.prev_n4 = pv.per_tap * pv.K_eff / 4; t.prev_slices = pv.slices;
+                rides[i] = true;
+            }
+        }
+    }
+    int sl[5] = {0, 0, 0, 0, 0}, bias_done[5] = {0, 0, 0, 0, 0};
+    const int trc = stegan_tile_wgrad_multi(n, ta, sl, bias_done, (hipStream_t)stream);
+    if (trc) return trc;                                    // 1: declined as a whole; < 0: launch error
+    for (int i = 0; i < n; ++i) {
+        stegan_wgrad_reduce& nx = next[i];
+        nx.partial = nullptr; nx.dw = nullptr; nx.per_tap = 0; nx.used_floats = 0; nx.slices = 0; nx.K = 0; nx.k_lo = 0; nx.K_eff = 0;
+        if (sl[i] > 1) {
+            nx.partial = workspace[i]; nx.dw = dw[i]; nx.per_tap = (int64_t)descs[i]->Cout * descs[i]->Cin;
+            nx.slices = sl[i]; nx.K = descs[i]->K; nx.k_lo = k_lo[i]; nx.K_eff = K_eff[i];
+            nx.used_floats = (int64_t)K_eff[i] * descs[i]->Cout * descs[i]->Cin * sl[i];
+        }
+        if (db && db[i] && !bias_done[i]) return STEGAN_E_ARG;      // (cannot happen: the multi plan refuses bias blocks)
+    }
+    // the pending sums that did not ride
+    stegan_wgrad_reduce rest[64];
+    int nr = 0;
+    for (int j = 0; j < n_prev && nr < 64; ++j)
+        if (prev[j].slices > 0 && !(j < n && rides[j])) rest[nr++] = prev[j];
+    if (nr) {
+        const int r2 = stegan_wgrad_reduce_multi(nr, rest, stream);
+        if (r2) return r2;
+    }
+    return STEGAN_OK_TILE;
+}
+
 // ---- the deferred slab sums of up to WRM_MAX layers in ONE launch (52 reduce launches a step become one per phase)
 namespace {
 constexpr int WRM_MAX = 48;

@@ -716,6 +716,54 @@ _WG_USED: dict = {}            # side streams forked since the last wgrad_join()
                                # stream that took no part in the current capture would be a capture-isolation error)
 
 
+# Round 5: the weight gradients of a batch (a generator block's five convs) as ONE launch of the tile kernel
+# (stegan_conv1d_bwd_weight_multi_hxc) + ONE launch for their slab sums, when every layer of the batch is a shape for it.
+WGRAD_MULTI = os.environ.get("STEGAN_WGRAD_MULTI", "1") == "1"
+
+
+def _wgrad_multi(batch) -> bool:
+    """True: the batch went out as one launch (and one reduce).  False: nothing was enqueued; go layer by layer."""
+    global LAST_CONV_KERNEL
+    n = len(batch)
+    if not (HALF and 2 <= n <= 5):
+        return False
+    dev = batch[0][0].device
+    st = _WG_ARENA.get(dev)
+    if st is None:
+        st = _WG_ARENA[dev] = [torch.empty(_WG_ARENA_FLOATS, device=dev, dtype=torch.float32), 0]
+    arena, used = st
+    descs, xs, xhs, dys, dyhs, dws, dbs, wss, wsf = [], [], [], [], [], [], [], [], []
+    off = used
+    for x, dy, cfg, dw, db in batch:
+        if cfg.stride != 1 or cfg.groups != 1 or not x.is_cuda:
+            return False
+        B, _, tin = x.shape
+        xh, dyh = _image_of(x, cfg.cin, tin), _image_of(dy, cfg.cout, dy.shape[2])
+        if xh is None or dyh is None:
+            return False
+        need = dw.numel() * 4                                   # room for four slices (the plan aims at two)
+        if off + need > arena.numel():
+            return False
+        descs.append(_desc(cfg, B, tin, dy.shape[2]))
+        xs.append(x); xhs.append(xh); dys.append(dy); dyhs.append(dyh); dws.append(dw); dbs.append(db)
+        wss.append(arena[off:off + need]); wsf.append(need)
+        off += (need + 63) & ~63
+    nxt = (WgradReduce * n)()
+    rc = _lib.lib().stegan_conv1d_bwd_weight_multi_hxc(
+        n, (C.POINTER(ConvDesc) * n)(*[C.pointer(d) for d in descs]), _ptr_array(xs), _ptr_array(xhs), _ptr_array(dys),
+        _ptr_array(dyhs), _ptr_array(dws), _ptr_array(dbs), _ptr_array(wss), (C.c_int64 * n)(*wsf), 0, None, nxt, _stream())
+    if rc == 1:
+        return False
+    check(0 if rc == OK_TILE else rc, "stegan_conv1d_bwd_weight_multi_hxc")
+    LAST_CONV_KERNEL = "tile"
+    st[1] = off
+    items = [nxt[i] for i in range(n) if nxt[i].slices > 0]
+    if items:
+        arr = (WgradReduce * len(items))(*items)
+        check(_lib.lib().stegan_wgrad_reduce_multi(len(items), arr, _stream()), "stegan_wgrad_reduce_multi")
+    return True
+
+
 def _wgrad_flush() -> None:
     if not _WG_PENDING:
         return
@@ -726,11 +774,12 @@ def _wgrad_flush() -> None:
     _WG_USED[side.cuda_stream] = side
     side.wait_stream(torch.cuda.current_stream())       # ONE cross-queue edge for the whole batch (11 us each inside a
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
-        chain = [None] if WGRAD_CHAIN else None         # the slab sum of layer i rides in the launch of layer i + 1
-        for x, dy, cfg, dw, db in _WG_PENDING:
-            conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
-        if chain is not None:
-            wgrad_chain_end(chain)
+        if not (WGRAD_MULTI and _wgrad_multi(_WG_PENDING)):
+            chain = [None] if WGRAD_CHAIN else None     # the slab sum of layer i rides in the launch of layer i + 1
+            for x, dy, cfg, dw, db in _WG_PENDING:
+                conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
+            if chain is not None:
+                wgrad_chain_end(chain)
     _WG_KEEP.extend((x, dy) for x, dy, _, _, _ in _WG_PENDING)
     _WG_PENDING.clear()
 

@@ -719,6 +719,7 @@ _WG_USED: dict = {}            # side streams forked since the last wgrad_join()
 # Round 5: the weight gradients of a batch (a generator block's five convs) as ONE launch of the tile kernel
 # (stegan_conv1d_bwd_weight_multi_hxc) + ONE launch for their slab sums, when every layer of the batch is a shape for it.
 WGRAD_MULTI = os.environ.get("STEGAN_WGRAD_MULTI", "1") == "1"
+_WG_STREAM_PENDING: dict = {}       # stream -> [(WgradReduce, dw kept alive)]: slab sums waiting for the next launch on that stream
 
 
 def _wgrad_multi(batch) -> bool:
@@ -748,19 +749,26 @@ def _wgrad_multi(batch) -> bool:
         xs.append(x); xhs.append(xh); dys.append(dy); dyhs.append(dyh); dws.append(dw); dbs.append(db)
         wss.append(arena[off:off + need]); wsf.append(need)
         off += (need + 63) & ~63
+    # the slab sums the previous launch ON THIS STREAM left pending ride in this launch's prologue; this launch's own wait for
+    # the next one on the stream, or for wgrad_join (one launch for all that are left)
+    sid = torch.cuda.current_stream().cuda_stream
+    prev = _WG_STREAM_PENDING.pop(sid, [])
+    parr = (WgradReduce * max(1, len(prev)))(*[it for it, _ in prev])
     nxt = (WgradReduce * n)()
     rc = _lib.lib().stegan_conv1d_bwd_weight_multi_hxc(
         n, (C.POINTER(ConvDesc) * n)(*[C.pointer(d) for d in descs]), _ptr_array(xs), _ptr_array(xhs), _ptr_array(dys),
-        _ptr_array(dyhs), _ptr_array(dws), _ptr_array(dbs), _ptr_array(wss), (C.c_int64 * n)(*wsf), 0, None, nxt, _stream())
+        _ptr_array(dyhs), _ptr_array(dws), _ptr_array(dbs), _ptr_array(wss), (C.c_int64 * n)(*wsf), len(prev),
+        parr if prev else None, nxt, _stream())
     if rc == 1:
+        if prev:
+            _WG_STREAM_PENDING[sid] = prev                      # untouched: still pending
         return False
     check(0 if rc == OK_TILE else rc, "stegan_conv1d_bwd_weight_multi_hxc")
     LAST_CONV_KERNEL = "tile"
     st[1] = off
-    items = [nxt[i] for i in range(n) if nxt[i].slices > 0]
+    items = [(WgradReduce.from_buffer_copy(nxt[i]), dws[i]) for i in range(n) if nxt[i].slices > 0]
     if items:
-        arr = (WgradReduce * len(items))(*items)
-        check(_lib.lib().stegan_wgrad_reduce_multi(len(items), arr, _stream()), "stegan_wgrad_reduce_multi")
+        _WG_STREAM_PENDING[sid] = items
     return True
 
 
@@ -774,12 +782,14 @@ def _wgrad_flush() -> None:
     _WG_USED[side.cuda_stream] = side
     side.wait_stream(torch.cuda.current_stream())       # ONE cross-queue edge for the whole batch (11 us each inside a
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
-        if not (WGRAD_MULTI and _wgrad_multi(_WG_PENDING)):
-            chain = [None] if WGRAD_CHAIN else None     # the slab sum of layer i rides in the launch of layer i + 1
-            for x, dy, cfg, dw, db in _WG_PENDING:
-                conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
-            if chain is not None:
-                wgrad_chain_end(chain)
+        for i in range(0, len(_WG_PENDING), 5):          # (a multi-problem launch takes five layers)
+            part = _WG_PENDING[i:i + 5]
+            if not (WGRAD_MULTI and _wgrad_multi(part)):
+                chain = [None] if WGRAD_CHAIN else None     # the slab sum of layer i rides in the launch of layer i + 1
+                for x, dy, cfg, dw, db in part:
+                    conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
+                if chain is not None:
+                    wgrad_chain_end(chain)
     _WG_KEEP.extend((x, dy) for x, dy, _, _, _ in _WG_PENDING)
     _WG_PENDING.clear()
 
@@ -819,6 +829,9 @@ def wgrad_join() -> None:
         if key != cur.cuda_stream:
             cur.wait_stream(s_)
     _SINK_STREAMS.clear()
+    for items in _WG_STREAM_PENDING.values():       # slab sums no later launch took along: with the deferred ones, one launch
+        _WG_DEFERRED.extend(items)
+    _WG_STREAM_PENDING.clear()
     _wgrad_reduce_flush()          # behind every weight-gradient launch of the phase: their slabs' sums, one launch
 
 
@@ -829,6 +842,7 @@ def wgrad_abort() -> None:
         torch.cuda.synchronize()
     _WG_ON[0] = False
     _WG_PENDING.clear(); _WG_KEEP.clear(); _WG_USED.clear(); _SINK_STREAMS.clear(); _WG_DEFERRED.clear()
+    _WG_STREAM_PENDING.clear()
     for st in _WG_ARENA.values():
         st[1] = 0
     fm_fold_abort()

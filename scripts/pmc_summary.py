@@ -12,7 +12,7 @@ The raw per-dispatch rows of the three passes are copied beside the summary (gzi
 import collections, csv, glob, gzip, io, json, shutil, sys
 
 FAMILIES = [("conv_tile_kernel", ("conv_tile_kernel",)),
-            ("conv_tile_wgrad_kernel", ("conv_tile_wgrad_kernel",)),
+            ("conv_tile_wgrad_kernel", ("conv_tile_wgrad_kernel", "conv_tile_wgrad_multi_kernel")),
             ("wgrad_small", ("wgrad_small_kernel", "wgrad_small_reduce_kernel")),
             ("conv_bf16_kernel", ("conv_bf16_kernel", "conv_bf16_multi_kernel")),
             ("conv_wgrad_bf16", ("conv_wgrad_bf16_img_kernel", "conv_wgrad_bf16_one_kernel", "conv_wgrad_bf16_kernel")),

@@ -1,5 +1,7 @@
+"""A generator block's five weight gradients: chained per-layer launches (ops.WGRAD_CHAIN) against ONE multi-layer launch of the
+tile kernel (ops._wgrad_multi, stegan_conv1d_bwd_weight_multi_hxc).  STEGAN_PLAN_DEBUG=1 prints the plans."""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/scripts")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ste_gan_amd import ops
 from tile_microbench import image

@@ -661,7 +661,10 @@ bool tile_plan(const TileConvArgs& a, TK& k, size_t& lds) {
         const size_t cap = pair ? 80 * 1024 : 160 * 1024;
 #endif
         const int ipc = (nW + 3) / 4 + (nX + 3) / 4;            // DMA instructions of the busiest producer wave per chunk
-        int NS = o.ns ? o.ns : 4;
+        // ring stages: TWO.  Four (as many as fit the LDS) are no faster per layer (sum of the 24 hot-path layers 302 vs 303 us)
+        // and cost the STEP 1.7 % (5.59 -> 5.50 ms): with half the LDS left free, blocks of the small kernels of the other
+        // streams (LayerNorm, attention, activation derivatives, the strided convs) are resident beside a tile block
+        int NS = o.ns ? o.ns : 2;
         if (NS > nch) NS = nch;
         if (NS < 2) NS = 2;
         while (NS > 2 && ((size_t)NS * stage > cap || (NS - 1) * ipc > 48)) --NS;

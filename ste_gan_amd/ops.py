@@ -784,12 +784,15 @@ def _wgrad_flush() -> None:
     with torch.cuda.stream(side):                       # captured graph: scripts/graph_edge_cost.py)
         for i in range(0, len(_WG_PENDING), 5):          # (a multi-problem launch takes five layers)
             part = _WG_PENDING[i:i + 5]
-            if not (WGRAD_MULTI and _wgrad_multi(part)):
-                chain = [None] if WGRAD_CHAIN else None     # the slab sum of layer i rides in the launch of layer i + 1
-                for x, dy, cfg, dw, db in part:
-                    conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
-                if chain is not None:
-                    wgrad_chain_end(chain)
+            # layers the tile kernel cannot take (the generator's 8-channel output conv) must not cost the others their launch
+            wide = [t for t in part if min(t[2].cin, t[2].cout) >= 32 and t[2].stride == 1 and t[2].groups == 1]
+            if WGRAD_MULTI and len(wide) >= 2 and _wgrad_multi(wide):
+                part = [t for t in part if not any(t is w for w in wide)]
+            chain = [None] if WGRAD_CHAIN else None         # the slab sum of layer i rides in the launch of layer i + 1
+            for x, dy, cfg, dw, db in part:
+                conv1d_bwd_weight(x, dy, cfg, dw, db, defer=True, chain=chain)
+            if chain is not None:
+                wgrad_chain_end(chain)
     _WG_KEEP.extend((x, dy) for x, dy, _, _, _ in _WG_PENDING)
     _WG_PENDING.clear()
 

@@ -373,6 +373,12 @@ int stegan_spectral_norm_fwd_multi(int32_t n, const float* const* w_orig, float*
 int stegan_spectral_norm_bwd(const float* w_orig, const float* dw, const float* u, const float* v,
                              const float* sigma, float* workspace, float* dw_orig, int32_t rows, int32_t cols,
                              void* stream);
+/* the same for n layers (or n calls on one layer: fake and real pass) as ONE launch per stage -- the transforms feed the
+ * optimiser only, so a step can run all of them when its gradients are finalized (round 5: 16 launches -> 2). */
+int stegan_spectral_norm_bwd_acc_multi(int32_t n, const float* const* w_orig, const float* const* dw, const float* const* u,
+                                       const float* const* v, const float* const* sigma, float* const* workspace,
+                                       float* const* dw_orig, const int32_t* rows, const int32_t* cols, int32_t accumulate,
+                                       void* stream);
 /* accumulate != 0: dw_orig += ... (the parameter's gradient arena view: no autograd accumulation kernel afterwards) */
 int stegan_spectral_norm_bwd_acc(const float* w_orig, const float* dw, const float* u, const float* v,
                                  const float* sigma, float* workspace, float* dw_orig, int32_t rows, int32_t cols,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "stegan_spectral_norm_fwd_multi": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_spectral_norm_bwd": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P],
     "stegan_spectral_norm_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "stegan_spectral_norm_bwd_acc_multi": [_I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P],
     "stegan_mpd_fold_fwd": [_P, _P, _I32, _I32, _I32, _I32, _P],
     "stegan_mpd_fold_bwd": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "stegan_mpd_fold_fwd_multi": [_P, _P, _I32, _I32, _I32, _P, _I32, _P],

@@ -324,9 +324,9 @@ __global__ __launch_bounds__(1024) void sn_finish_multi_kernel(const SNMulti a) 
 }
 
 // dW_orig = dw/sigma - (<dw, W>/sigma^2) u v^T      two kernels: row dots -> total, then elementwise
-__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ W, const float* __restrict__ dw,
-                                                         float* __restrict__ rowdot, int R, int Cn) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void sn_bwd_dot_body(const float* __restrict__ W, const float* __restrict__ dw,
+                                                float* __restrict__ rowdot, int R, int Cn, int bx) {
+    const int row = bx * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const float* wr = W + (size_t)row * Cn;
@@ -345,10 +345,15 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict
     if (lane == 0) rowdot[row] = a;
 }
 
-__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw, const float* __restrict__ rowdot,
-                                                           const float* __restrict__ u, const float* __restrict__ v,
-                                                           const float* __restrict__ sigma, float* __restrict__ dW,
-                                                           int R, int Cn, int accumulate) {
+__global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const float* __restrict__ W, const float* __restrict__ dw,
+                                                         float* __restrict__ rowdot, int R, int Cn) {
+    sn_bwd_dot_body(W, dw, rowdot, R, Cn, blockIdx.x);
+}
+
+__device__ __forceinline__ void sn_bwd_apply_body(const float* __restrict__ dw, const float* __restrict__ rowdot,
+                                                  const float* __restrict__ u, const float* __restrict__ v,
+                                                  const float* __restrict__ sigma, float* __restrict__ dW,
+                                                  int R, int Cn, int accumulate, int bx, int nbx) {
     __shared__ float tot;
     if (threadIdx.x < 64) {            // every block re-reduces the R row dots (R <= 1024): deterministic, no atomics
         float a = 0.f;
@@ -360,11 +365,46 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restri
     const float sg = *sigma;
     const float k = tot / (sg * sg), inv = 1.f / sg;
     const long total = (long)R * Cn;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)bx * 256 + threadIdx.x; i < total; i += (long)nbx * 256) {
         const int j = (int)(i % Cn), r = (int)(i / Cn);
         const float gv = dw[i] * inv - k * u[r] * v[j];
         dW[i] = accumulate ? dW[i] + gv : gv;               // accumulate: straight into the parameter's .grad arena view
     }
+}
+
+__global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const float* __restrict__ dw, const float* __restrict__ rowdot,
+                                                           const float* __restrict__ u, const float* __restrict__ v,
+                                                           const float* __restrict__ sigma, float* __restrict__ dW,
+                                                           int R, int Cn, int accumulate) {
+    sn_bwd_apply_body(dw, rowdot, u, v, sigma, dW, R, Cn, accumulate, blockIdx.x, gridDim.x);
+}
+
+// the same for up to SNB_MAX layers in one launch per stage (round 5: the scale discriminator's eight spectral-norm backward
+// transforms of a step -- four layers, fake and real pass -- used to be 16 launches inside its backward pass; the weight
+// gradients they produce are read by the optimiser only, so they run as two launches when the gradients are finalized)
+constexpr int SNB_MAX = 8;
+struct SNBwdMulti {
+    int n;
+    int fdot[SNB_MAX + 1], fapp[SNB_MAX + 1];
+    struct E { const float* W; const float* dw; const float* u; const float* v; const float* sigma; float* rowdot; float* dW;
+               int R, Cn, accumulate; } e[SNB_MAX];
+};
+__global__ __launch_bounds__(256) void sn_bwd_dot_multi_kernel(const SNBwdMulti a) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < SNB_MAX; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.fdot[i]) pi = i;
+    const SNBwdMulti::E& e = a.e[pi];
+    sn_bwd_dot_body(e.W, e.dw, e.rowdot, e.R, e.Cn, (int)blockIdx.x - a.fdot[pi]);
+}
+__global__ __launch_bounds__(256) void sn_bwd_apply_multi_kernel(const SNBwdMulti a) {
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < SNB_MAX; ++i)
+        if (i < a.n && (int)blockIdx.x >= a.fapp[i]) pi = i;
+    const SNBwdMulti::E& e = a.e[pi];
+    sn_bwd_apply_body(e.dw, e.rowdot, e.u, e.v, e.sigma, e.dW, e.R, e.Cn, e.accumulate, (int)blockIdx.x - a.fapp[pi],
+                      a.fapp[pi + 1] - a.fapp[pi]);
 }
 
 inline int nblocks(long total) {
@@ -524,6 +564,35 @@ extern "C" int stegan_spectral_norm_bwd_acc(const float* w_orig, const float* dw
     hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, w_orig, dw, workspace, rows, cols);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(nblocks((long)rows * cols)), dim3(256), 0, s, dw, workspace, u, v, sigma,
                        dw_orig, rows, cols, accumulate);
+    STEGAN_LAUNCH_CHECK();
+    return STEGAN_OK;
+}
+
+extern "C" int stegan_spectral_norm_bwd_acc_multi(int32_t n, const float* const* w_orig, const float* const* dw,
+                                                  const float* const* u, const float* const* v, const float* const* sigma,
+                                                  float* const* workspace, float* const* dw_orig, const int32_t* rows,
+                                                  const int32_t* cols, int32_t accumulate, void* stream) {
+    STEGAN_CHECK_ARG(n >= 1 && w_orig && dw && u && v && sigma && workspace && dw_orig && rows && cols);
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += SNB_MAX) {
+        SNBwdMulti a;
+        a.n = n - base < SNB_MAX ? n - base : SNB_MAX;
+        a.fdot[0] = 0; a.fapp[0] = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int j = base + i;
+            STEGAN_CHECK_ARG(w_orig[j] && dw[j] && u[j] && v[j] && sigma[j] && workspace[j] && dw_orig[j] && rows[j] > 0 && cols[j] > 0);
+            SNBwdMulti::E& e = a.e[i];
+            e.W = w_orig[j]; e.dw = dw[j]; e.u = u[j]; e.v = v[j]; e.sigma = sigma[j]; e.rowdot = workspace[j]; e.dW = dw_orig[j];
+            e.R = rows[j]; e.Cn = cols[j]; e.accumulate = accumulate;
+            int nb = nblocks((long)rows[j] * cols[j]);
+            if (nb > 1024) nb = 1024;
+            a.fdot[i + 1] = a.fdot[i] + ceil_div(rows[j], 4);
+            a.fapp[i + 1] = a.fapp[i] + nb;
+        }
+        for (int i = a.n; i < SNB_MAX; ++i) { a.fdot[i + 1] = a.fdot[a.n]; a.fapp[i + 1] = a.fapp[a.n]; }
+        hipLaunchKernelGGL(sn_bwd_dot_multi_kernel, dim3((unsigned)a.fdot[a.n]), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(sn_bwd_apply_multi_kernel, dim3((unsigned)a.fapp[a.n]), dim3(256), 0, s, a);
+    }
     STEGAN_LAUNCH_CHECK();
     return STEGAN_OK;
 }

@@ -836,6 +836,7 @@ def wgrad_join() -> None:
         _WG_DEFERRED.extend(items)
     _WG_STREAM_PENDING.clear()
     _wgrad_reduce_flush()          # behind every weight-gradient launch of the phase: their slabs' sums, one launch
+    sn_bwd_flush()                 # ... and the spectral-norm transforms of the raw gradients those launches produced
 
 
 def wgrad_abort() -> None:
@@ -846,6 +847,7 @@ def wgrad_abort() -> None:
     _WG_ON[0] = False
     _WG_PENDING.clear(); _WG_KEEP.clear(); _WG_USED.clear(); _SINK_STREAMS.clear(); _WG_DEFERRED.clear()
     _WG_STREAM_PENDING.clear()
+    _SN_PENDING.clear()
     for st in _WG_ARENA.values():
         st[1] = 0
     fm_fold_abort()
@@ -1368,12 +1370,45 @@ class _SNConvFn(torch.autograd.Function):
             rows = w_orig.shape[0]
             ws = torch.empty(rows, device=dy.device, dtype=torch.float32)
             dw_orig = torch.empty_like(w_orig) if sink is None else sink[0]
-            check(_lib.lib().stegan_spectral_norm_bwd_acc(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
-                                                          rows, w_orig.numel() // rows, 0 if sink is None else 1, _stream()),
-                  "stegan_spectral_norm_bwd_acc")
+            if sink is not None and SN_BWD_DEFER:
+                # sink mode: only the optimiser reads this gradient -- the transform waits for wgrad_join (finalize_grads),
+                # where all of a step's run as one launch per stage (sn_bwd_flush)
+                _SN_PENDING.append((w_orig, dw, u, v, sigma, ws, dw_orig, rows, w_orig.numel() // rows))
+            else:
+                check(_lib.lib().stegan_spectral_norm_bwd_acc(_p(w_orig), _p(dw), _p(u), _p(v), _p(sigma), _p(ws), _p(dw_orig),
+                                                              rows, w_orig.numel() // rows, 0 if sink is None else 1, _stream()),
+                      "stegan_spectral_norm_bwd_acc")
             if sink is not None:
-                dw_orig = db = None              # already in the gradient arena
+                dw_orig = db = None              # already in the gradient arena (or on its way: sn_bwd_flush)
         return dx, dw_orig, None, None, db, None, None, None, None, None, None
+
+
+SN_BWD_DEFER = os.environ.get("STEGAN_SN_BWD_DEFER", "1") == "1"
+_SN_PENDING: list = []          # (w_orig, raw dw, u, v, sigma, workspace, dW arena view, rows, cols) in backward order
+
+
+def sn_bwd_flush() -> None:
+    """The spectral-norm backward transforms a backward pass left pending (sink mode), on the current stream, which the caller
+    has ordered behind every weight-gradient launch (wgrad_join).  Two passes through one layer (fake, real) add into the SAME
+    arena view with different u / v / sigma: they go into different launches, in the order the backward pass produced them, so
+    the sums are formed exactly as by the per-layer launches (bit-identical)."""
+    if not _SN_PENDING:
+        return
+    rounds, seen = [], {}
+    for e in _SN_PENDING:
+        r = seen.get(e[6].data_ptr(), 0)
+        seen[e[6].data_ptr()] = r + 1
+        while len(rounds) <= r:
+            rounds.append([])
+        rounds[r].append(e)
+    i32 = lambda xs: (C.c_int32 * len(xs))(*xs)
+    for grp in rounds:
+        n = len(grp)
+        col = lambda k: _ptr_array([e[k] for e in grp])
+        check(_lib.lib().stegan_spectral_norm_bwd_acc_multi(n, col(0), col(1), col(2), col(3), col(4), col(5), col(6),
+                                                            i32([e[7] for e in grp]), i32([e[8] for e in grp]), 1, _stream()),
+              "stegan_spectral_norm_bwd_acc_multi")
+    _SN_PENDING.clear()
 
 
 def sn_conv1d(x, w_orig, u, v, bias, cfg: ConvCfg, training: bool, prepared=None, pre=None, sink=None, fuse=None) -> Tensor:
